@@ -1,0 +1,232 @@
+"""Deterministic inputs shared by the golden-vector generator and the tests.
+
+Nothing here imports the reference.  Everything is derived from numpy RandomState streams
+so that the generator (build container, reference importable) and the tests (GPU box, no
+reference) regenerate bit-identical weights, batches and sampling noise from a seed.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+# ---------------------------------------------------------------------------------------
+# shape configs
+# ---------------------------------------------------------------------------------------
+SHAPES = {
+    # name: dict(stoch, discrete, deter, hidden, units, A, cnn_depth, B, T, H, actor_dist, imag_gradient)
+    "tiny": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
+                 actor_dist="normal", imag_gradient="dynamics", encoder="cnn"),
+    "tiny_onehot": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=5, cnn_depth=2, B=3, T=6, H=4,
+                        actor_dist="onehot", imag_gradient="reinforce", encoder="cnn"),
+    "tiny_proprio": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
+                         actor_dist="normal", imag_gradient="dynamics", encoder="mlp",
+                         enc_mlp_units=32, enc_mlp_layers=2),
+    "cfg1": dict(stoch=32, discrete=32, deter=512, hidden=512, units=512, A=6, cnn_depth=32, B=16, T=64, H=15,
+                 actor_dist="normal", imag_gradient="dynamics", encoder="mlp",
+                 enc_mlp_units=1024, enc_mlp_layers=5),
+    "cfg2": dict(stoch=32, discrete=32, deter=512, hidden=512, units=512, A=6, cnn_depth=32, B=16, T=64, H=15,
+                 actor_dist="normal", imag_gradient="dynamics", encoder="cnn"),
+    "cfg3": dict(stoch=32, discrete=32, deter=1024, hidden=512, units=512, A=18, cnn_depth=32, B=32, T=64, H=15,
+                 actor_dist="onehot", imag_gradient="reinforce", encoder="cnn"),
+}
+# walker_walk proprio keys, in the order the reference's obs_space dict would list them
+PROPRIO_KEYS: Tuple[Tuple[str, int], ...] = (("orientations", 14), ("height", 1), ("velocity", 9))
+
+
+def path_config(name: str):
+    """oracle.PathConfig for a named shape config."""
+    from oracle.dv3_oracle import PathConfig
+
+    s = SHAPES[name]
+    kw = dict(
+        stoch=s["stoch"], discrete=s["discrete"], deter=s["deter"], hidden=s["hidden"], units=s["units"],
+        num_actions=s["A"], cnn_depth=s["cnn_depth"], actor_dist=s["actor_dist"],
+        imag_gradient=s["imag_gradient"], horizon=s["H"], encoder=s["encoder"],
+    )
+    if s["encoder"] == "mlp":
+        kw.update(mlp_keys=PROPRIO_KEYS, enc_mlp_units=s["enc_mlp_units"], enc_mlp_layers=s["enc_mlp_layers"])
+    return PathConfig(**kw)
+
+
+# ---------------------------------------------------------------------------------------
+# parameter shapes by reference state_dict name
+# ---------------------------------------------------------------------------------------
+def param_shapes(name: str) -> Dict[str, Tuple[int, ...]]:
+    s = SHAPES[name]
+    S, D, De, Hd, U, A, d = s["stoch"], s["discrete"], s["deter"], s["hidden"], s["units"], s["A"], s["cnn_depth"]
+    SD, F = S * D, S * D + De
+    sh: Dict[str, Tuple[int, ...]] = {}
+
+    def ln(prefix, n):
+        sh[prefix + ".weight"] = (n,)
+        sh[prefix + ".bias"] = (n,)
+
+    def mlp(prefix, nm, layers, inp, units):
+        for i in range(layers):
+            sh[f"{prefix}layers.{nm}_linear{i}.weight"] = (units, inp if i == 0 else units)
+            ln(f"{prefix}layers.{nm}_norm{i}", units)
+
+    if s["encoder"] == "cnn":
+        E = d * 8 * 16
+        cin = 3
+        for i in range(4):
+            cout = d * 2**i
+            sh[f"encoder._cnn.layers.{3 * i}.weight"] = (cout, cin, 4, 4)
+            ln(f"encoder._cnn.layers.{3 * i + 1}.norm", cout)
+            cin = cout
+    else:
+        E = s["enc_mlp_units"]
+        mlp("encoder._mlp.", "Encoder", s["enc_mlp_layers"], sum(w for _, w in PROPRIO_KEYS), E)
+    sh["dynamics.W"] = (1, De)
+    sh["dynamics._img_in_layers.0.weight"] = (Hd, SD + A)
+    ln("dynamics._img_in_layers.1", Hd)
+    sh["dynamics._cell.layers.GRU_linear.weight"] = (3 * De, Hd + De)
+    ln("dynamics._cell.layers.GRU_norm", 3 * De)
+    sh["dynamics._img_out_layers.0.weight"] = (Hd, De)
+    ln("dynamics._img_out_layers.1", Hd)
+    sh["dynamics._obs_out_layers.0.weight"] = (Hd, De + E)
+    ln("dynamics._obs_out_layers.1", Hd)
+    sh["dynamics._imgs_stat_layer.weight"] = (SD, Hd)
+    sh["dynamics._imgs_stat_layer.bias"] = (SD,)
+    sh["dynamics._obs_stat_layer.weight"] = (SD, Hd)
+    sh["dynamics._obs_stat_layer.bias"] = (SD,)
+    if s["encoder"] == "cnn":
+        sh["heads.decoder._cnn._linear_layer.weight"] = (E, F)
+        sh["heads.decoder._cnn._linear_layer.bias"] = (E,)
+        cin = d * 8
+        for i in range(3):
+            sh[f"heads.decoder._cnn.layers.{3 * i}.weight"] = (cin, cin // 2, 4, 4)
+            ln(f"heads.decoder._cnn.layers.{3 * i + 1}.norm", cin // 2)
+            cin //= 2
+        sh["heads.decoder._cnn.layers.9.weight"] = (cin, 3, 4, 4)
+        sh["heads.decoder._cnn.layers.9.bias"] = (3,)
+    else:
+        mlp("heads.decoder._mlp.", "Decoder", s["enc_mlp_layers"], F, E)
+        for k, w in PROPRIO_KEYS:
+            sh[f"heads.decoder._mlp.mean_layer.{k}.weight"] = (w, E)
+            sh[f"heads.decoder._mlp.mean_layer.{k}.bias"] = (w,)
+    for pre, nm, out in (("heads.reward.", "Reward", 255), ("heads.cont.", "Cont", 1)):
+        mlp(pre, nm, 2, F, U)
+        sh[pre + "mean_layer.weight"] = (out, U)
+        sh[pre + "mean_layer.bias"] = (out,)
+    mlp("actor.", "Actor", 2, F, U)
+    sh["actor.mean_layer.weight"] = (A, U)
+    sh["actor.mean_layer.bias"] = (A,)
+    if s["actor_dist"] == "normal":
+        sh["actor.std_layer.weight"] = (A, U)
+        sh["actor.std_layer.bias"] = (A,)
+    for pre in ("value.", "_slow_value."):
+        mlp(pre, "Value", 2, F, U)
+        sh[pre + "mean_layer.weight"] = (255, U)
+        sh[pre + "mean_layer.bias"] = (255,)
+    return sh
+
+
+def make_weights(name: str, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Deterministic fp32 weights, one numpy stream per parameter name.
+
+    Not the reference's init scheme (that one needs torch's RNG); any weights pin parity.
+    Scales follow tools.weight_init (tools.py:890-917) so activations sit in a realistic
+    regime; LN affine and biases are perturbed so that no term is trivially 0 or 1.
+    """
+    out = {}
+    for k, shp in param_shapes(name).items():
+        rs = np.random.RandomState((zlib.crc32(k.encode()) + 7919 * seed) & 0x7FFFFFFF)
+        if k == "dynamics.W":
+            w = 0.5 * rs.randn(*shp)
+        elif len(shp) == 1:
+            if k.endswith(".weight"):  # every 1-D ".weight" on the path is a LayerNorm scale
+                w = 1.0 + 0.1 * rs.randn(*shp)
+            else:
+                w = 0.1 * rs.randn(*shp)
+        else:
+            if len(shp) == 4:
+                # Conv2d weight [out,in,kh,kw]; ConvTranspose2d weight [in,out,kh,kw]; fan avg is symmetric
+                fan = (shp[0] + shp[1]) * shp[2] * shp[3] / 2.0
+            else:
+                fan = (shp[0] + shp[1]) / 2.0
+            w = rs.randn(*shp) * np.sqrt(1.0 / fan)
+            if "mean_layer" in k and ("reward" in k or "value" in k):
+                w *= 0.3  # reference zero-inits these (outscale 0.0); keep them small but non-zero
+        out[k] = w.astype(np.float32)
+    return out
+
+
+def make_batch(name: str, seed: int = 0, extra_first: bool = True) -> Dict[str, np.ndarray]:
+    """Synthetic replay minibatch per SURVEY.md §8d."""
+    s = SHAPES[name]
+    B, T, A = s["B"], s["T"], s["A"]
+    rs = np.random.RandomState(seed)
+    data = {}
+    data["image"] = rs.randint(0, 256, size=(B, T, 64, 64, 3)).astype(np.uint8)
+    if s["actor_dist"] == "onehot":
+        idx = rs.randint(0, A, size=(B, T))
+        data["action"] = np.eye(A, dtype=np.float32)[idx]
+    else:
+        data["action"] = rs.uniform(-1, 1, size=(B, T, A)).astype(np.float32)
+    data["reward"] = rs.randn(B, T).astype(np.float32)
+    data["discount"] = np.ones((B, T), np.float32)
+    first = np.zeros((B, T), bool)
+    first[:, 0] = True
+    if extra_first:
+        for b in range(B):
+            if b % 2 == 0 and T > 2:
+                first[b, rs.randint(1, T)] = True
+    data["is_first"] = first
+    term = np.zeros((B, T), bool)
+    term[B // 2, T - 1] = True  # one terminal so the cont head sees both classes
+    data["is_terminal"] = term
+    if s["encoder"] == "mlp":
+        for k, w in PROPRIO_KEYS:
+            data[k] = rs.randn(B, T, w).astype(np.float32)
+    return data
+
+
+def make_noise(name: str, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Every random draw of one update, as explicit fp32 arrays.
+
+    observe: q_prior, q_post [T,B,S,D] ~ Exp(1);  imagine: act [H,N,A] (N(0,1) for the normal
+    actor, Exp(1) for the onehot actor), q_img [H,N,S,D] ~ Exp(1).
+    """
+    s = SHAPES[name]
+    B, T, H, S, D, A = s["B"], s["T"], s["H"], s["stoch"], s["discrete"], s["A"]
+    N = B * T
+    rs = np.random.RandomState(1000 + seed)
+    out = {
+        "q_prior": rs.exponential(size=(T, B, S, D)).astype(np.float32),
+        "q_post": rs.exponential(size=(T, B, S, D)).astype(np.float32),
+        "q_img": rs.exponential(size=(H, N, S, D)).astype(np.float32),
+    }
+    if s["actor_dist"] == "onehot":
+        out["act"] = rs.exponential(size=(H, N, A)).astype(np.float32)
+    else:
+        out["act"] = rs.randn(H, N, A).astype(np.float32)
+    # guard against an exact zero (division by q)
+    for k in ("q_prior", "q_post", "q_img"):
+        np.maximum(out[k], 1e-20, out=out[k])
+    return out
+
+
+def observe_tape(noise: Dict[str, np.ndarray]) -> List[np.ndarray]:
+    """Noise in the order the reference's observe scan draws it."""
+    tape = []
+    for t in range(noise["q_prior"].shape[0]):
+        tape.append(noise["q_prior"][t])
+        tape.append(noise["q_post"][t])
+    return tape
+
+
+def imagine_tape(noise: Dict[str, np.ndarray]) -> List[np.ndarray]:
+    tape = []
+    for t in range(noise["q_img"].shape[0]):
+        tape.append(noise["act"][t])
+        tape.append(noise["q_img"][t])
+    return tape
+
+
+def checksum(x: np.ndarray) -> np.ndarray:
+    """(sum, abs-sum, max-abs) in float64 -- cheap whole-tensor pin for large outputs."""
+    x = np.asarray(x, np.float64)
+    return np.array([x.sum(), np.abs(x).sum(), np.abs(x).max()], np.float64)
