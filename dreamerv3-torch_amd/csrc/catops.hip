@@ -1,0 +1,327 @@
+// One-hot categorical latents with 1% uniform mixing: sampling, straight-through backward, KL and
+// entropy.  Reference: tools.OneHotDist (tools.py:436-460) as used by RSSM.get_dist
+// (networks.py:161-166), RSSM.kl_loss (networks.py:272-290) and the 'onehot' actor
+// (networks.py:713-714).
+//
+// A categorical group has D classes (32 for the RSSM, num_actions for the discrete actor) and is
+// owned by G = pow2 >= D consecutive lanes, one class per lane; 64/G groups per wave.
+#include "dv3_common.h"
+
+namespace dv3 {
+
+// p_hat = (1-u) softmax(l) + u/D for the lane's class; also returns the plain softmax value
+template <int G>
+__device__ __forceinline__ void unimix_probs(float l, bool valid, int D, float unimix, float& sm, float& ph) {
+  const float m = group_max<G>(valid ? l : -INFINITY);
+  const float e = valid ? expf(l - m) : 0.f;
+  const float s = group_sum<G>(e);
+  sm = e / s;
+  ph = valid ? sm * (1.f - unimix) + unimix / (float)D : 0.f;
+}
+
+// sample: idx = argmax_d p_hat[d] / q[d], q ~ Exp(1) (the single-draw path of torch.multinomial);
+// mode: idx = argmax_d p_hat[d].  Ties resolve to the lowest class index, as torch.argmax does.
+template <int G>
+__global__ __launch_bounds__(256) void onehot_sample_kernel(const float* __restrict__ logit,
+                                                            const float* __restrict__ noise,
+                                                            const unsigned long long* __restrict__ rng_state,
+                                                            float* __restrict__ out, int* __restrict__ idx_out,
+                                                            long R, int D, float unimix, int mode) {
+  constexpr int GPB = 256 / G;
+  const int sub = threadIdx.x / G, d = threadIdx.x % G;
+  const bool valid = d < D;
+  unsigned long long seed = 0, offset = 0;
+  if (!mode && !noise) {
+    seed = rng_state[0];
+    offset = rng_state[1];
+  }
+  for (long r0 = (long)blockIdx.x * GPB; r0 < R; r0 += (long)gridDim.x * GPB) {
+    const long r = r0 + sub;
+    const bool rv = r < R;
+    const float l = (rv && valid) ? logit[r * D + d] : 0.f;
+    float sm, ph;
+    unimix_probs<G>(l, valid, D, unimix, sm, ph);
+    float score = ph;
+    if (!mode) {
+      float q;
+      if (noise) {
+        q = (rv && valid) ? noise[r * D + d] : 1.f;
+      } else {
+        uint32_t o[4];
+        const unsigned long long e = (unsigned long long)r * D + d;
+        Philox ph4(seed);
+        ph4(offset + (e >> 2), 0x5eedULL, o);
+        q = -logf(u01(o[e & 3]));
+        q = fmaxf(q, 1e-30f);
+      }
+      score = ph / q;
+    }
+    if (!valid) score = -INFINITY;
+    // argmax with lowest-index tie-break
+    float best = score;
+    int bi = d;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if (rv && valid) out[r * D + d] = (d == bi) ? 1.f : 0.f;
+    if (rv && d == 0 && idx_out) idx_out[r] = bi;
+  }
+}
+
+// Straight-through backward.  sample: forward = onehot + (p - sg(p))  -> t = g.
+// mode: forward = onehot + (log p - sg(log p))                        -> t = g / p_hat.
+// dlogit_k (+)= (1-u) sm_k (t_k - sum_j sm_j t_j)      (normalisation constants cancel)
+template <int G>
+__global__ __launch_bounds__(256) void onehot_st_bwd_kernel(const float* __restrict__ logit,
+                                                            const float* __restrict__ g, float* __restrict__ dlogit,
+                                                            long R, int D, float unimix, int mode, int accumulate) {
+  constexpr int GPB = 256 / G;
+  const int sub = threadIdx.x / G, d = threadIdx.x % G;
+  const bool valid = d < D;
+  for (long r0 = (long)blockIdx.x * GPB; r0 < R; r0 += (long)gridDim.x * GPB) {
+    const long r = r0 + sub;
+    const bool rv = r < R;
+    const float l = (rv && valid) ? logit[r * D + d] : 0.f;
+    float sm, ph;
+    unimix_probs<G>(l, valid, D, unimix, sm, ph);
+    float t = (rv && valid) ? g[r * D + d] : 0.f;
+    if (mode && valid) t = t / ph;
+    const float dot = group_sum<G>(sm * t);
+    if (rv && valid) {
+      const float v = (1.f - unimix) * sm * (t - dot);
+      float* o = dlogit + r * D + d;
+      *o = accumulate ? (*o + v) : v;
+    }
+  }
+}
+
+// KL(post || prior) summed over the S groups of one state row, plus both entropies.
+//   kl = sum p (log p - log q),  ent = -sum p log p      (p, q unimixed)
+template <int G>
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ post, const float* __restrict__ prior,
+                                                     float* __restrict__ kl, float* __restrict__ ent_post,
+                                                     float* __restrict__ ent_prior, long rows, int S, int D,
+                                                     float unimix) {
+  constexpr int GPW = 64 / G;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / G, d = lane % G;
+  const bool valid = d < D;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    float a_kl = 0.f, a_ep = 0.f, a_eq = 0.f;
+    for (int s0 = 0; s0 < S; s0 += GPW) {
+      const int sg = s0 + sub;
+      const bool gv = sg < S;
+      const long off = (row * S + sg) * D + d;
+      const float lp = (gv && valid) ? post[off] : 0.f;
+      const float lq = (gv && valid) ? prior[off] : 0.f;
+      float smp, pp, smq, pq;
+      unimix_probs<G>(lp, valid, D, unimix, smp, pp);
+      unimix_probs<G>(lq, valid, D, unimix, smq, pq);
+      if (gv && valid) {
+        const float lgp = logf(pp), lgq = logf(pq);
+        a_kl += pp * (lgp - lgq);
+        a_ep -= pp * lgp;
+        a_eq -= pq * lgq;
+      }
+    }
+    a_kl = group_sum<64>(a_kl);
+    a_ep = group_sum<64>(a_ep);
+    a_eq = group_sum<64>(a_eq);
+    if (lane == 0) {
+      kl[row] = a_kl;
+      if (ent_post) ent_post[row] = a_ep;
+      if (ent_prior) ent_prior[row] = a_eq;
+    }
+  }
+}
+
+// loss_row = dyn_scale*max(KL(sg(post)||prior), free) + rep_scale*max(KL(post||sg(prior)), free)
+// d/dpost  = rep_scale * up * (1-u) sm_p (d - sum sm_p d),  d = log p - log q
+// d/dprior = dyn_scale * up * (1-u) sm_q (h - sum sm_q h),  h = -p/q
+// gradient passes the clip where kl >= free.  `up` is a scalar (the 1/(B*T) of torch.mean).
+template <int G>
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ post, const float* __restrict__ prior,
+                                                     const float* __restrict__ kl, float* __restrict__ dpost,
+                                                     float* __restrict__ dprior, long rows, int S, int D,
+                                                     float unimix, float free_nats, float dyn_scale,
+                                                     float rep_scale, float up, int acc_post, int acc_prior) {
+  constexpr int GPW = 64 / G;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane / G, d = lane % G;
+  const bool valid = d < D;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float pass = (kl[row] >= free_nats) ? up : 0.f;
+    for (int s0 = 0; s0 < S; s0 += GPW) {
+      const int sg = s0 + sub;
+      const bool gv = sg < S;
+      const long off = (row * S + sg) * D + d;
+      const float lp = (gv && valid) ? post[off] : 0.f;
+      const float lq = (gv && valid) ? prior[off] : 0.f;
+      float smp, pp, smq, pq;
+      unimix_probs<G>(lp, valid, D, unimix, smp, pp);
+      unimix_probs<G>(lq, valid, D, unimix, smq, pq);
+      const float dd = valid ? (logf(pp) - logf(pq)) : 0.f;
+      const float hh = valid ? (-pp / pq) : 0.f;
+      const float dotp = group_sum<G>(smp * dd);
+      const float dotq = group_sum<G>(smq * hh);
+      if (gv && valid) {
+        const float gp = rep_scale * pass * (1.f - unimix) * smp * (dd - dotp);
+        const float gq = dyn_scale * pass * (1.f - unimix) * smq * (hh - dotq);
+        dpost[off] = acc_post ? dpost[off] + gp : gp;
+        dprior[off] = acc_prior ? dprior[off] + gq : gq;
+      }
+    }
+  }
+}
+
+// per-group entropy / log-prob of a one-hot action (discrete actor)
+template <int G>
+__global__ __launch_bounds__(256) void onehot_ent_logp_kernel(const float* __restrict__ logit,
+                                                              const float* __restrict__ x, float* __restrict__ ent,
+                                                              float* __restrict__ logp, long R, int D,
+                                                              float unimix) {
+  constexpr int GPB = 256 / G;
+  const int sub = threadIdx.x / G, d = threadIdx.x % G;
+  const bool valid = d < D;
+  for (long r0 = (long)blockIdx.x * GPB; r0 < R; r0 += (long)gridDim.x * GPB) {
+    const long r = r0 + sub;
+    const bool rv = r < R;
+    const float l = (rv && valid) ? logit[r * D + d] : 0.f;
+    float sm, ph;
+    unimix_probs<G>(l, valid, D, unimix, sm, ph);
+    const float lg = valid ? logf(ph) : 0.f;
+    const float e = group_sum<G>(valid ? -ph * lg : 0.f);
+    const float xv = (rv && valid && x) ? x[r * D + d] : 0.f;
+    const float lp = group_sum<G>(xv * lg);
+    if (rv && d == 0) {
+      if (ent) ent[r] = e;
+      if (logp) logp[r] = lp;
+    }
+  }
+}
+
+// backward of entropy and log-prob w.r.t. the logits:
+//   dH/dp_j = -(log p_j + 1);  dlogp/dp_j = x_j / p_j;  through p = (1-u) sm + u/D
+template <int G>
+__global__ __launch_bounds__(256) void onehot_ent_logp_bwd_kernel(const float* __restrict__ logit,
+                                                                  const float* __restrict__ x,
+                                                                  const float* __restrict__ dent,
+                                                                  const float* __restrict__ dlogp,
+                                                                  float* __restrict__ dlogit, long R, int D,
+                                                                  float unimix, int accumulate) {
+  constexpr int GPB = 256 / G;
+  const int sub = threadIdx.x / G, d = threadIdx.x % G;
+  const bool valid = d < D;
+  for (long r0 = (long)blockIdx.x * GPB; r0 < R; r0 += (long)gridDim.x * GPB) {
+    const long r = r0 + sub;
+    const bool rv = r < R;
+    const float l = (rv && valid) ? logit[r * D + d] : 0.f;
+    float sm, ph;
+    unimix_probs<G>(l, valid, D, unimix, sm, ph);
+    float t = 0.f;
+    if (rv && valid) {
+      if (dent) t += dent[r] * -(logf(ph) + 1.f);
+      if (dlogp && x) t += dlogp[r] * x[r * D + d] / ph;
+    }
+    const float dot = group_sum<G>(sm * t);
+    if (rv && valid) {
+      const float v = (1.f - unimix) * sm * (t - dot);
+      float* o = dlogit + r * D + d;
+      *o = accumulate ? (*o + v) : v;
+    }
+  }
+}
+
+static int pick_g(int D) {
+  int g = 4;
+  while (g < 64 && g < D) g <<= 1;
+  return g;
+}
+static unsigned cap_blocks(long n, long per_block, long cap) {
+  long b = (n + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+#define DV3_G_DISPATCH(D, CALL)                   \
+  switch (pick_g(D)) {                            \
+    case 4: { constexpr int G = 4; CALL; } break;   \
+    case 8: { constexpr int G = 8; CALL; } break;   \
+    case 16: { constexpr int G = 16; CALL; } break; \
+    case 32: { constexpr int G = 32; CALL; } break; \
+    default: { constexpr int G = 64; CALL; } break; \
+  }
+
+}  // namespace dv3
+
+using namespace dv3;
+
+extern "C" int dv3_onehot_sample_fwd(const float* logit, const float* noise, const unsigned long long* rng_state,
+                                     float* onehot, int* idx, long R, int D, float unimix, int mode, void* stream) {
+  if (R <= 0) return 0;
+  if (D <= 0 || D > 64 || !logit || !onehot) return DV3_ERR_ARG;
+  if (!mode && !noise && !rng_state) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_sample_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
+                                       logit, noise, rng_state, onehot, idx, R, D, unimix, mode));
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_onehot_st_bwd(const float* logit, const float* dstoch, float* dlogit, long R, int D, float unimix,
+                                 int mode, int accumulate, void* stream) {
+  if (R <= 0) return 0;
+  if (D <= 0 || D > 64 || !logit || !dstoch || !dlogit) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_st_bwd_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
+                                       logit, dstoch, dlogit, R, D, unimix, mode, accumulate));
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_kl_fwd(const float* post_logit, const float* prior_logit, float* kl, float* ent_post,
+                          float* ent_prior, long rows, int S, int D, float unimix, void* stream) {
+  if (rows <= 0) return 0;
+  if (D <= 0 || D > 64 || S <= 0 || !post_logit || !prior_logit || !kl) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DV3_G_DISPATCH(D, hipLaunchKernelGGL((kl_fwd_kernel<G>), dim3(cap_blocks(rows, 4, 4096)), dim3(256), 0, s, post_logit,
+                                       prior_logit, kl, ent_post, ent_prior, rows, S, D, unimix));
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_kl_bwd(const float* post_logit, const float* prior_logit, const float* kl, float* dpost,
+                          float* dprior, long rows, int S, int D, float unimix, float free_nats, float dyn_scale,
+                          float rep_scale, float upstream, int acc_post, int acc_prior, void* stream) {
+  if (rows <= 0) return 0;
+  if (D <= 0 || D > 64 || S <= 0 || !post_logit || !prior_logit || !kl || !dpost || !dprior) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DV3_G_DISPATCH(D, hipLaunchKernelGGL((kl_bwd_kernel<G>), dim3(cap_blocks(rows, 4, 4096)), dim3(256), 0, s, post_logit,
+                                       prior_logit, kl, dpost, dprior, rows, S, D, unimix, free_nats, dyn_scale,
+                                       rep_scale, upstream, acc_post, acc_prior));
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_onehot_ent_logp_fwd(const float* logit, const float* x, float* ent, float* logp, long R, int D,
+                                       float unimix, void* stream) {
+  if (R <= 0) return 0;
+  if (D <= 0 || D > 64 || !logit) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_ent_logp_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
+                                       logit, x, ent, logp, R, D, unimix));
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_onehot_ent_logp_bwd(const float* logit, const float* x, const float* dent, const float* dlogp,
+                                       float* dlogit, long R, int D, float unimix, int accumulate, void* stream) {
+  if (R <= 0) return 0;
+  if (D <= 0 || D > 64 || !logit || !dlogit) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_ent_logp_bwd_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0,
+                                       s, logit, x, dent, dlogp, dlogit, R, D, unimix, accumulate));
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,131 @@
+// Dense fp32 GEMM on v_mfma_f32_32x32x2_f32 -- every Linear layer of the hot path.
+//
+//   C[M,N] (+)= [A | A2][M,K] * op(B)[K,N] + bias[N]
+//
+// Replaces, on the reference side, the ATen mm/addmm launches issued by nn.Linear inside
+// networks.RSSM.img_step / obs_step (networks.py:195-233), networks.GRUCell.forward
+// (networks.py:760-768), networks.MLP.forward (networks.py:657-681) and
+// networks.ConvDecoder._linear_layer (networks.py:569), plus their autograd transposes:
+//   forward  y = x W^T   : transA=0 transB=1   (W is [N][K], k-contiguous)
+//   dgrad    dx = dy W   : transA=0 transB=0   (W is [K=N_out][N=K_in])
+//   wgrad    dW = dy^T x : transA=1 transB=0   (A = dy [rows][N_out], B = x [rows][K_in])
+// The two-segment A ([A | A2] along K) is the reference's torch.cat([...], -1) in front of the
+// Linear (networks.py:196, 216, 762; get_feat networks.py:154-159), done without materialising it.
+#include "mfma_gemm.h"
+#include "dv3_common.h"
+
+namespace dv3 {
+
+struct GemmParams {
+  const float* A;
+  const float* A2;
+  const float* B;
+  float* C;
+  const float* bias;
+  int M, N, K, K1;
+  long lda, lda2, ldb, ldc;
+  int accumulate;
+  int vecA, vecB;
+  int tiles_m, tiles_n;
+};
+
+template <class TS, bool TA, bool TB>
+__global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[TS::lds_floats];
+  // A operand: rows = M.  TA=false -> A[m][k] (k-contiguous).  TA=true -> A[k][m].
+  using ATile = DenseTile<TS::BM, TS::BK, !TA>;
+  // B operand: rows = N.  TB=true -> B[n][k] (k-contiguous).  TB=false -> B[k][n].
+  using BTile = DenseTile<TS::BN, TS::BK, TB>;
+  DenseOperand<!TA> aop{p.A, p.A2, p.lda, p.lda2, p.M, p.K, p.K1, p.vecA != 0};
+  DenseOperand<TB> bop{p.B, nullptr, p.ldb, 0, p.N, p.K, p.K, p.vecB != 0};
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  // consecutive workgroups walk N fastest: neighbours share the A row panel in L2
+  const int m0 = (wg / p.tiles_n) * TS::BM;
+  const int n0 = (wg % p.tiles_n) * TS::BN;
+
+  f32x16 acc[TS::TM][TS::TN];
+  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, 0, p.K, lds, acc);
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / TS::WN, wn = wave % TS::WN;
+  const int col_l = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < TS::TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TS::TN; ++b) {
+      const int n = n0 + (wn * TS::TN + b) * 32 + col_l;
+      if (n >= p.N) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TS::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.M) {
+          float* c = p.C + (long)m * p.ldc + n;
+          float v = acc[a][b][r] + bv;
+          if (p.accumulate) v += *c;
+          *c = v;
+        }
+      }
+    }
+  }
+}
+
+template <class TS>
+static hipError_t launch_ts(const GemmParams& p0, int transA, int transB, hipStream_t s) {
+  GemmParams p = p0;
+  p.tiles_m = (p.M + TS::BM - 1) / TS::BM;
+  p.tiles_n = (p.N + TS::BN - 1) / TS::BN;
+  dim3 grid(p.tiles_m * p.tiles_n), block(kThreads);
+  if (!transA && transB) hipLaunchKernelGGL((gemm_kernel<TS, false, true>), grid, block, 0, s, p);
+  else if (!transA && !transB) hipLaunchKernelGGL((gemm_kernel<TS, false, false>), grid, block, 0, s, p);
+  else if (transA && !transB) hipLaunchKernelGGL((gemm_kernel<TS, true, false>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_kernel<TS, true, true>), grid, block, 0, s, p);
+  return hipGetLastError();
+}
+
+using T128 = TileShape<2, 2, 2, 2, 16>;    // 128 x 128, BK 16
+using T64 = TileShape<2, 2, 1, 1, 32>;     // 64 x 64,  BK 32
+using T32x128 = TileShape<1, 4, 1, 1, 32>;  // 32 x 128, BK 32 (few rows: the observe scan, M = batch)
+
+// Pick the tile that minimises (waves of workgroups over 256 CUs) x (MFMAs per wave per k-step).
+static int pick_tile(int M, int N) {
+  if (M <= 32) return 2;
+  auto cost = [&](int bm, int bn, int per_wave) {
+    long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    return ((tiles + 255) / 256) * per_wave;
+  };
+  const long c128 = cost(128, 128, 4), c64 = cost(64, 64, 1);
+  return (c64 < c128) ? 1 : 0;
+}
+
+}  // namespace dv3
+
+using namespace dv3;
+
+extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda,
+                            const float* A2, long lda2, int K1, const float* B, long ldb, float* C, long ldc,
+                            const float* bias, int accumulate, int tile, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (K < 0 || !A || !B || !C) return DV3_ERR_ARG;
+  GemmParams p{};
+  p.A = A; p.A2 = A2; p.B = B; p.C = C; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.K1 = (A2 ? K1 : K);
+  p.lda = lda; p.lda2 = lda2; p.ldb = ldb; p.ldc = ldc;
+  p.accumulate = accumulate;
+  if (A2) {
+    if (transA) return DV3_ERR_ARG;             // K-concat only for the k-contiguous orientation
+    if (K1 <= 0 || K1 >= K || (K1 % 32) != 0) return DV3_ERR_ARG;  // segment edge on a BK boundary
+  }
+  // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
+  p.vecA = 1; p.vecB = 1;
+  const int t = (tile >= 0 && tile <= 2) ? tile : pick_tile(M, N);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  if (t == 0) e = launch_ts<T128>(p, transA, transB, s);
+  else if (t == 1) e = launch_ts<T64>(p, transA, transB, s);
+  else e = launch_ts<T32x128>(p, transA, transB, s);
+  return (int)e;
+}

@@ -1,0 +1,547 @@
+// Output heads and losses of the hot path (all HBM-bound row kernels).
+//
+// Reference: tools.DiscDist (tools.py:463-517) for the reward / value heads, tools.Bernoulli
+// (tools.py:604-628) for the continue head, tools.MSEDist (tools.py:520-540) + the u8 -> f32/255
+// image decode of WorldModel.preprocess (models.py:176-180), tools.ContDist around a Normal for the
+// continuous actor (networks.py:693-700, tools.py:575-601), tools.lambda_return (tools.py:682-728)
+// and the discount weights of ImagBehavior._compute_target (models.py:620-638).
+#include "dv3_common.h"
+
+namespace dv3 {
+
+constexpr int kBuckets = 255;
+
+// torch.linspace(-20, 20, 255) element k, as ATen computes it (symmetric halves)
+__device__ __forceinline__ float bucket(int k) {
+  const float step = (20.f - (-20.f)) / 254.f;
+  return (k < kBuckets / 2) ? (-20.f + step * (float)k) : (20.f - step * (float)(kBuckets - 1 - k));
+}
+__device__ __forceinline__ float symlogf_(float x) {
+  const float s = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+  return s * logf(fabsf(x) + 1.f);
+}
+__device__ __forceinline__ float symexpf_(float x) {
+  const float s = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+  return s * (expf(fabsf(x)) - 1.f);
+}
+
+// one wave per row of 255 logits; lane owns classes lane + 64 v
+struct DiscRow {
+  float l[4], sm[4];
+  float lse;
+  __device__ __forceinline__ void load(const float* row, int lane) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k = lane + 64 * v;
+      l[v] = (k < kBuckets) ? row[k] : -INFINITY;
+      m = fmaxf(m, l[v]);
+    }
+    m = group_max<64>(m);
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      sm[v] = (lane + 64 * v < kBuckets) ? expf(l[v] - m) : 0.f;
+      s += sm[v];
+    }
+    s = group_sum<64>(s);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) sm[v] *= inv;
+    lse = m + logf(s);
+  }
+  __device__ __forceinline__ float mean(int lane) const {
+    float a = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k = lane + 64 * v;
+      if (k < kBuckets) a += sm[v] * bucket(k);
+    }
+    return group_sum<64>(a);
+  }
+};
+
+// two-hot target of tools.py:490-508 for symlog(x): indices and weights
+__device__ __forceinline__ void twohot(float x, int lane, int& below, int& above, float& wb, float& wa) {
+  const float y = symlogf_(x);
+  int le = 0, gt = 0;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int k = lane + 64 * v;
+    if (k < kBuckets) {
+      const float b = bucket(k);
+      le += (b <= y) ? 1 : 0;
+      gt += (b > y) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    le += __shfl_xor(le, o, 64);
+    gt += __shfl_xor(gt, o, 64);
+  }
+  below = min(max(le - 1, 0), kBuckets - 1);
+  above = min(max(kBuckets - gt, 0), kBuckets - 1);
+  const bool eq = below == above;
+  const float db = eq ? 1.f : fabsf(bucket(below) - y);
+  const float da = eq ? 1.f : fabsf(bucket(above) - y);
+  const float tot = db + da;
+  wb = da / tot;
+  wa = db / tot;
+}
+
+__global__ __launch_bounds__(256) void disc_mode_fwd_kernel(const float* __restrict__ logits,
+                                                            float* __restrict__ out, long R) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+    DiscRow d;
+    d.load(logits + r * kBuckets, lane);
+    const float m = d.mean(lane);
+    if (lane == 0) out[r] = symexpf_(m);
+  }
+}
+
+// dlogits_k (+)= up[r] * exp(|m|) * sm_k * (b_k - m)
+__global__ __launch_bounds__(256) void disc_mode_bwd_kernel(const float* __restrict__ logits,
+                                                            const float* __restrict__ up,
+                                                            float* __restrict__ dlogits, long R, int accumulate) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+    DiscRow d;
+    d.load(logits + r * kBuckets, lane);
+    const float m = d.mean(lane);
+    const float c = up[r] * expf(fabsf(m));
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k = lane + 64 * v;
+      if (k < kBuckets) {
+        const float g = c * d.sm[v] * (bucket(k) - m);
+        float* o = dlogits + r * kBuckets + k;
+        *o = accumulate ? (*o + g) : g;
+      }
+    }
+  }
+}
+
+// out[r] = sum_k target_k (l_k - lse)
+__global__ __launch_bounds__(256) void disc_logprob_fwd_kernel(const float* __restrict__ logits,
+                                                               const float* __restrict__ x, float* __restrict__ out,
+                                                               long R) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+    DiscRow d;
+    d.load(logits + r * kBuckets, lane);
+    int below, above;
+    float wb, wa;
+    twohot(x[r], lane, below, above, wb, wa);
+    float a = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k = lane + 64 * v;
+      if (k < kBuckets) {
+        const float t = (k == below ? wb : 0.f) + (k == above ? wa : 0.f);
+        a += t * (d.l[v] - d.lse);
+      }
+    }
+    a = group_sum<64>(a);
+    if (lane == 0) out[r] = a;
+  }
+}
+
+// d(logprob)/dlogits_k = target_k - sm_k ; dlogits (+)= up[r] * that
+__global__ __launch_bounds__(256) void disc_logprob_bwd_kernel(const float* __restrict__ logits,
+                                                               const float* __restrict__ x,
+                                                               const float* __restrict__ up,
+                                                               float* __restrict__ dlogits, long R, int accumulate) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+    DiscRow d;
+    d.load(logits + r * kBuckets, lane);
+    int below, above;
+    float wb, wa;
+    twohot(x[r], lane, below, above, wb, wa);
+    const float u = up[r];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int k = lane + 64 * v;
+      if (k < kBuckets) {
+        const float t = (k == below ? wb : 0.f) + (k == above ? wa : 0.f);
+        const float g = u * (t - d.sm[v]);
+        float* o = dlogits + r * kBuckets + k;
+        *o = accumulate ? (*o + g) : g;
+      }
+    }
+  }
+}
+
+// Bernoulli(logits=l).log_prob(x) = -softplus(l)(1-x) - softplus(-l) x      (tools.py:622-627)
+__device__ __forceinline__ float softplusf_(float z) { return (z > 20.f) ? z : log1pf(expf(z)); }
+__global__ void bernoulli_logprob_fwd_kernel(const float* __restrict__ l, const float* __restrict__ x,
+                                             float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = -softplusf_(l[i]) * (1.f - x[i]) - softplusf_(-l[i]) * x[i];
+}
+// d/dl = x - sigmoid(l)
+__global__ void bernoulli_logprob_bwd_kernel(const float* __restrict__ l, const float* __restrict__ x,
+                                             const float* __restrict__ up, float* __restrict__ dl, long n,
+                                             int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float g = up[i] * (x[i] - sigmoidf_(l[i]));
+    dl[i] = accumulate ? dl[i] + g : g;
+  }
+}
+
+// Image reconstruction loss on raw u8 pixels: target = u8/255 (models.py:180), loss[img] = sum (recon-t)^2
+// (tools.py:531-540), drecon = 2*up*(recon-t) written in the same pass when drecon != null.
+__global__ __launch_bounds__(256) void mse_image_kernel(const float* __restrict__ recon,
+                                                        const unsigned char* __restrict__ image,
+                                                        float* __restrict__ loss, float* __restrict__ drecon, int P,
+                                                        float up) {
+  __shared__ float red[4];
+  const long base = (long)blockIdx.x * P;
+  float a = 0.f;
+  for (int i = threadIdx.x * 4; i < P; i += 256 * 4) {
+    if (i + 3 < P) {
+      const float4 r = *reinterpret_cast<const float4*>(recon + base + i);
+      const uchar4 u = *reinterpret_cast<const uchar4*>(image + base + i);
+      const float d0 = r.x - (float)u.x / 255.f, d1 = r.y - (float)u.y / 255.f;
+      const float d2 = r.z - (float)u.z / 255.f, d3 = r.w - (float)u.w / 255.f;
+      a += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      if (drecon) {
+        float4 g = {2.f * up * d0, 2.f * up * d1, 2.f * up * d2, 2.f * up * d3};
+        *reinterpret_cast<float4*>(drecon + base + i) = g;
+      }
+    } else {
+      for (int e = i; e < P; ++e) {
+        const float d = recon[base + e] - (float)image[base + e] / 255.f;
+        a += d * d;
+        if (drecon) drecon[base + e] = 2.f * up * d;
+      }
+    }
+  }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) loss[blockIdx.x] = a;
+}
+
+// u8 image -> f32 (u8/255 - 0.5), the encoder's input (models.py:180 + networks.py:487)
+__global__ void image_to_f32_kernel(const unsigned char* __restrict__ img, float* __restrict__ out, long n) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n) {
+      const uchar4 u = *reinterpret_cast<const uchar4*>(img + i);
+      float4 o = {(float)u.x / 255.f - 0.5f, (float)u.y / 255.f - 0.5f, (float)u.z / 255.f - 0.5f,
+                  (float)u.w / 255.f - 0.5f};
+      *reinterpret_cast<float4*>(out + i) = o;
+    } else {
+      for (long e = i; e < n; ++e) out[e] = (float)img[e] / 255.f - 0.5f;
+    }
+  }
+}
+
+// symlog-MSE (tools.SymlogDist, tools.py:558-572): loss[row] = sum_j d_j, d = (mode - symlog(x))^2 zeroed
+// below 1e-8; dmode = 2*up*(mode - symlog(x)) where d >= 1e-8.
+__global__ __launch_bounds__(256) void symlog_mse_kernel(const float* __restrict__ mode, const float* __restrict__ x,
+                                                         float* __restrict__ loss, float* __restrict__ dmode,
+                                                         long R, int W, float up) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+    float a = 0.f;
+    for (int j = lane; j < W; j += 64) {
+      const float df = mode[r * W + j] - symlogf_(x[r * W + j]);
+      float d = df * df;
+      const bool keep = !(d < 1e-8f);
+      if (!keep) d = 0.f;
+      a += d;
+      if (dmode) dmode[r * W + j] = keep ? 2.f * up * df : 0.f;
+    }
+    a = group_sum<64>(a);
+    if (lane == 0) loss[r] = a;
+  }
+}
+// symlog of the proprio encoder input (networks.py:659-660)
+__global__ void symlog_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = symlogf_(x[i]);
+}
+
+// ---- continuous actor: Normal(tanh(mean), (max-min)*sigmoid(std+2)+min), absmax=1 ------------------
+// One thread per row (A is tiny).  Outputs action (sampled, rescaled), entropy, log-prob of the action.
+__global__ void actor_normal_fwd_kernel(const float* __restrict__ mean_raw, const float* __restrict__ std_raw,
+                                        const float* __restrict__ eps, float* __restrict__ action,
+                                        float* __restrict__ ent, long M, int A, float min_std, float max_std) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < M; r += (long)gridDim.x * blockDim.x) {
+    float e = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float mu = tanhf(mean_raw[r * A + a]);
+      const float sd = (max_std - min_std) * sigmoidf_(std_raw[r * A + a] + 2.f) + min_std;
+      if (action) {
+        const float pre = mu + sd * eps[r * A + a];
+        action[r * A + a] = pre * (1.f / fmaxf(fabsf(pre), 1.f));
+      }
+      e += 0.5f + 0.9189385332046727f + logf(sd);
+    }
+    if (ent) ent[r] = e;
+  }
+}
+// log_prob of a given action under the same Normal (reinforce branch, models.py:667)
+__global__ void actor_normal_logp_kernel(const float* __restrict__ mean_raw, const float* __restrict__ std_raw,
+                                         const float* __restrict__ action, float* __restrict__ logp, long M, int A,
+                                         float min_std, float max_std) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < M; r += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float mu = tanhf(mean_raw[r * A + a]);
+      const float sd = (max_std - min_std) * sigmoidf_(std_raw[r * A + a] + 2.f) + min_std;
+      const float d = action[r * A + a] - mu;
+      s += -(d * d) / (2.f * sd * sd) - logf(sd) - 0.9189385332046727f;
+    }
+    logp[r] = s;
+  }
+}
+// Backward of the three actor outputs w.r.t. (mean_raw, std_raw):
+//   daction (through the rsample; the absmax rescale factor is a constant), dent, dlogp (action held fixed).
+// Any of daction / dent / dlogp may be null.
+__global__ void actor_normal_bwd_kernel(const float* __restrict__ mean_raw, const float* __restrict__ std_raw,
+                                        const float* __restrict__ eps, const float* __restrict__ action,
+                                        const float* __restrict__ daction, const float* __restrict__ dent,
+                                        const float* __restrict__ dlogp, float* __restrict__ dmean_raw,
+                                        float* __restrict__ dstd_raw, long M, int A, float min_std,
+                                        float max_std) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < M; r += (long)gridDim.x * blockDim.x) {
+    for (int a = 0; a < A; ++a) {
+      const long i = r * A + a;
+      const float mu = tanhf(mean_raw[i]);
+      const float sg = sigmoidf_(std_raw[i] + 2.f);
+      const float sd = (max_std - min_std) * sg + min_std;
+      float dmu = 0.f, dsd = 0.f;
+      if (daction) {
+        const float pre = mu + sd * eps[i];
+        const float g = daction[i] * (1.f / fmaxf(fabsf(pre), 1.f));
+        dmu += g;
+        dsd += g * eps[i];
+      }
+      if (dent) dsd += dent[r] / sd;
+      if (dlogp) {
+        const float d = action[i] - mu;
+        dmu += dlogp[r] * d / (sd * sd);
+        dsd += dlogp[r] * (d * d / (sd * sd * sd) - 1.f / sd);
+      }
+      dmean_raw[i] = dmu * (1.f - mu * mu);
+      dstd_raw[i] = dsd * (max_std - min_std) * sg * (1.f - sg);
+    }
+  }
+}
+
+// ---- lambda-return and discount weights over the imagination horizon -------------------------------
+// disc_t = gamma * sigmoid(cont_logit_t);  R_t = r_{t+1} + disc_{t+1}((1-lam) v_{t+1} + lam R_{t+1}),
+// R_{H-1} := v_{H-1};  weights_t = prod_{s<t} disc_s.   All tensors [H][N].  One thread per column.
+__global__ void lambda_return_fwd_kernel(const float* __restrict__ reward, const float* __restrict__ value,
+                                         const float* __restrict__ cont_logit, float* __restrict__ target,
+                                         float* __restrict__ weights, float* __restrict__ disc_out, int H, long N,
+                                         float gamma, float lam) {
+  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
+    float w = 1.f;
+    for (int t = 0; t < H; ++t) {
+      const float d = gamma * sigmoidf_(cont_logit[t * N + n]);
+      weights[t * N + n] = w;
+      if (disc_out) disc_out[t * N + n] = d;
+      w *= d;
+    }
+    float agg = value[(long)(H - 1) * N + n];
+    for (int t = H - 2; t >= 0; --t) {
+      const float d = gamma * sigmoidf_(cont_logit[(t + 1) * N + n]);
+      const float inp = reward[(t + 1) * N + n] + d * value[(t + 1) * N + n] * (1.f - lam);
+      agg = inp + d * lam * agg;
+      target[t * N + n] = agg;
+    }
+  }
+}
+// Given dtarget [H-1][N]: dreward [H][N] (row 0 = 0), dcont_logit [H][N] (row 0 = 0).  value carries no
+// gradient on this path (models.py:626 evaluates it on the detached feats).
+__global__ void lambda_return_bwd_kernel(const float* __restrict__ dtarget, const float* __restrict__ value,
+                                         const float* __restrict__ cont_logit, const float* __restrict__ target,
+                                         float* __restrict__ dreward, float* __restrict__ dcont_logit, int H, long N,
+                                         float gamma, float lam) {
+  for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
+    dreward[n] = 0.f;
+    dcont_logit[n] = 0.f;
+    float G = 0.f;  // dL/dR_t, carried forward in t
+    for (int t = 0; t <= H - 2; ++t) {
+      const float sg = sigmoidf_(cont_logit[(t + 1) * N + n]);
+      const float d = gamma * sg;
+      G = dtarget[t * N + n] + ((t > 0) ? G : 0.f);
+      const float rnext = (t + 1 <= H - 2) ? target[(t + 1) * N + n] : value[(long)(H - 1) * N + n];
+      dreward[(t + 1) * N + n] = G;
+      dcont_logit[(t + 1) * N + n] = G * ((1.f - lam) * value[(t + 1) * N + n] + lam * rnext) * gamma * sg * (1.f - sg);
+      G = G * d * lam;  // flows into R_{t+1}
+    }
+  }
+}
+
+// ---- is_first reset blend (networks.py:181-193): out = x*(1-m) + init*m, m per row -------------------
+__global__ void reset_blend_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ init,
+                                   const float* __restrict__ first, float* __restrict__ out, long ldo, int B,
+                                   int n) {
+  const long total = (long)B * n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / n), j = (int)(i % n);
+    const float m = first[b];
+    const float xv = x ? x[b * ldx + j] : 0.f;
+    const float iv = init ? init[j] : 0.f;
+    out[b * ldo + j] = xv * (1.f - m) + iv * m;
+  }
+}
+// dx = dout*(1-m);  dinit[j] += sum_b dout[b][j]*m_b
+__global__ void reset_blend_bwd_kernel(const float* __restrict__ dout, long ldo, const float* __restrict__ first,
+                                       float* __restrict__ dx, long ldx, float* __restrict__ dinit, int B, int n) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float m = first[b];
+      const float g = dout[b * ldo + j];
+      if (dx) dx[b * ldx + j] = g * (1.f - m);
+      acc += g * m;
+    }
+    if (dinit) dinit[j] += acc;
+  }
+}
+
+static unsigned nblk(long n, int per, long cap) {
+  long b = (n + per - 1) / per;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace dv3
+
+using namespace dv3;
+#define S_ ((hipStream_t)stream)
+
+extern "C" int dv3_disc_mode_fwd(const float* logits, float* out, long R, void* stream) {
+  if (R <= 0) return 0;
+  if (!logits || !out) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(disc_mode_fwd_kernel, dim3(nblk(R, 4, 4096)), dim3(256), 0, S_, logits, out, R);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_disc_mode_bwd(const float* logits, const float* up, float* dlogits, long R, int accumulate,
+                                 void* stream) {
+  if (R <= 0) return 0;
+  if (!logits || !up || !dlogits) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(disc_mode_bwd_kernel, dim3(nblk(R, 4, 4096)), dim3(256), 0, S_, logits, up, dlogits, R, accumulate);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_disc_logprob_fwd(const float* logits, const float* x, float* out, long R, void* stream) {
+  if (R <= 0) return 0;
+  if (!logits || !x || !out) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(disc_logprob_fwd_kernel, dim3(nblk(R, 4, 4096)), dim3(256), 0, S_, logits, x, out, R);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_disc_logprob_bwd(const float* logits, const float* x, const float* up, float* dlogits, long R,
+                                    int accumulate, void* stream) {
+  if (R <= 0) return 0;
+  if (!logits || !x || !up || !dlogits) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(disc_logprob_bwd_kernel, dim3(nblk(R, 4, 4096)), dim3(256), 0, S_, logits, x, up, dlogits, R,
+                     accumulate);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_bernoulli_logprob_fwd(const float* logit, const float* x, float* out, long n, void* stream) {
+  if (n <= 0) return 0;
+  if (!logit || !x || !out) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(bernoulli_logprob_fwd_kernel, dim3(nblk(n, 256, 2048)), dim3(256), 0, S_, logit, x, out, n);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_bernoulli_logprob_bwd(const float* logit, const float* x, const float* up, float* dlogit, long n,
+                                         int accumulate, void* stream) {
+  if (n <= 0) return 0;
+  if (!logit || !x || !up || !dlogit) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(bernoulli_logprob_bwd_kernel, dim3(nblk(n, 256, 2048)), dim3(256), 0, S_, logit, x, up, dlogit, n,
+                     accumulate);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_mse_image(const float* recon, const unsigned char* image_u8, float* loss, float* drecon,
+                             long n_images, int pixels, float upstream, void* stream) {
+  if (n_images <= 0) return 0;
+  if (!recon || !image_u8 || !loss || pixels <= 0 || (pixels % 4) != 0) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(mse_image_kernel, dim3((unsigned)n_images), dim3(256), 0, S_, recon, image_u8, loss, drecon, pixels,
+                     upstream);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_image_to_f32(const unsigned char* image_u8, float* out, long n, void* stream) {
+  if (n <= 0) return 0;
+  if (!image_u8 || !out) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(image_to_f32_kernel, dim3(nblk(n, 1024, 4096)), dim3(256), 0, S_, image_u8, out, n);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_symlog_mse(const float* mode, const float* x, float* loss, float* dmode, long R, int W,
+                              float upstream, void* stream) {
+  if (R <= 0) return 0;
+  if (!mode || !x || !loss || W <= 0) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(symlog_mse_kernel, dim3(nblk(R, 4, 4096)), dim3(256), 0, S_, mode, x, loss, dmode, R, W, upstream);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_symlog(const float* x, float* y, long n, void* stream) {
+  if (n <= 0) return 0;
+  if (!x || !y) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(symlog_kernel, dim3(nblk(n, 256, 2048)), dim3(256), 0, S_, x, y, n);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_actor_normal_fwd(const float* mean_raw, const float* std_raw, const float* eps, float* action,
+                                    float* entropy, long M, int A, float min_std, float max_std, void* stream) {
+  if (M <= 0) return 0;
+  if (!mean_raw || !std_raw || A <= 0 || (action && !eps)) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(actor_normal_fwd_kernel, dim3(nblk(M, 256, 2048)), dim3(256), 0, S_, mean_raw, std_raw, eps, action,
+                     entropy, M, A, min_std, max_std);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_actor_normal_logp(const float* mean_raw, const float* std_raw, const float* action, float* logp,
+                                     long M, int A, float min_std, float max_std, void* stream) {
+  if (M <= 0) return 0;
+  if (!mean_raw || !std_raw || !action || !logp || A <= 0) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(actor_normal_logp_kernel, dim3(nblk(M, 256, 2048)), dim3(256), 0, S_, mean_raw, std_raw, action,
+                     logp, M, A, min_std, max_std);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_actor_normal_bwd(const float* mean_raw, const float* std_raw, const float* eps,
+                                    const float* action, const float* daction, const float* dent, const float* dlogp,
+                                    float* dmean_raw, float* dstd_raw, long M, int A, float min_std, float max_std,
+                                    void* stream) {
+  if (M <= 0) return 0;
+  if (!mean_raw || !std_raw || !dmean_raw || !dstd_raw || A <= 0) return DV3_ERR_ARG;
+  if ((daction && !eps) || (dlogp && !action)) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(actor_normal_bwd_kernel, dim3(nblk(M, 256, 2048)), dim3(256), 0, S_, mean_raw, std_raw, eps, action,
+                     daction, dent, dlogp, dmean_raw, dstd_raw, M, A, min_std, max_std);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_lambda_return_fwd(const float* reward, const float* value, const float* cont_logit, float* target,
+                                     float* weights, float* disc, int H, long N, float gamma, float lam,
+                                     void* stream) {
+  if (N <= 0) return 0;
+  if (H < 2 || !reward || !value || !cont_logit || !target || !weights) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(lambda_return_fwd_kernel, dim3(nblk(N, 256, 2048)), dim3(256), 0, S_, reward, value, cont_logit,
+                     target, weights, disc, H, N, gamma, lam);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_lambda_return_bwd(const float* dtarget, const float* value, const float* cont_logit,
+                                     const float* target, float* dreward, float* dcont_logit, int H, long N,
+                                     float gamma, float lam, void* stream) {
+  if (N <= 0) return 0;
+  if (H < 2 || !dtarget || !value || !cont_logit || !target || !dreward || !dcont_logit) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(lambda_return_bwd_kernel, dim3(nblk(N, 256, 2048)), dim3(256), 0, S_, dtarget, value, cont_logit,
+                     target, dreward, dcont_logit, H, N, gamma, lam);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_reset_blend(const float* x, long ldx, const float* init, const float* is_first, float* out,
+                               long ldo, int B, int n, void* stream) {
+  if (B <= 0 || n <= 0) return 0;
+  if (!is_first || !out) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(reset_blend_kernel, dim3(nblk((long)B * n, 256, 2048)), dim3(256), 0, S_, x, ldx, init, is_first,
+                     out, ldo, B, n);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_reset_blend_bwd(const float* dout, long ldo, const float* is_first, float* dx, long ldx,
+                                   float* dinit, int B, int n, void* stream) {
+  if (B <= 0 || n <= 0) return 0;
+  if (!dout || !is_first) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(reset_blend_bwd_kernel, dim3(nblk(n, 256, 2048)), dim3(256), 0, S_, dout, ldo, is_first, dx, ldx,
+                     dinit, B, n);
+  return (int)hipGetLastError();
+}

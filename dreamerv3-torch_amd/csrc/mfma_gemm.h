@@ -1,0 +1,217 @@
+// fp32 MFMA tile engine for gfx950 (CDNA4), shared by the dense GEMM and the implicit-GEMM
+// convolution kernels.
+//
+// Why fp32 MFMA: the parity bar is fp32 1e-4 through 64 sampled recurrent steps, so inputs
+// cannot be rounded to bf16.  v_mfma_f32_32x32x2_f32 is an exact k-ordered fmaf chain at the
+// fp32 vector peak (157 TFLOP/s chip-wide) while leaving the VALU free for epilogues.
+//
+// Structure (one workgroup = 4 waves = one BM x BN tile of C):
+//   * LDS image is k-major: As[k][m], Bs[k][n] (row stride +4 floats).  A 32x32x2 MFMA wants
+//     A[i][k0+h] / B[k0+h][j] for lane (i = l&31, h = l>>5): one conflict-free ds_read_b32 each
+//     (32 consecutive floats per half-wave).
+//   * global -> registers -> LDS staging, software-pipelined: the loads of K-tile t+1 are issued
+//     before the MFMAs of tile t and written to the other LDS buffer after them; one barrier per
+//     K-tile.
+//   * Loaders are functors, so "A" can be a dense matrix in either orientation, two K-segments
+//     (the reference's torch.cat([...], -1) in front of every Linear), or an im2col gather.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dv3 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 4-byte aligned float4: gfx950 global loads only need dword alignment
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int kThreads = 256;
+
+// Bijective XCD-aware remap of a linear workgroup id (blocks b and b+8 share an XCD / L2, so
+// give each XCD a contiguous chunk of tiles).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense operand loader.  The operand is a logical [R x K] matrix (R = rows of the tile
+// dimension, i.e. M for A and N for B).
+//   KCONTIG = true : element (r,k) at p[r*ld + k]        (x[M][K], W[N][K])
+//   KCONTIG = false: element (r,k) at p[k*ld + r]        (dY^T for wgrad, W as [K][N] for dgrad)
+// Optional second K-segment (KCONTIG only): k >= K1 reads p2[r*ld2 + (k-K1)]; K1 % BK == 0.
+// ---------------------------------------------------------------------------------------------
+template <bool KCONTIG>
+struct DenseOperand {
+  const float* p;
+  const float* p2;
+  long ld, ld2;
+  int R, K, K1;
+  bool vec_ok;  // ld % 4 == 0-independent: only dword alignment is needed; false forces scalar
+};
+
+template <int ROWS, int BK, bool KCONTIG>
+struct DenseTile {
+  // registers held per thread for one staged tile
+  static constexpr int kVecs = ROWS * BK / 4 / kThreads;
+  static_assert(ROWS * BK % (4 * kThreads) == 0, "tile must split into float4 per thread");
+  // LDS row stride.  k-contiguous sources are transposed on the way in with ds_write_b32; the pad
+  // spreads the BK/4 column chunks of a 32-lane group over the 32 banks (pad = 8/CH).  Row-contiguous
+  // sources are written with ds_write_b128 and need a 16-byte multiple.
+  static constexpr int LD = ROWS + (KCONTIG ? (BK == 16 ? 2 : 1) : 4);
+  f32x4 v[kVecs];
+
+  __device__ __forceinline__ void load(const DenseOperand<KCONTIG>& op, int r0, int k0, int tid) {
+    if constexpr (KCONTIG) {
+      constexpr int CH = BK / 4;            // float4 chunks per row
+      constexpr int RPP = kThreads / CH;    // rows per pass
+      const float* base = op.p;
+      long ld = op.ld;
+      int kk0 = k0, kend = op.K1;
+      if (k0 >= op.K1) { base = op.p2; ld = op.ld2; kk0 = k0 - op.K1; kend = op.K - op.K1; }
+      const bool interior = (r0 + ROWS <= op.R) && (kk0 + BK <= kend) && op.vec_ok;
+      const int c = tid % CH, rr = tid / CH;
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        const int r = r0 + p * RPP + rr;
+        const int k = kk0 + 4 * c;
+        if (interior) {
+          v[p] = *reinterpret_cast<const f32x4u*>(base + (long)r * ld + k);
+        } else {
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+          if (r < op.R) {
+            const float* q = base + (long)r * ld + k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (k + e < kend) t[e] = q[e];
+          }
+          v[p] = t;
+        }
+      }
+    } else {
+      constexpr int CH = ROWS / 4;          // float4 chunks per k-row
+      constexpr int KPP = kThreads / CH;    // k-rows per pass
+      static_assert(kThreads % CH == 0 && BK % KPP == 0, "bad tile");
+      const bool interior = (r0 + ROWS <= op.R) && (k0 + BK <= op.K) && op.vec_ok;
+      const int c = tid % CH, kr = tid / CH;
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        const int k = k0 + p * KPP + kr;
+        const int r = r0 + 4 * c;
+        if (interior) {
+          v[p] = *reinterpret_cast<const f32x4u*>(op.p + (long)k * op.ld + r);
+        } else {
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+          if (k < op.K) {
+            const float* q = op.p + (long)k * op.ld + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (r + e < op.R) t[e] = q[e];
+          }
+          v[p] = t;
+        }
+      }
+    }
+  }
+
+  // LDS image: s[k][row], row stride LD
+  __device__ __forceinline__ void store(float* s, int tid) const {
+    if constexpr (KCONTIG) {
+      constexpr int CH = BK / 4;
+      constexpr int RPP = kThreads / CH;
+      const int c = tid % CH, rr = tid / CH;
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        const int r = p * RPP + rr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[(4 * c + e) * LD + r] = v[p][e];
+      }
+    } else {
+      constexpr int CH = ROWS / 4;
+      constexpr int KPP = kThreads / CH;
+      const int c = tid % CH, kr = tid / CH;
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        const int k = p * KPP + kr;
+        *reinterpret_cast<f32x4*>(&s[k * LD + 4 * c]) = v[p];
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Tile shape: 4 waves as WM x WN, each wave TM x TN MFMA tiles of 32x32.
+// ---------------------------------------------------------------------------------------------
+template <int WM_, int WN_, int TM_, int TN_, int BK_>
+struct TileShape {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, BK = BK_;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static constexpr int lds_floats = 2 * BK * (BM + 4) + 2 * BK * (BN + 4);  // upper bound on any pad
+};
+
+// The K loop.  ATile/BTile: staged-tile types with load(op, r0, k0, tid) / store(lds, tid).
+// acc[tm][tn] on exit holds C(m0 + wm*TM*32 + tm*32 + row(reg,lane), n0 + ... + (lane&31)),
+// row(reg, lane) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+template <class TS, class ATile, class BTile, class AOp, class BOp>
+__device__ __forceinline__ void mfma_mainloop(const AOp& aop, const BOp& bop, int m0, int n0, int kbeg,
+                                              int kend, float* lds, f32x16 (&acc)[TS::TM][TS::TN]) {
+  constexpr int BM = TS::BM, BN = TS::BN, BK = TS::BK;
+  constexpr int LDA = ATile::LD, LDB = BTile::LD;
+  float* As = lds;
+  float* Bs = lds + 2 * BK * (BM + 4);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / TS::WN, wn = wave % TS::WN;
+  const int i = lane & 31, h = lane >> 5;
+
+#pragma unroll
+  for (int a = 0; a < TS::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TS::TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  ATile at;
+  BTile bt;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk <= 0) return;
+  at.load(aop, m0, kbeg, tid);
+  bt.load(bop, n0, kbeg, tid);
+  at.store(As, tid);
+  bt.store(Bs, tid);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nk; ++t) {
+    const bool more = (t + 1 < nk);
+    if (more) {
+      at.load(aop, m0, kbeg + (t + 1) * BK, tid);
+      bt.load(bop, n0, kbeg + (t + 1) * BK, tid);
+    }
+    const float* as = As + cur * BK * LDA + wm * TS::TM * 32 + i;
+    const float* bs = Bs + cur * BK * LDB + wn * TS::TN * 32 + i;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av[TS::TM], bv[TS::TN];
+#pragma unroll
+      for (int a = 0; a < TS::TM; ++a) av[a] = as[(kk + h) * LDA + a * 32];
+#pragma unroll
+      for (int b = 0; b < TS::TN; ++b) bv[b] = bs[(kk + h) * LDB + b * 32];
+#pragma unroll
+      for (int a = 0; a < TS::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TS::TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    if (more) {
+      at.store(As + (cur ^ 1) * BK * LDA, tid);
+      bt.store(Bs + (cur ^ 1) * BK * LDB, tid);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+}  // namespace dv3

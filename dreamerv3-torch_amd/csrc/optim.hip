@@ -1,0 +1,112 @@
+// Optimizer step on flat fp32 buckets: global grad-norm, clip, Adam -- one launch each per
+// optimizer, no host synchronisation (the step counter and the norm live in device memory so the
+// whole update can sit inside one hipGraph).
+//
+// Reference: tools.Optimizer.__call__ (tools.py:760-776): clip_grad_norm_(params, clip) then
+// torch.optim.Adam(lr, eps).step(), betas (0.9, 0.999); slow critic EMA models.py:683-689.
+// The flat bucket is also the unit of the data-parallel all-reduce (one RCCL call per optimizer).
+#include "dv3_common.h"
+
+namespace dv3 {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  const long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    a += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0) {
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) a += x[i] * x[i];
+  }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) atomicAdd(out, a);
+}
+
+// state[0] = step count (float, exact up to 2^24), state[1] = sum of squared grads (input),
+// state[2] = grad norm (output, for the `*_grad_norm` metric)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   float* __restrict__ state, float lr, float b1, float b2,
+                                                   float eps, float clip, float wd) {
+  const float step = state[0] + 1.f;
+  const float norm = sqrtf(state[1]);
+  float coef = 1.f;
+  if (clip > 0.f) coef = fminf(clip / (norm + 1e-6f), 1.f);
+  const float bc1 = 1.f - powf(b1, step);
+  const float bc2s = sqrtf(1.f - powf(b2, step));
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    float pi = p[i];
+    if (wd > 0.f) pi *= (1.f - wd);  // tools.py:778-783 (applied before the step, as the reference does)
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+// runs after adam_kernel on the same stream: bump the step, publish the norm, clear the accumulator
+__global__ void adam_finish_kernel(float* __restrict__ state) {
+  state[0] += 1.f;
+  state[2] = sqrtf(state[1]);
+  state[1] = 0.f;
+}
+
+// y = a*x + b*y   (slow-critic EMA: a = mix, b = 1 - mix; gradient averaging etc.)
+__global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a, float b) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + b * y[i];
+}
+
+// advance the Philox offset kept in device memory: rng_state = {seed, offset}
+__global__ void rng_advance_kernel(unsigned long long* st, unsigned long long inc) { st[1] += inc; }
+
+}  // namespace dv3
+
+using namespace dv3;
+
+static unsigned blocks_for(long n, long cap) {
+  long b = (n + 1023) / 1024;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+extern "C" int dv3_sumsq_accumulate(const float* x, long n, float* out, void* stream) {
+  if (n <= 0) return 0;
+  if (!x || !out || ((uintptr_t)x & 15)) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float* state,
+                             float lr, float beta1, float beta2, float eps, float clip, float weight_decay,
+                             void* stream) {
+  if (n <= 0) return 0;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !state) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, state,
+                     lr, beta1, beta2, eps, clip, weight_decay);
+  hipLaunchKernelGGL(adam_finish_kernel, dim3(1), dim3(1), 0, s, state);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_axpby(const float* x, float* y, long n, float a, float b, void* stream) {
+  if (n <= 0) return 0;
+  if (!x || !y) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, (hipStream_t)stream, x, y, n, a, b);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_rng_advance(unsigned long long* rng_state, unsigned long long increment, void* stream) {
+  if (!rng_state) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state, increment);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_version(void) { return 1; }

@@ -1,0 +1,367 @@
+// Row-wise kernels of the hot path: LayerNorm(eps 1e-3)+SiLU and the LayerNorm-GRU gate math,
+// forward and backward.  HBM-bound: one pass over the row, statistics in registers, wave (or
+// sub-wave group) per row, parameter gradients accumulated in registers across a grid-stride
+// loop and flushed with one atomicAdd per column per wave.
+//
+// Reference sites: nn.LayerNorm + SiLU after every bias-free Linear (networks.py:48-58, 62-78,
+// 624-636), ImgChLayerNorm + SiLU after every conv (networks.py:475-477, 551-554, 801-810),
+// GRUCell.forward (networks.py:760-768).
+#include "dv3_common.h"
+
+namespace dv3 {
+
+constexpr int kMaxV = 32;  // per-lane cached elements (template NV <= kMaxV); rows up to 64*32 = 2048
+
+// address of (row r, col c) for an activation tensor that is either plain [R][ld] or, when
+// G > 0, the reference's (C,H,W) flatten of an NHWC tile: rows are (image, pixel) pairs with G
+// pixels per image and the element lives at img*(N*G) + c*G + pix  (networks.py:494).
+__device__ __forceinline__ long act_addr(long r, int c, long ld, int N, int G) {
+  if (G <= 0) return r * ld + c;
+  const long img = r / G;
+  const int pix = (int)(r - img * G);
+  return img * ((long)N * G) + (long)c * G + pix;
+}
+
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void ln_act_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y,
+                                                         long ldy, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out, long R, int N, int act,
+                                                         int G) {
+  constexpr int RPB = 256 / LPR;
+  const int sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  float g[NV], b[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = l + v * LPR;
+    const bool ok = c < N;
+    g[v] = ok ? gamma[c] : 0.f;
+    b[v] = ok ? beta[c] : 0.f;
+  }
+  const float inv_n = 1.f / (float)N;
+  for (long r = (long)blockIdx.x * RPB + sub; r < R; r += (long)gridDim.x * RPB) {
+    float xv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = l + v * LPR;
+      xv[v] = (c < N) ? x[r * ldx + c] : 0.f;
+      s += xv[v];
+    }
+    const float mean = group_sum<LPR>(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = l + v * LPR;
+      const float d = (c < N) ? xv[v] - mean : 0.f;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(group_sum<LPR>(q) * inv_n + kLnEps);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = l + v * LPR;
+      if (c < N) {
+        float z = (xv[v] - mean) * rstd * g[v] + b[v];
+        if (act) z = siluf_(z);
+        y[act_addr(r, c, ldy, N, G)] = z;
+      }
+    }
+    if (l == 0) {
+      if (mean_out) mean_out[r] = mean;
+      if (rstd_out) rstd_out[r] = rstd;
+    }
+  }
+}
+
+// dx = d(loss)/d(x) given dy = d(loss)/d(act(LN(x))).  dgamma/dbeta are ACCUMULATED (+=).
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void ln_act_bwd_kernel(const float* __restrict__ dy, long lddy,
+                                                         const float* __restrict__ x, long ldx,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const float* __restrict__ mean_in,
+                                                         const float* __restrict__ rstd_in, float* __restrict__ dx,
+                                                         long lddx, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, long R, int N, int act, int G,
+                                                         int accumulate_dx) {
+  constexpr int RPB = 256 / LPR;
+  const int sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  __shared__ float red[2][64 * kMaxV];
+  for (int c = threadIdx.x; c < N; c += 256) {
+    red[0][c] = 0.f;
+    red[1][c] = 0.f;
+  }
+  __syncthreads();
+  float g[NV], b[NV], pg[NV], pb[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = l + v * LPR;
+    const bool ok = c < N;
+    g[v] = ok ? gamma[c] : 0.f;
+    b[v] = ok ? beta[c] : 0.f;
+    pg[v] = 0.f;
+    pb[v] = 0.f;
+  }
+  const float inv_n = 1.f / (float)N;
+  for (long r = (long)blockIdx.x * RPB + sub; r < R; r += (long)gridDim.x * RPB) {
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    float xh[NV], dxh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = l + v * LPR;
+      xh[v] = 0.f;
+      dxh[v] = 0.f;
+      if (c < N) {
+        const float xhat = (x[r * ldx + c] - mean) * rstd;
+        float dz = dy[act_addr(r, c, lddy, N, G)];
+        if (act) dz *= dsiluf_(xhat * g[v] + b[v]);
+        pg[v] += dz * xhat;
+        pb[v] += dz;
+        xh[v] = xhat;
+        dxh[v] = dz * g[v];
+        s1 += dxh[v];
+        s2 += dxh[v] * xhat;
+      }
+    }
+    s1 = group_sum<LPR>(s1) * inv_n;
+    s2 = group_sum<LPR>(s2) * inv_n;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = l + v * LPR;
+      if (c < N) {
+        const float d = rstd * (dxh[v] - s1 - xh[v] * s2);
+        float* o = dx + r * lddx + c;
+        *o = accumulate_dx ? (*o + d) : d;
+      }
+    }
+  }
+  if (dgamma) {
+    // block-level reduce in LDS, then one global atomic per column per block
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = l + v * LPR;
+      if (c < N) {
+        atomicAdd(&red[0][c], pg[v]);
+        atomicAdd(&red[1][c], pb[v]);
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += 256) {
+      atomicAdd(dgamma + c, red[0][c]);
+      atomicAdd(dbeta + c, red[1][c]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm-GRU gates (networks.py:760-768).  One wave per row.
+//   y = LN(p) over all 3*De;  r = sigmoid(y[0:De]); c = tanh(r * y[De:2De]); u = sigmoid(y[2De:] - 1)
+//   h' = u*c + (1-u)*h
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ p, long ldp,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ h,
+                                                      long ldh, float* __restrict__ hn, long ldhn,
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                      int M, int De) {
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int N = 3 * De;
+  const float inv_n = 1.f / (float)N;
+  for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
+    const float* pr = p + (long)r * ldp;
+    float s = 0.f;
+    for (int c = l; c < N; c += 64) s += pr[c];
+    const float mean = group_sum<64>(s) * inv_n;
+    float q = 0.f;
+    for (int c = l; c < N; c += 64) {
+      const float d = pr[c] - mean;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(group_sum<64>(q) * inv_n + kLnEps);
+    for (int j = l; j < De; j += 64) {
+      const float yr = (pr[j] - mean) * rstd * gamma[j] + beta[j];
+      const float yc = (pr[De + j] - mean) * rstd * gamma[De + j] + beta[De + j];
+      const float yu = (pr[2 * De + j] - mean) * rstd * gamma[2 * De + j] + beta[2 * De + j];
+      const float rg = sigmoidf_(yr);
+      const float cg = tanhf(rg * yc);
+      const float ug = sigmoidf_(yu - 1.f);
+      const float hp = h[(long)r * ldh + j];
+      hn[(long)r * ldhn + j] = ug * cg + (1.f - ug) * hp;
+    }
+    if (l == 0) {
+      mean_out[r] = mean;
+      rstd_out[r] = rstd;
+    }
+  }
+}
+
+// Backward: dp (w.r.t. the GEMM output p), dh (direct (1-u) path; OVERWRITTEN or accumulated), and
+// accumulated dgamma/dbeta.  dy of the LN output is staged in LDS (3*De floats per wave).
+__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dhn, long lddhn,
+                                                      const float* __restrict__ p, long ldp,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ h,
+                                                      long ldh, const float* __restrict__ mean_in,
+                                                      const float* __restrict__ rstd_in, float* __restrict__ dp,
+                                                      long lddp, float* __restrict__ dh, long lddh,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                      int De, int accumulate_dh) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 4 waves x 3*De (dy) + 2 x 3*De (dgamma,dbeta)
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int N = 3 * De;
+  float* dyw = smem + (long)wave * N;
+  float* accg = smem + 4L * N;
+  float* accb = accg + N;
+  for (int c = threadIdx.x; c < 2 * N; c += 256) accg[c] = 0.f;
+  __syncthreads();
+  const float inv_n = 1.f / (float)N;
+  for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
+    const float* pr = p + (long)r * ldp;
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = l; j < De; j += 64) {
+      const float xr = (pr[j] - mean) * rstd, xc = (pr[De + j] - mean) * rstd, xu = (pr[2 * De + j] - mean) * rstd;
+      const float gr = gamma[j], gc = gamma[De + j], gu = gamma[2 * De + j];
+      const float yr = xr * gr + beta[j], yc = xc * gc + beta[De + j], yu = xu * gu + beta[2 * De + j];
+      const float rg = sigmoidf_(yr);
+      const float cg = tanhf(rg * yc);
+      const float ug = sigmoidf_(yu - 1.f);
+      const float hp = h[(long)r * ldh + j];
+      const float g = dhn[(long)r * lddhn + j];
+      const float du = g * (cg - hp) * ug * (1.f - ug);
+      const float drc = g * ug * (1.f - cg * cg);
+      const float dr = drc * yc * rg * (1.f - rg);
+      const float dc = drc * rg;
+      float* o = dh + (long)r * lddh + j;
+      const float dhd = g * (1.f - ug);
+      *o = accumulate_dh ? (*o + dhd) : dhd;
+      dyw[j] = dr;
+      dyw[De + j] = dc;
+      dyw[2 * De + j] = du;
+      s1 += dr * gr + dc * gc + du * gu;
+      s2 += dr * gr * xr + dc * gc * xc + du * gu * xu;
+    }
+    s1 = group_sum<64>(s1) * inv_n;
+    s2 = group_sum<64>(s2) * inv_n;
+    // same lane wrote and reads dyw[c] for c == l (mod 64) only when De % 64 == 0; otherwise sync the wave
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (int c = l; c < N; c += 64) {
+      const float xh = (pr[c] - mean) * rstd;
+      const float dy = dyw[c];
+      dp[(long)r * lddp + c] = rstd * (dy * gamma[c] - s1 - xh * s2);
+      if (dgamma) {
+        atomicAdd(accg + c, dy * xh);
+        atomicAdd(accb + c, dy);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+  }
+  if (dgamma) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += 256) {
+      atomicAdd(dgamma + c, accg[c]);
+      atomicAdd(dbeta + c, accb[c]);
+    }
+  }
+}
+
+template <int LPR, int NV>
+static void launch_ln_fwd(const float* x, long ldx, const float* g, const float* b, float* y, long ldy, float* mean,
+                          float* rstd, long R, int N, int act, int G, hipStream_t s) {
+  const long rpb = 256 / LPR;
+  long blocks = (R + rpb - 1) / rpb;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((ln_act_fwd_kernel<LPR, NV>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, g, b, y, ldy, mean,
+                     rstd, R, N, act, G);
+}
+template <int LPR, int NV>
+static void launch_ln_bwd(const float* dy, long lddy, const float* x, long ldx, const float* g, const float* b,
+                          const float* mean, const float* rstd, float* dx, long lddx, float* dg, float* db, long R,
+                          int N, int act, int G, int acc, hipStream_t s) {
+  const long rpb = 256 / LPR;
+  long blocks = (R + rpb - 1) / rpb;
+  if (blocks > 512) blocks = 512;  // fewer blocks -> fewer dgamma/dbeta atomics
+  hipLaunchKernelGGL((ln_act_bwd_kernel<LPR, NV>), dim3((unsigned)blocks), dim3(256), 0, s, dy, lddy, x, ldx, g, b, mean,
+                     rstd, dx, lddx, dg, db, R, N, act, G, acc);
+}
+static int pick_lpr(int N) {
+  int lpr = 4;
+  while (lpr < 64 && lpr < N) lpr <<= 1;
+  return lpr;
+}
+// dispatch on (lanes per row, elements per lane): sub-wave groups for short rows (conv channels),
+// a full wave with 1..32 cached elements per lane for long ones
+#define DV3_LN_DISPATCH(FN, ...)                                   \
+  do {                                                             \
+    const int lpr_ = pick_lpr(N);                                  \
+    if (lpr_ == 4) FN<4, 1>(__VA_ARGS__);                          \
+    else if (lpr_ == 8) FN<8, 1>(__VA_ARGS__);                     \
+    else if (lpr_ == 16) FN<16, 1>(__VA_ARGS__);                   \
+    else if (lpr_ == 32) FN<32, 1>(__VA_ARGS__);                   \
+    else {                                                         \
+      const int nv_ = (N + 63) / 64;                               \
+      if (nv_ <= 1) FN<64, 1>(__VA_ARGS__);                        \
+      else if (nv_ <= 2) FN<64, 2>(__VA_ARGS__);                   \
+      else if (nv_ <= 4) FN<64, 4>(__VA_ARGS__);                   \
+      else if (nv_ <= 8) FN<64, 8>(__VA_ARGS__);                   \
+      else if (nv_ <= 16) FN<64, 16>(__VA_ARGS__);                 \
+      else FN<64, 32>(__VA_ARGS__);                                \
+    }                                                              \
+  } while (0)
+
+}  // namespace dv3
+
+using namespace dv3;
+
+extern "C" int dv3_ln_act_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy,
+                              float* mean, float* rstd, long R, int N, int act, int chw_group, void* stream) {
+  if (R <= 0) return 0;
+  if (N <= 0 || N > 64 * kMaxV || !x || !y || !gamma || !beta) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DV3_LN_DISPATCH(launch_ln_fwd, x, ldx, gamma, beta, y, ldy, mean, rstd, R, N, act, chw_group, s);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
+                              const float* beta, const float* mean, const float* rstd, float* dx, long lddx,
+                              float* dgamma, float* dbeta, long R, int N, int act, int chw_group, int accumulate_dx,
+                              void* stream) {
+  if (R <= 0) return 0;
+  if (N <= 0 || N > 64 * kMaxV || !x || !dy || !dx || !gamma || !beta || !mean || !rstd) return DV3_ERR_ARG;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DV3_LN_DISPATCH(launch_ln_bwd, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, R, N, act, chw_group,
+                  accumulate_dx, s);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_gru_fwd(const float* p, long ldp, const float* gamma, const float* beta, const float* h, long ldh,
+                           float* h_new, long ldhn, float* mean, float* rstd, int M, int De, void* stream) {
+  if (M <= 0) return 0;
+  if (De <= 0 || !p || !gamma || !beta || !h || !h_new || !mean || !rstd) return DV3_ERR_ARG;
+  int blocks = (M + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, ldp, gamma, beta, h, ldh,
+                     h_new, ldhn, mean, rstd, M, De);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_gru_bwd(const float* dh_new, long lddhn, const float* p, long ldp, const float* gamma,
+                           const float* beta, const float* h, long ldh, const float* mean, const float* rstd,
+                           float* dp, long lddp, float* dh, long lddh, float* dgamma, float* dbeta, int M, int De,
+                           int accumulate_dh, void* stream) {
+  if (M <= 0) return 0;
+  if (De <= 0 || !dh_new || !p || !gamma || !beta || !h || !mean || !rstd || !dp || !dh) return DV3_ERR_ARG;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return DV3_ERR_ARG;
+  const size_t shmem = (size_t)6 * 3 * De * sizeof(float);
+  if (shmem > 150 * 1024) return DV3_ERR_ARG;  // De <= 2048; larger cells need the block-per-row variant
+  int blocks = (M + 3) / 4;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, dh_new, lddhn, p, ldp, gamma,
+                     beta, h, ldh, mean, rstd, dp, lddp, dh, lddh, dgamma, dbeta, M, De, accumulate_dh);
+  return (int)hipGetLastError();
+}

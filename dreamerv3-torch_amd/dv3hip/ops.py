@@ -1,0 +1,517 @@
+"""Tensor-level wrappers over the libdv3hip C ABI (one function per entry point).
+
+Host-side contract checks live here: every wrapper validates device, dtype, contiguity and the
+shapes the kernel and its grid assume BEFORE anything is launched (a faulting kernel can take the
+whole node down).  All launches go to torch's current stream and are hipGraph-capturable.
+PyTorch is used for device memory and streams only; no ATen math on this path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _f32(t: torch.Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != F32:
+        raise TypeError(f"{name}: expected a CUDA/HIP float32 tensor, got "
+                        f"{type(t).__name__} {getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
+
+
+def _rows2d(t: torch.Tensor, name: str):
+    """A 2-D (possibly row-strided) view with unit inner stride -> (rows, cols, ld)."""
+    _f32(t, name)
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        raise ValueError(f"{name}: need a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} "
+                         f"strides {t.stride()}")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+    return t.shape[0], t.shape[1], ld
+
+
+def _contig(t: torch.Tensor, name: str, dtype=F32) -> None:
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise TypeError(f"{name}: expected a contiguous CUDA/HIP {dtype} tensor")
+
+
+def _call(fn_name: str, *args) -> None:
+    lib = _lib.load()
+    _lib.check(getattr(lib, fn_name)(*args), fn_name)
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=False, tile=-1):
+    """C (+)= [A|A2] @ op(B) + bias.   op(B)[K,N]: transB -> B is [N,K]; else B is [K,N]."""
+    ra, ca, lda = _rows2d(A, "A")
+    rb, cb, ldb = _rows2d(B, "B")
+    M, N, ldc = _rows2d(C, "C")
+    Ka = ra if transA else ca
+    Ma = ca if transA else ra
+    Kb, Nb = (cb, rb) if transB else (rb, cb)
+    K1 = Ka
+    K = Ka
+    lda2 = 0
+    if A2 is not None:
+        if transA:
+            raise ValueError("A2 requires transA=False")
+        r2, c2, lda2 = _rows2d(A2, "A2")
+        if r2 != Ma:
+            raise ValueError("A2 rows mismatch")
+        K = Ka + c2
+    if Ma != M or Nb != N or Kb != K:
+        raise ValueError(f"gemm shape mismatch: A{'^T' if transA else ''}[{Ma},{K}] B[{Kb},{Nb}] C[{M},{N}]")
+    if bias is not None:
+        _contig(bias, "bias")
+        if bias.numel() != N:
+            raise ValueError("bias size mismatch")
+    s = _stream()
+    if A2 is not None and (K1 % 32) != 0:
+        # segment edge not on a K-tile boundary: two passes, the second accumulating
+        Bv1 = B[:, :K1] if transB else B[:K1]
+        Bv2 = B[:, K1:] if transB else B[K1:]
+        gemm(A, Bv1, C, transA=False, transB=transB, bias=bias, accumulate=accumulate, tile=tile)
+        gemm(A2, Bv2, C, transA=False, transB=transB, accumulate=True, tile=tile)
+        return C
+    _call("dv3_gemm_f32", int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(A2), lda2, K1, _ptr(B), ldb,
+          _ptr(C), ldc, _ptr(bias), int(accumulate), tile, s)
+    return C
+
+
+def ln_act_fwd(x, gamma, beta, y, mean=None, rstd=None, *, act=True, chw_group=0):
+    R, N, ldx = _rows2d(x, "x")
+    _contig(gamma, "gamma"), _contig(beta, "beta")
+    if gamma.numel() != N or beta.numel() != N:
+        raise ValueError("LN affine size mismatch")
+    if chw_group:
+        _contig(y, "y")
+        if y.numel() != R * N or R % chw_group:
+            raise ValueError("chw output size mismatch")
+        ldy = N
+    else:
+        Ry, Ny, ldy = _rows2d(y, "y")
+        if (Ry, Ny) != (R, N):
+            raise ValueError("y shape mismatch")
+    for t, nm in ((mean, "mean"), (rstd, "rstd")):
+        if t is not None:
+            _contig(t, nm)
+            if t.numel() != R:
+                raise ValueError(nm + " size mismatch")
+    _call("dv3_ln_act_fwd", _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(y), ldy, _ptr(mean), _ptr(rstd), R, N,
+          int(act), int(chw_group), _stream())
+    return y
+
+
+def ln_act_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma=None, dbeta=None, *, act=True, chw_group=0,
+               accumulate_dx=False):
+    R, N, ldx = _rows2d(x, "x")
+    if chw_group:
+        _contig(dy, "dy")
+        if dy.numel() != R * N:
+            raise ValueError("dy size mismatch")
+        lddy = N
+    else:
+        Rd, Nd, lddy = _rows2d(dy, "dy")
+        if (Rd, Nd) != (R, N):
+            raise ValueError("dy shape mismatch")
+    Rx, Nx, lddx = _rows2d(dx, "dx")
+    if (Rx, Nx) != (R, N):
+        raise ValueError("dx shape mismatch")
+    _contig(gamma, "gamma"), _contig(beta, "beta"), _contig(mean, "mean"), _contig(rstd, "rstd")
+    if gamma.numel() != N or beta.numel() != N or mean.numel() != R or rstd.numel() != R:
+        raise ValueError("LN bwd size mismatch")
+    if (dgamma is None) != (dbeta is None):
+        raise ValueError("dgamma/dbeta: both or neither")
+    if dgamma is not None:
+        _contig(dgamma, "dgamma"), _contig(dbeta, "dbeta")
+        if dgamma.numel() != N or dbeta.numel() != N:
+            raise ValueError("dgamma size mismatch")
+    _call("dv3_ln_act_bwd", _ptr(dy), lddy, _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx),
+          lddx, _ptr(dgamma), _ptr(dbeta), R, N, int(act), int(chw_group), int(accumulate_dx), _stream())
+    return dx
+
+
+def gru_fwd(p, gamma, beta, h, h_new, mean, rstd):
+    M, N3, ldp = _rows2d(p, "p")
+    Mh, De, ldh = _rows2d(h, "h")
+    Mn, Dn, ldhn = _rows2d(h_new, "h_new")
+    if N3 != 3 * De or Mh != M or (Mn, Dn) != (M, De):
+        raise ValueError("gru shapes mismatch")
+    _contig(gamma, "gamma"), _contig(beta, "beta"), _contig(mean, "mean"), _contig(rstd, "rstd")
+    if gamma.numel() != N3 or beta.numel() != N3 or mean.numel() != M or rstd.numel() != M:
+        raise ValueError("gru param sizes mismatch")
+    _call("dv3_gru_fwd", _ptr(p), ldp, _ptr(gamma), _ptr(beta), _ptr(h), ldh, _ptr(h_new), ldhn, _ptr(mean),
+          _ptr(rstd), M, De, _stream())
+    return h_new
+
+
+def gru_bwd(dh_new, p, gamma, beta, h, mean, rstd, dp, dh, dgamma=None, dbeta=None, *, accumulate_dh=False):
+    M, N3, ldp = _rows2d(p, "p")
+    Mh, De, ldh = _rows2d(h, "h")
+    Mg, Dg, lddhn = _rows2d(dh_new, "dh_new")
+    Mp, Np, lddp = _rows2d(dp, "dp")
+    Md, Dd, lddh = _rows2d(dh, "dh")
+    if N3 != 3 * De or Mh != M or (Mg, Dg) != (M, De) or (Mp, Np) != (M, N3) or (Md, Dd) != (M, De):
+        raise ValueError("gru bwd shapes mismatch")
+    _contig(gamma, "gamma"), _contig(beta, "beta"), _contig(mean, "mean"), _contig(rstd, "rstd")
+    if gamma.numel() != N3 or mean.numel() != M or rstd.numel() != M:
+        raise ValueError("gru bwd sizes mismatch")
+    if (dgamma is None) != (dbeta is None):
+        raise ValueError("dgamma/dbeta: both or neither")
+    if dgamma is not None:
+        _contig(dgamma, "dgamma"), _contig(dbeta, "dbeta")
+        if dgamma.numel() != N3 or dbeta.numel() != N3:
+            raise ValueError("dgamma size mismatch")
+    _call("dv3_gru_bwd", _ptr(dh_new), lddhn, _ptr(p), ldp, _ptr(gamma), _ptr(beta), _ptr(h), ldh, _ptr(mean),
+          _ptr(rstd), _ptr(dp), lddp, _ptr(dh), lddh, _ptr(dgamma), _ptr(dbeta), M, De, int(accumulate_dh), _stream())
+
+
+def _groups(t, name, D):
+    _contig(t, name)
+    if t.shape[-1] != D or t.numel() % D:
+        raise ValueError(f"{name}: last dim must be {D}")
+    return t.numel() // D
+
+
+def onehot_sample(logit, out, *, noise=None, rng_state=None, idx=None, unimix=0.01, mode=False):
+    D = logit.shape[-1]
+    R = _groups(logit, "logit", D)
+    if _groups(out, "out", D) != R:
+        raise ValueError("out size mismatch")
+    if noise is not None and _groups(noise, "noise", D) != R:
+        raise ValueError("noise size mismatch")
+    if rng_state is not None:
+        _contig(rng_state, "rng_state", torch.int64)
+        if rng_state.numel() < 2:
+            raise ValueError("rng_state needs {seed, offset}")
+    if idx is not None:
+        _contig(idx, "idx", torch.int32)
+        if idx.numel() != R:
+            raise ValueError("idx size mismatch")
+    if not mode and noise is None and rng_state is None:
+        raise ValueError("sampling needs noise or rng_state")
+    _call("dv3_onehot_sample_fwd", _ptr(logit), _ptr(noise), _ptr(rng_state), _ptr(out), _ptr(idx), R, D,
+          float(unimix), int(mode), _stream())
+    return out
+
+
+def onehot_st_bwd(logit, dstoch, dlogit, *, unimix=0.01, mode=False, accumulate=False):
+    D = logit.shape[-1]
+    R = _groups(logit, "logit", D)
+    if _groups(dstoch, "dstoch", D) != R or _groups(dlogit, "dlogit", D) != R:
+        raise ValueError("size mismatch")
+    _call("dv3_onehot_st_bwd", _ptr(logit), _ptr(dstoch), _ptr(dlogit), R, D, float(unimix), int(mode),
+          int(accumulate), _stream())
+    return dlogit
+
+
+def onehot_ent_logp_fwd(logit, x=None, ent=None, logp=None, *, unimix=0.01):
+    D = logit.shape[-1]
+    R = _groups(logit, "logit", D)
+    if x is not None and _groups(x, "x", D) != R:
+        raise ValueError("x size mismatch")
+    for t, nm in ((ent, "ent"), (logp, "logp")):
+        if t is not None:
+            _contig(t, nm)
+            if t.numel() != R:
+                raise ValueError(nm + " size mismatch")
+    _call("dv3_onehot_ent_logp_fwd", _ptr(logit), _ptr(x), _ptr(ent), _ptr(logp), R, D, float(unimix), _stream())
+
+
+def onehot_ent_logp_bwd(logit, x, dent, dlogp, dlogit, *, unimix=0.01, accumulate=False):
+    D = logit.shape[-1]
+    R = _groups(logit, "logit", D)
+    if _groups(dlogit, "dlogit", D) != R:
+        raise ValueError("dlogit size mismatch")
+    for t, nm in ((dent, "dent"), (dlogp, "dlogp")):
+        if t is not None:
+            _contig(t, nm)
+            if t.numel() != R:
+                raise ValueError(nm + " size mismatch")
+    if x is not None and _groups(x, "x", D) != R:
+        raise ValueError("x size mismatch")
+    _call("dv3_onehot_ent_logp_bwd", _ptr(logit), _ptr(x), _ptr(dent), _ptr(dlogp), _ptr(dlogit), R, D,
+          float(unimix), int(accumulate), _stream())
+
+
+def kl_fwd(post_logit, prior_logit, kl, ent_post=None, ent_prior=None, *, unimix=0.01):
+    S, D = post_logit.shape[-2], post_logit.shape[-1]
+    _contig(post_logit, "post_logit"), _contig(prior_logit, "prior_logit"), _contig(kl, "kl")
+    rows = post_logit.numel() // (S * D)
+    if prior_logit.shape != post_logit.shape or kl.numel() != rows:
+        raise ValueError("kl shapes mismatch")
+    for t, nm in ((ent_post, "ent_post"), (ent_prior, "ent_prior")):
+        if t is not None:
+            _contig(t, nm)
+            if t.numel() != rows:
+                raise ValueError(nm + " size mismatch")
+    _call("dv3_kl_fwd", _ptr(post_logit), _ptr(prior_logit), _ptr(kl), _ptr(ent_post), _ptr(ent_prior), rows, S, D,
+          float(unimix), _stream())
+
+
+def kl_bwd(post_logit, prior_logit, kl, dpost, dprior, *, unimix, free, dyn_scale, rep_scale, upstream,
+           acc_post=False, acc_prior=False):
+    S, D = post_logit.shape[-2], post_logit.shape[-1]
+    for t, nm in ((post_logit, "post"), (prior_logit, "prior"), (kl, "kl"), (dpost, "dpost"), (dprior, "dprior")):
+        _contig(t, nm)
+    rows = post_logit.numel() // (S * D)
+    if (prior_logit.shape != post_logit.shape or dpost.numel() != post_logit.numel()
+            or dprior.numel() != post_logit.numel() or kl.numel() != rows):
+        raise ValueError("kl bwd shapes mismatch")
+    _call("dv3_kl_bwd", _ptr(post_logit), _ptr(prior_logit), _ptr(kl), _ptr(dpost), _ptr(dprior), rows, S, D,
+          float(unimix), float(free), float(dyn_scale), float(rep_scale), float(upstream), int(acc_post),
+          int(acc_prior), _stream())
+
+
+def _disc_rows(logits):
+    _contig(logits, "logits")
+    if logits.shape[-1] != 255:
+        raise ValueError("DiscDist heads have 255 buckets")
+    return logits.numel() // 255
+
+
+def disc_mode_fwd(logits, out):
+    R = _disc_rows(logits)
+    _contig(out, "out")
+    if out.numel() != R:
+        raise ValueError("out size mismatch")
+    _call("dv3_disc_mode_fwd", _ptr(logits), _ptr(out), R, _stream())
+    return out
+
+
+def disc_mode_bwd(logits, up, dlogits, *, accumulate=False):
+    R = _disc_rows(logits)
+    _contig(up, "up"), _contig(dlogits, "dlogits")
+    if up.numel() != R or dlogits.numel() != R * 255:
+        raise ValueError("size mismatch")
+    _call("dv3_disc_mode_bwd", _ptr(logits), _ptr(up), _ptr(dlogits), R, int(accumulate), _stream())
+
+
+def disc_logprob_fwd(logits, x, out):
+    R = _disc_rows(logits)
+    _contig(x, "x"), _contig(out, "out")
+    if x.numel() != R or out.numel() != R:
+        raise ValueError("size mismatch")
+    _call("dv3_disc_logprob_fwd", _ptr(logits), _ptr(x), _ptr(out), R, _stream())
+    return out
+
+
+def disc_logprob_bwd(logits, x, up, dlogits, *, accumulate=False):
+    R = _disc_rows(logits)
+    _contig(x, "x"), _contig(up, "up"), _contig(dlogits, "dlogits")
+    if x.numel() != R or up.numel() != R or dlogits.numel() != R * 255:
+        raise ValueError("size mismatch")
+    _call("dv3_disc_logprob_bwd", _ptr(logits), _ptr(x), _ptr(up), _ptr(dlogits), R, int(accumulate), _stream())
+
+
+def bernoulli_logprob_fwd(logit, x, out):
+    for t, nm in ((logit, "logit"), (x, "x"), (out, "out")):
+        _contig(t, nm)
+    n = logit.numel()
+    if x.numel() != n or out.numel() != n:
+        raise ValueError("size mismatch")
+    _call("dv3_bernoulli_logprob_fwd", _ptr(logit), _ptr(x), _ptr(out), n, _stream())
+    return out
+
+
+def bernoulli_logprob_bwd(logit, x, up, dlogit, *, accumulate=False):
+    for t, nm in ((logit, "logit"), (x, "x"), (up, "up"), (dlogit, "dlogit")):
+        _contig(t, nm)
+    n = logit.numel()
+    if x.numel() != n or up.numel() != n or dlogit.numel() != n:
+        raise ValueError("size mismatch")
+    _call("dv3_bernoulli_logprob_bwd", _ptr(logit), _ptr(x), _ptr(up), _ptr(dlogit), n, int(accumulate), _stream())
+
+
+def image_to_f32(image_u8, out):
+    _contig(image_u8, "image", torch.uint8), _contig(out, "out")
+    if out.numel() != image_u8.numel():
+        raise ValueError("size mismatch")
+    _call("dv3_image_to_f32", _ptr(image_u8), _ptr(out), image_u8.numel(), _stream())
+    return out
+
+
+def mse_image(recon, image_u8, loss, drecon=None, *, upstream=0.0):
+    _contig(recon, "recon"), _contig(image_u8, "image", torch.uint8), _contig(loss, "loss")
+    n_img = loss.numel()
+    if recon.numel() != image_u8.numel() or recon.numel() % max(n_img, 1):
+        raise ValueError("size mismatch")
+    pixels = recon.numel() // n_img
+    if drecon is not None:
+        _contig(drecon, "drecon")
+        if drecon.numel() != recon.numel():
+            raise ValueError("drecon size mismatch")
+    _call("dv3_mse_image", _ptr(recon), _ptr(image_u8), _ptr(loss), _ptr(drecon), n_img, pixels, float(upstream),
+          _stream())
+
+
+def symlog(x, y):
+    _contig(x, "x"), _contig(y, "y")
+    if x.numel() != y.numel():
+        raise ValueError("size mismatch")
+    _call("dv3_symlog", _ptr(x), _ptr(y), x.numel(), _stream())
+    return y
+
+
+def symlog_mse(mode, x, loss, dmode=None, *, upstream=0.0):
+    _contig(mode, "mode"), _contig(x, "x"), _contig(loss, "loss")
+    W = mode.shape[-1]
+    R = mode.numel() // W
+    if x.shape != mode.shape or loss.numel() != R:
+        raise ValueError("size mismatch")
+    if dmode is not None:
+        _contig(dmode, "dmode")
+        if dmode.numel() != mode.numel():
+            raise ValueError("dmode size mismatch")
+    _call("dv3_symlog_mse", _ptr(mode), _ptr(x), _ptr(loss), _ptr(dmode), R, W, float(upstream), _stream())
+
+
+def actor_normal_fwd(mean_raw, std_raw, eps=None, action=None, entropy=None, *, min_std=0.1, max_std=1.0):
+    _contig(mean_raw, "mean_raw"), _contig(std_raw, "std_raw")
+    A = mean_raw.shape[-1]
+    M = mean_raw.numel() // A
+    if std_raw.shape != mean_raw.shape:
+        raise ValueError("std shape mismatch")
+    for t, nm in ((eps, "eps"), (action, "action")):
+        if t is not None:
+            _contig(t, nm)
+            if t.numel() != M * A:
+                raise ValueError(nm + " size mismatch")
+    if entropy is not None:
+        _contig(entropy, "entropy")
+        if entropy.numel() != M:
+            raise ValueError("entropy size mismatch")
+    _call("dv3_actor_normal_fwd", _ptr(mean_raw), _ptr(std_raw), _ptr(eps), _ptr(action), _ptr(entropy), M, A,
+          float(min_std), float(max_std), _stream())
+
+
+def actor_normal_logp(mean_raw, std_raw, action, logp, *, min_std=0.1, max_std=1.0):
+    for t, nm in ((mean_raw, "mean_raw"), (std_raw, "std_raw"), (action, "action"), (logp, "logp")):
+        _contig(t, nm)
+    A = mean_raw.shape[-1]
+    M = mean_raw.numel() // A
+    if std_raw.numel() != M * A or action.numel() != M * A or logp.numel() != M:
+        raise ValueError("size mismatch")
+    _call("dv3_actor_normal_logp", _ptr(mean_raw), _ptr(std_raw), _ptr(action), _ptr(logp), M, A, float(min_std),
+          float(max_std), _stream())
+
+
+def actor_normal_bwd(mean_raw, std_raw, dmean_raw, dstd_raw, *, eps=None, action=None, daction=None, dent=None,
+                     dlogp=None, min_std=0.1, max_std=1.0):
+    for t, nm in ((mean_raw, "mean_raw"), (std_raw, "std_raw"), (dmean_raw, "dmean_raw"), (dstd_raw, "dstd_raw")):
+        _contig(t, nm)
+    A = mean_raw.shape[-1]
+    M = mean_raw.numel() // A
+    for t, nm, n in ((eps, "eps", M * A), (action, "action", M * A), (daction, "daction", M * A), (dent, "dent", M),
+                     (dlogp, "dlogp", M)):
+        if t is not None:
+            _contig(t, nm)
+            if t.numel() != n:
+                raise ValueError(nm + " size mismatch")
+    if std_raw.numel() != M * A or dmean_raw.numel() != M * A or dstd_raw.numel() != M * A:
+        raise ValueError("size mismatch")
+    _call("dv3_actor_normal_bwd", _ptr(mean_raw), _ptr(std_raw), _ptr(eps), _ptr(action), _ptr(daction), _ptr(dent),
+          _ptr(dlogp), _ptr(dmean_raw), _ptr(dstd_raw), M, A, float(min_std), float(max_std), _stream())
+
+
+def lambda_return_fwd(reward, value, cont_logit, target, weights, disc=None, *, gamma, lam):
+    for t, nm in ((reward, "reward"), (value, "value"), (cont_logit, "cont_logit"), (target, "target"),
+                  (weights, "weights")):
+        _contig(t, nm)
+    H = reward.shape[0]
+    N = reward.numel() // H
+    if value.numel() != H * N or cont_logit.numel() != H * N or weights.numel() != H * N or target.numel() != (H - 1) * N:
+        raise ValueError("size mismatch")
+    if disc is not None:
+        _contig(disc, "disc")
+        if disc.numel() != H * N:
+            raise ValueError("disc size mismatch")
+    _call("dv3_lambda_return_fwd", _ptr(reward), _ptr(value), _ptr(cont_logit), _ptr(target), _ptr(weights),
+          _ptr(disc), H, N, float(gamma), float(lam), _stream())
+
+
+def lambda_return_bwd(dtarget, value, cont_logit, target, dreward, dcont_logit, *, gamma, lam):
+    for t, nm in ((dtarget, "dtarget"), (value, "value"), (cont_logit, "cont_logit"), (target, "target"),
+                  (dreward, "dreward"), (dcont_logit, "dcont_logit")):
+        _contig(t, nm)
+    H = value.shape[0]
+    N = value.numel() // H
+    if (dtarget.numel() != (H - 1) * N or target.numel() != (H - 1) * N or cont_logit.numel() != H * N
+            or dreward.numel() != H * N or dcont_logit.numel() != H * N):
+        raise ValueError("size mismatch")
+    _call("dv3_lambda_return_bwd", _ptr(dtarget), _ptr(value), _ptr(cont_logit), _ptr(target), _ptr(dreward),
+          _ptr(dcont_logit), H, N, float(gamma), float(lam), _stream())
+
+
+def reset_blend(x, init, is_first, out):
+    B, n, ldo = _rows2d(out, "out")
+    ldx = 0
+    if x is not None:
+        Bx, nx, ldx = _rows2d(x, "x")
+        if (Bx, nx) != (B, n):
+            raise ValueError("x shape mismatch")
+    if init is not None:
+        _contig(init, "init")
+        if init.numel() != n:
+            raise ValueError("init size mismatch")
+    _contig(is_first, "is_first")
+    if is_first.numel() != B:
+        raise ValueError("is_first size mismatch")
+    _call("dv3_reset_blend", _ptr(x), ldx, _ptr(init), _ptr(is_first), _ptr(out), ldo, B, n, _stream())
+    return out
+
+
+def reset_blend_bwd(dout, is_first, dx=None, dinit=None):
+    B, n, ldo = _rows2d(dout, "dout")
+    ldx = 0
+    if dx is not None:
+        Bx, nx, ldx = _rows2d(dx, "dx")
+        if (Bx, nx) != (B, n):
+            raise ValueError("dx shape mismatch")
+    if dinit is not None:
+        _contig(dinit, "dinit")
+        if dinit.numel() != n:
+            raise ValueError("dinit size mismatch")
+    _contig(is_first, "is_first")
+    if is_first.numel() != B:
+        raise ValueError("is_first size mismatch")
+    _call("dv3_reset_blend_bwd", _ptr(dout), ldo, _ptr(is_first), _ptr(dx), ldx, _ptr(dinit), B, n, _stream())
+
+
+def sumsq_accumulate(x, out):
+    _contig(x, "x"), _contig(out, "out")
+    _call("dv3_sumsq_accumulate", _ptr(x), x.numel(), _ptr(out), _stream())
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, state, *, lr, beta1=0.9, beta2=0.999, eps, clip, weight_decay=0.0):
+    for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"),
+                  (state, "state")):
+        _contig(t, nm)
+    n = param.numel()
+    if grad.numel() != n or exp_avg.numel() != n or exp_avg_sq.numel() != n or state.numel() < 3:
+        raise ValueError("size mismatch")
+    _call("dv3_adam_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, _ptr(state), float(lr),
+          float(beta1), float(beta2), float(eps), float(clip or 0.0), float(weight_decay or 0.0), _stream())
+
+
+def axpby(x, y, a, b):
+    _contig(x, "x"), _contig(y, "y")
+    if x.numel() != y.numel():
+        raise ValueError("size mismatch")
+    _call("dv3_axpby", _ptr(x), _ptr(y), x.numel(), float(a), float(b), _stream())
+    return y
+
+
+def rng_advance(rng_state, increment):
+    _contig(rng_state, "rng_state", torch.int64)
+    _call("dv3_rng_advance", _ptr(rng_state), int(increment), _stream())

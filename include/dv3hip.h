@@ -1,0 +1,160 @@
+/* libdv3hip -- C ABI of the MI355X-native (gfx950) DreamerV3 world-model training hot path.
+ *
+ * The reference (ChenFengTsai/dreamerv3-torch) is pure Python on PyTorch: it has no FFI, plugin or
+ * operator registry.  The "interface each entry point replaces" is therefore the ATen op sequence
+ * a reference Python method issues; every declaration below cites that method (file:line in the
+ * reference checkout).  The Python class surface that sits on top of this ABI (networks.RSSM,
+ * models.WorldModel, ...) mirrors the reference's names and signatures; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (fp32 unless typed otherwise), caller-allocated; no entry
+ *     point allocates, frees, synchronises or keeps state between calls.
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); every launch is
+ *     asynchronous on it and is hipGraph-capturable.
+ *   - Return value: 0 on success, DV3_ERR_ARG (10001) when an argument is rejected before any
+ *     launch, otherwise the hipError_t of the failed launch.  Nothing throws across the ABI.
+ *   - Row-major everywhere; `ld*` are leading dimensions in elements.
+ *   - "accumulate" flags: 0 = overwrite the output, 1 = add into it.
+ */
+#ifndef DV3HIP_H_
+#define DV3HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DV3_ERR_ARG 10001
+
+int dv3_version(void);
+
+/* ---- dense layers -------------------------------------------------------------------------------
+ * C[M,N] (+)= [A | A2][M,K] * op(B)[K,N] + bias[N] on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+ *   transA=0: A[m*lda+k]   transA=1: A[k*lda+m]      transB=1: B[n*ldb+k]   transB=0: B[k*ldb+n]
+ *   A2/K1: optional second K segment (columns K1..K-1 come from A2[m*lda2 + k-K1]); K1 % 32 == 0,
+ *          transA must be 0.  Pass A2=NULL for a single operand.
+ *   tile: -1 = choose, 0 = 128x128, 1 = 64x64, 2 = 32x128.
+ * Replaces nn.Linear forward / its autograd transposes in RSSM.img_step, obs_step
+ * (networks.py:195-233), GRUCell.forward (networks.py:762), MLP.forward (networks.py:657-681),
+ * ConvDecoder._linear_layer (networks.py:569), and the torch.cat in front of them
+ * (networks.py:154-159, 196, 216, 762). */
+int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* A2,
+                 long lda2, int K1, const float* B, long ldb, float* C, long ldc, const float* bias,
+                 int accumulate, int tile, void* stream);
+
+/* ---- LayerNorm(eps 1e-3) [+ SiLU] ----------------------------------------------------------------
+ * y = act(LN(x) * gamma + beta), rows of length N <= 2048; mean/rstd [R] are saved for the backward
+ * (may be NULL in fwd).  act: 0 none, 1 SiLU.  chw_group G > 0 addresses y (fwd) / dy (bwd) as the
+ * (C,H,W) flatten of G-pixel images: element (r,c) at (r/G)*N*G + c*G + r%G (networks.py:494).
+ * Replaces nn.LayerNorm + SiLU (networks.py:55-56, 66-67, 75-76, 631-633) and ImgChLayerNorm + SiLU
+ * (networks.py:476-477, 552-554, 801-810).  bwd ACCUMULATES dgamma/dbeta (both or neither NULL). */
+int dv3_ln_act_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy,
+                   float* mean, float* rstd, long R, int N, int act, int chw_group, void* stream);
+int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma, const float* beta,
+                   const float* mean, const float* rstd, float* dx, long lddx, float* dgamma, float* dbeta,
+                   long R, int N, int act, int chw_group, int accumulate_dx, void* stream);
+
+/* ---- LayerNorm-GRU gates -- GRUCell.forward (networks.py:760-768) ---------------------------------
+ * p [M,3*De] is the output of the fused Linear on cat[x,h]; LN over all 3*De, then
+ * r=sigmoid, c=tanh(r*c), u=sigmoid(u-1), h' = u*c + (1-u)*h.   De <= 2048 for the backward. */
+int dv3_gru_fwd(const float* p, long ldp, const float* gamma, const float* beta, const float* h, long ldh,
+                float* h_new, long ldhn, float* mean, float* rstd, int M, int De, void* stream);
+int dv3_gru_bwd(const float* dh_new, long lddhn, const float* p, long ldp, const float* gamma, const float* beta,
+                const float* h, long ldh, const float* mean, const float* rstd, float* dp, long lddp, float* dh,
+                long lddh, float* dgamma, float* dbeta, int M, int De, int accumulate_dh, void* stream);
+
+/* ---- one-hot categorical with unimix -- tools.OneHotDist (tools.py:436-460) -----------------------
+ * R groups of D <= 64 classes.  sample: onehot(argmax p_hat/q), q = noise[R,D] ~ Exp(1) when given,
+ * else Philox draws from rng_state = {seed, offset} (device memory).  mode=1: onehot(argmax p_hat).
+ * idx (optional) receives the chosen class.  st_bwd is the straight-through gradient
+ * (tools.py:446-450, 456-459): dlogit (+)= J^T dstoch.  Used by RSSM.get_dist/get_stoch
+ * (networks.py:161-166, 235-239) and the discrete actor (networks.py:713-714). */
+int dv3_onehot_sample_fwd(const float* logit, const float* noise, const unsigned long long* rng_state,
+                          float* onehot, int* idx, long R, int D, float unimix, int mode, void* stream);
+int dv3_onehot_st_bwd(const float* logit, const float* dstoch, float* dlogit, long R, int D, float unimix,
+                      int mode, int accumulate, void* stream);
+/* entropy [R] and log-prob [R] of one-hot x (either output may be NULL), and their backward */
+int dv3_onehot_ent_logp_fwd(const float* logit, const float* x, float* ent, float* logp, long R, int D,
+                            float unimix, void* stream);
+int dv3_onehot_ent_logp_bwd(const float* logit, const float* x, const float* dent, const float* dlogp,
+                            float* dlogit, long R, int D, float unimix, int accumulate, void* stream);
+
+/* ---- RSSM.kl_loss (networks.py:272-290) ----------------------------------------------------------
+ * rows = B*T state rows of S groups x D classes.  fwd: kl[rows] = KL(post||prior) (the un-clipped
+ * `value`; dyn and rep share this forward value), plus both entropies (metrics models.py:158-163).
+ * bwd: gradient of  upstream * (dyn_scale*max(KL(sg(post)||prior),free) + rep_scale*max(KL(post||sg(prior)),free)). */
+int dv3_kl_fwd(const float* post_logit, const float* prior_logit, float* kl, float* ent_post, float* ent_prior,
+               long rows, int S, int D, float unimix, void* stream);
+int dv3_kl_bwd(const float* post_logit, const float* prior_logit, const float* kl, float* dpost, float* dprior,
+               long rows, int S, int D, float unimix, float free_nats, float dyn_scale, float rep_scale,
+               float upstream, int acc_post, int acc_prior, void* stream);
+
+/* ---- 255-bucket symlog two-hot head -- tools.DiscDist (tools.py:463-517) --------------------------
+ * logits [R,255].  mode: symexp(sum softmax*linspace(-20,20,255)).  logprob: two-hot cross-entropy of
+ * symlog(x[r]).  bwd: dlogits (+)= up[r] * d(out[r])/dlogits. */
+int dv3_disc_mode_fwd(const float* logits, float* out, long R, void* stream);
+int dv3_disc_mode_bwd(const float* logits, const float* up, float* dlogits, long R, int accumulate, void* stream);
+int dv3_disc_logprob_fwd(const float* logits, const float* x, float* out, long R, void* stream);
+int dv3_disc_logprob_bwd(const float* logits, const float* x, const float* up, float* dlogits, long R,
+                         int accumulate, void* stream);
+
+/* ---- continue head -- tools.Bernoulli.log_prob (tools.py:622-627) --------------------------------- */
+int dv3_bernoulli_logprob_fwd(const float* logit, const float* x, float* out, long n, void* stream);
+int dv3_bernoulli_logprob_bwd(const float* logit, const float* x, const float* up, float* dlogit, long n,
+                              int accumulate, void* stream);
+
+/* ---- image decode + reconstruction loss -----------------------------------------------------------
+ * dv3_image_to_f32: u8 -> u8/255 - 0.5 (WorldModel.preprocess models.py:180 + ConvEncoder networks.py:487).
+ * dv3_mse_image: loss[img] = sum_pixels (recon - u8/255)^2 (tools.MSEDist.log_prob, tools.py:531-540,
+ * negated), and, when drecon != NULL, drecon = 2*upstream*(recon - u8/255) in the same pass. */
+int dv3_image_to_f32(const unsigned char* image_u8, float* out, long n, void* stream);
+int dv3_mse_image(const float* recon, const unsigned char* image_u8, float* loss, float* drecon, long n_images,
+                  int pixels, float upstream, void* stream);
+
+/* ---- proprio inputs/outputs -- tools.symlog (tools.py:22-23), tools.SymlogDist (tools.py:543-572) --- */
+int dv3_symlog(const float* x, float* y, long n, void* stream);
+int dv3_symlog_mse(const float* mode, const float* x, float* loss, float* dmode, long R, int W, float upstream,
+                   void* stream);
+
+/* ---- continuous actor -- MLP.dist 'normal' (networks.py:693-700) + ContDist absmax (tools.py:594-598)
+ * mean_raw/std_raw [M,A] are the two head Linears.  fwd: action = rescale(tanh(mean) + std*eps)
+ * (action may be NULL), entropy [M] (may be NULL).  logp: Normal log_prob of a given action.
+ * bwd: any of daction / dent / dlogp may be NULL. */
+int dv3_actor_normal_fwd(const float* mean_raw, const float* std_raw, const float* eps, float* action,
+                         float* entropy, long M, int A, float min_std, float max_std, void* stream);
+int dv3_actor_normal_logp(const float* mean_raw, const float* std_raw, const float* action, float* logp, long M,
+                          int A, float min_std, float max_std, void* stream);
+int dv3_actor_normal_bwd(const float* mean_raw, const float* std_raw, const float* eps, const float* action,
+                         const float* daction, const float* dent, const float* dlogp, float* dmean_raw,
+                         float* dstd_raw, long M, int A, float min_std, float max_std, void* stream);
+
+/* ---- lambda-return + discount weights -- tools.lambda_return (tools.py:682-728),
+ * ImagBehavior._compute_target (models.py:620-638).  reward/value/cont_logit/weights/disc [H,N],
+ * target [H-1,N]; disc = gamma*sigmoid(cont_logit) (disc may be NULL). */
+int dv3_lambda_return_fwd(const float* reward, const float* value, const float* cont_logit, float* target,
+                          float* weights, float* disc, int H, long N, float gamma, float lam, void* stream);
+int dv3_lambda_return_bwd(const float* dtarget, const float* value, const float* cont_logit, const float* target,
+                          float* dreward, float* dcont_logit, int H, long N, float gamma, float lam, void* stream);
+
+/* ---- is_first reset -- RSSM.obs_step (networks.py:176-193), branch-free -----------------------------
+ * out[b,:] = x[b,:]*(1-m_b) + init[:]*m_b  (x or init may be NULL = zeros).  bwd: dx = dout*(1-m)
+ * (dx may be NULL), dinit += sum_b dout[b,:]*m_b (dinit may be NULL). */
+int dv3_reset_blend(const float* x, long ldx, const float* init, const float* is_first, float* out, long ldo,
+                    int B, int n, void* stream);
+int dv3_reset_blend_bwd(const float* dout, long ldo, const float* is_first, float* dx, long ldx, float* dinit,
+                        int B, int n, void* stream);
+
+/* ---- optimizer -- tools.Optimizer.__call__ (tools.py:760-776) on a flat fp32 bucket ----------------
+ * state[0] = step count, state[1] = sum of squares accumulator, state[2] = last grad norm.
+ * dv3_sumsq_accumulate adds sum(x^2) into *out (x 16-byte aligned).  dv3_adam_step clips by
+ * clip/(norm+1e-6) (clip <= 0: no clipping), applies torch.optim.Adam's update, bumps the step and
+ * clears the accumulator -- all on device.  dv3_axpby: y = a*x + b*y (slow critic, models.py:683-689). */
+int dv3_sumsq_accumulate(const float* x, long n, float* out, void* stream);
+int dv3_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float* state,
+                  float lr, float beta1, float beta2, float eps, float clip, float weight_decay, void* stream);
+int dv3_axpby(const float* x, float* y, long n, float a, float b, void* stream);
+int dv3_rng_advance(unsigned long long* rng_state, unsigned long long increment, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DV3HIP_H_ */

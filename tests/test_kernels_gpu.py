@@ -1,0 +1,454 @@
+"""Per-kernel parity: every libdv3hip entry point against the CPU oracle's math on seeded inputs.
+
+Floating-point bar (BASELINE.json north_star): fp32, 1e-4.  GEMM inputs are O(1) with K up to 4608,
+so absolute tolerances scale with sqrt(K).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dv3_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dv3hip import ops as _ops
+
+    return _ops
+
+
+def dev(x):
+    return x.cuda()
+
+
+def assert_close(got, ref, tol=TOL, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item() if got.numel() else 0.0
+    scale = max(1.0, ref.abs().max().item() if ref.numel() else 1.0)
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [
+    # M, N, K
+    (1024, 512, 1030),   # img_in: K not a multiple of anything
+    (1024, 1536, 1024),  # GRU
+    (16, 1536, 1024),    # observe-scan GRU (M = batch)
+    (16, 512, 4608),     # obs_out
+    (1024, 255, 512),    # reward head: N odd
+    (1024, 6, 512),      # actor mean
+    (100, 70, 50),       # ragged everything
+    (33, 129, 17),
+    (1, 1, 1),
+    (15360, 512, 1536),  # behaviour heads
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+def test_gemm_nt_bias(ops, M, N, K, tile):
+    if M * N * K > 5e9 and tile in (1, 2):
+        pytest.skip("large shape: default tile only")
+    g = torch.Generator().manual_seed(M * 31 + N * 7 + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    C = torch.full((M, N), float("nan")).cuda()
+    ops.gemm(dev(A), dev(W), C, bias=dev(b), tile=tile)
+    assert_close(C, A @ W.t() + b, what=f"gemm_nt {M}x{N}x{K} tile {tile}")
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1030, 512), (16, 1024, 1536), (77, 45, 130), (1024, 512, 255)])
+def test_gemm_nn_dgrad(ops, M, N, K):
+    g = torch.Generator().manual_seed(1)
+    dY = torch.randn(M, K, generator=g)
+    W = torch.randn(K, N, generator=g) / math.sqrt(K)
+    C = torch.empty(M, N).cuda()
+    ops.gemm(dev(dY), dev(W), C, transB=False)
+    assert_close(C, dY @ W, what="gemm_nn")
+
+
+@pytest.mark.parametrize("rows,Nout,Kin", [(1024, 512, 1030), (1024, 1536, 1024), (333, 70, 45), (14336, 255, 512)])
+def test_gemm_tn_wgrad_accumulate(ops, rows, Nout, Kin):
+    g = torch.Generator().manual_seed(2)
+    dY = torch.randn(rows, Nout, generator=g) / math.sqrt(rows)
+    X = torch.randn(rows, Kin, generator=g)
+    C0 = torch.randn(Nout, Kin, generator=g)
+    C = dev(C0.clone())
+    ops.gemm(dev(dY), dev(X), C, transA=True, transB=False, accumulate=True)
+    assert_close(C, C0 + dY.t() @ X, what="gemm_tn")
+
+
+@pytest.mark.parametrize("M,K1,K2,N", [(1024, 1024, 6, 512), (1024, 512, 512, 1536), (16, 512, 4096, 512),
+                                       (48, 16, 3, 16), (9, 64, 5, 33)])
+def test_gemm_two_segment_concat(ops, M, K1, K2, N):
+    """[A | A2] @ W^T == torch.cat([A, A2], -1) @ W^T, including row-strided views."""
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(M, K1 + 11, generator=g)
+    A = big[:, :K1]  # row-strided view
+    A2 = torch.randn(M, K2, generator=g)
+    W = torch.randn(N, K1 + K2, generator=g) / math.sqrt(K1 + K2)
+    C = torch.empty(M, N).cuda()
+    bigd = dev(big)
+    ops.gemm(bigd[:, :K1], dev(W), C, A2=dev(A2))
+    assert_close(C, torch.cat([A, A2], -1) @ W.t(), what="gemm_concat")
+
+
+def test_gemm_strided_output_slice(ops):
+    """dgrad into a column slice of a wider buffer (the backward of torch.cat)."""
+    g = torch.Generator().manual_seed(4)
+    dY = torch.randn(64, 48, generator=g)
+    W = torch.randn(48, 100, generator=g)
+    buf = torch.zeros(64, 130).cuda()
+    ops.gemm(dev(dY), dev(W)[:, 30:], buf[:, 10:80], transB=False)
+    ref = torch.zeros(64, 130)
+    ref[:, 10:80] = dY @ W[:, 30:]
+    assert_close(buf, ref, what="gemm slice")
+
+
+def test_gemm_is_exact_fp32_on_integers(ops):
+    """MFMA fp32 is an exact fma chain: small-integer data must reproduce bit-exactly."""
+    g = torch.Generator().manual_seed(5)
+    A = torch.randint(-4, 5, (130, 200), generator=g).float()
+    W = torch.randint(-4, 5, (70, 200), generator=g).float()  # asymmetric on purpose (layout check)
+    C = torch.empty(130, 70).cuda()
+    ops.gemm(dev(A), dev(W), C)
+    assert torch.equal(C.cpu(), A @ W.t())
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    A = torch.zeros(8, 16).cuda()
+    W = torch.zeros(4, 17).cuda()
+    C = torch.zeros(8, 4).cuda()
+    with pytest.raises(ValueError):
+        ops.gemm(A, W, C)
+    with pytest.raises(TypeError):
+        ops.gemm(A.double(), W, C)
+
+
+# ------------------------------------------------------------------------------------------ LN / GRU
+@pytest.mark.parametrize("R,N", [(1024, 512), (16, 512), (1000, 32), (257, 64), (100, 128), (64, 256), (7, 1536),
+                                 (33, 16), (50, 3), (5, 1024), (3, 2048), (4, 700)])
+@pytest.mark.parametrize("act", [True, False])
+def test_ln_act_fwd_bwd(ops, R, N, act):
+    g = torch.Generator().manual_seed(R + N)
+    x = (torch.randn(R, N, generator=g) * 2 + 0.3).requires_grad_(True)
+    gam = (1 + 0.1 * torch.randn(N, generator=g)).requires_grad_(True)
+    bet = (0.1 * torch.randn(N, generator=g)).requires_grad_(True)
+    dy = torch.randn(R, N, generator=g)
+    y_ref = O.layer_norm(x, gam, bet)
+    if act:
+        y_ref = F.silu(y_ref)
+    y_ref.backward(dy)
+    y = torch.empty(R, N).cuda()
+    mean = torch.empty(R).cuda()
+    rstd = torch.empty(R).cuda()
+    xd, gd, bd = dev(x.detach()), dev(gam.detach()), dev(bet.detach())
+    ops.ln_act_fwd(xd, gd, bd, y, mean, rstd, act=act)
+    assert_close(y, y_ref, what="ln fwd")
+    dx = torch.empty(R, N).cuda()
+    dg = torch.zeros(N).cuda()
+    db = torch.zeros(N).cuda()
+    ops.ln_act_bwd(dev(dy), xd, gd, bd, mean, rstd, dx, dg, db, act=act)
+    assert_close(dx, x.grad, what="ln dx")
+    assert_close(dg, gam.grad, tol=2e-4, what="ln dgamma")
+    assert_close(db, bet.grad, tol=2e-4, what="ln dbeta")
+
+
+def test_ln_chw_flatten_matches_reference_order(ops):
+    """Encoder output is flattened (C,H,W) (networks.py:494); our activations are NHWC."""
+    n_img, G, C = 5, 16, 24
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n_img * G, C, generator=g)
+    gam, bet = torch.ones(C), torch.zeros(C)
+    y = torch.empty(n_img, C * G).cuda()
+    ops.ln_act_fwd(dev(x), dev(gam), dev(bet), y, act=True, chw_group=G)
+    ref = F.silu(O.layer_norm(x, gam, bet)).reshape(n_img, G, C).permute(0, 2, 1).reshape(n_img, C * G)
+    assert_close(y, ref, what="chw flatten")
+
+
+@pytest.mark.parametrize("M,De", [(1024, 512), (16, 512), (5, 16), (33, 1024), (3, 40)])
+def test_gru_fwd_bwd(ops, M, De):
+    g = torch.Generator().manual_seed(M + De)
+    p_pre = (torch.randn(M, 3 * De, generator=g)).requires_grad_(True)
+    h = torch.randn(M, De, generator=g).requires_grad_(True)
+    gam = (1 + 0.1 * torch.randn(3 * De, generator=g)).requires_grad_(True)
+    bet = (0.1 * torch.randn(3 * De, generator=g)).requires_grad_(True)
+    dh_new = torch.randn(M, De, generator=g)
+    parts = O.layer_norm(p_pre, gam, bet)
+    r, c, u = parts[:, :De], parts[:, De:2 * De], parts[:, 2 * De:]
+    r = torch.sigmoid(r)
+    c = torch.tanh(r * c)
+    u = torch.sigmoid(u - 1)
+    ref = u * c + (1 - u) * h
+    ref.backward(dh_new)
+    pd, hd, gd, bd = dev(p_pre.detach()), dev(h.detach()), dev(gam.detach()), dev(bet.detach())
+    hn = torch.empty(M, De).cuda()
+    mean, rstd = torch.empty(M).cuda(), torch.empty(M).cuda()
+    ops.gru_fwd(pd, gd, bd, hd, hn, mean, rstd)
+    assert_close(hn, ref, what="gru fwd")
+    dp = torch.empty(M, 3 * De).cuda()
+    dh = torch.empty(M, De).cuda()
+    dg, db = torch.zeros(3 * De).cuda(), torch.zeros(3 * De).cuda()
+    ops.gru_bwd(dev(dh_new), pd, gd, bd, hd, mean, rstd, dp, dh, dg, db)
+    assert_close(dp, p_pre.grad, what="gru dp")
+    assert_close(dh, h.grad, what="gru dh")
+    assert_close(dg, gam.grad, tol=2e-4, what="gru dgamma")
+    assert_close(db, bet.grad, tol=2e-4, what="gru dbeta")
+
+
+# ------------------------------------------------------------------------------------------ categorical
+@pytest.mark.parametrize("R,D", [(32768, 32), (48, 4), (1000, 18), (77, 5), (10, 64)])
+def test_onehot_sample_mode_and_straight_through(ops, R, D):
+    g = torch.Generator().manual_seed(R + D)
+    logit = (2 * torch.randn(R, D, generator=g)).requires_grad_(True)
+    q = torch.empty(R, D).exponential_(generator=g)
+    gs = torch.randn(R, D, generator=g)
+    ref = O.onehot_sample(logit, q, 0.01)
+    ref.backward(gs)
+    out = torch.empty(R, D).cuda()
+    idx = torch.empty(R, dtype=torch.int32).cuda()
+    ld = dev(logit.detach())
+    ops.onehot_sample(ld, out, noise=dev(q), idx=idx, unimix=0.01)
+    flips = (out.cpu() != ref.detach()).any(-1).float().mean().item()
+    assert flips <= 2e-4, f"sample flip rate {flips}"
+    assert torch.equal(out.sum(-1).cpu(), torch.ones(R))
+    assert torch.equal(out.argmax(-1).int(), idx)
+    dl = torch.zeros(R, D).cuda()
+    ops.onehot_st_bwd(ld, dev(gs), dl, unimix=0.01)
+    assert_close(dl, logit.grad, what="st bwd")
+    # mode + its straight-through (through log p)
+    logit2 = logit.detach().clone().requires_grad_(True)
+    refm = O.onehot_mode(logit2, 0.01)
+    refm.backward(gs)
+    ops.onehot_sample(ld, out, unimix=0.01, mode=True)
+    assert torch.equal(out.cpu(), torch.nn.functional.one_hot(logit.argmax(-1), D).float())
+    ops.onehot_st_bwd(ld, dev(gs), dl, unimix=0.01, mode=True)
+    assert_close(dl, logit2.grad, what="mode st bwd")
+
+
+def test_onehot_sample_philox_is_a_categorical_sampler(ops):
+    """In-kernel RNG path: empirical frequencies follow p_hat (chi-square style bound)."""
+    D, R = 8, 1 << 18
+    logit = torch.tensor([0.0, 1.0, -1.0, 2.0, 0.5, -2.0, 0.0, 1.5]).repeat(R, 1).cuda()
+    st = torch.tensor([1234, 0], dtype=torch.int64).cuda()
+    out = torch.empty(R, D).cuda()
+    ops.onehot_sample(logit, out, rng_state=st, unimix=0.01)
+    freq = out.mean(0).cpu()
+    p = F.softmax(logit[0].cpu(), -1) * 0.99 + 0.01 / D
+    assert (freq - p).abs().max().item() < 5e-3
+    out2 = torch.empty(R, D).cuda()
+    ops.rng_advance(st, R * D // 4 + 1)
+    ops.onehot_sample(logit, out2, rng_state=st, unimix=0.01)
+    assert (out != out2).any()
+
+
+@pytest.mark.parametrize("rows,S,D", [(1024, 32, 32), (18, 4, 4), (7, 3, 5)])
+def test_kl_fwd_bwd(ops, rows, S, D):
+    g = torch.Generator().manual_seed(rows)
+    post = (1.5 * torch.randn(rows, S, D, generator=g)).requires_grad_(True)
+    prior = (1.5 * torch.randn(rows, S, D, generator=g)).requires_grad_(True)
+    cfg = O.PathConfig(stoch=S, discrete=D)
+    cfg.kl_free = 1.0 if D == 32 else 0.3  # make the clip bite on some rows only
+    loss, value, dyn, rep = O.kl_loss(cfg, post, prior)
+    up = 1.0 / rows
+    (loss.sum() * up).backward()
+    kl = torch.empty(rows).cuda()
+    ep, eq = torch.empty(rows).cuda(), torch.empty(rows).cuda()
+    pd, qd = dev(post.detach()), dev(prior.detach())
+    ops.kl_fwd(pd, qd, kl, ep, eq, unimix=0.01)
+    assert_close(kl, value, what="kl")
+    assert_close(ep, O.onehot_entropy(post, 0.01), what="post ent")
+    assert_close(eq, O.onehot_entropy(prior, 0.01), what="prior ent")
+    dp, dq = torch.empty_like(pd), torch.empty_like(qd)
+    ops.kl_bwd(pd, qd, kl, dp, dq, unimix=0.01, free=cfg.kl_free, dyn_scale=cfg.dyn_scale, rep_scale=cfg.rep_scale,
+               upstream=up)
+    assert_close(dp, post.grad, tol=1e-5, what="dpost")
+    assert_close(dq, prior.grad, tol=1e-5, what="dprior")
+
+
+def test_onehot_entropy_logprob_fwd_bwd(ops):
+    R, D = 500, 18
+    g = torch.Generator().manual_seed(9)
+    logit = torch.randn(R, D, generator=g).requires_grad_(True)
+    x = F.one_hot(torch.randint(0, D, (R,), generator=g), D).float()
+    de, dl_ = torch.randn(R, generator=g), torch.randn(R, generator=g)
+    cfg = O.PathConfig(actor_dist="onehot")
+    lg = O.unimix_logits(logit, 0.01)
+    pr = F.softmax(lg, -1)
+    ent_ref = -(lg * pr).sum(-1)
+    lp_ref = O.onehot_logprob(logit, x, 0.01)
+    ((ent_ref * de).sum() + (lp_ref * dl_).sum()).backward()
+    ent, lp = torch.empty(R).cuda(), torch.empty(R).cuda()
+    ld = dev(logit.detach())
+    ops.onehot_ent_logp_fwd(ld, dev(x), ent, lp, unimix=0.01)
+    assert_close(ent, ent_ref, what="ent")
+    assert_close(lp, lp_ref, what="logp")
+    dlog = torch.empty(R, D).cuda()
+    ops.onehot_ent_logp_bwd(ld, dev(x), dev(de), dev(dl_), dlog, unimix=0.01)
+    assert_close(dlog, logit.grad, what="dlogit")
+
+
+# ------------------------------------------------------------------------------------------ heads
+def test_disc_head_mode_logprob_fwd_bwd(ops):
+    R = 3000
+    g = torch.Generator().manual_seed(11)
+    logits = (2 * torch.randn(R, 255, generator=g)).requires_grad_(True)
+    x = torch.cat([torch.randn(R - 6, generator=g) * 30,
+                   torch.tensor([0.0, 1e9, -1e9, float(O.symexp(torch.tensor(20.0))), 0.15748, -485165184.0])])
+    up_m, up_l = torch.randn(R, generator=g), torch.randn(R, generator=g)
+    mode_ref = O.disc_mode(logits).squeeze(-1)
+    lp_ref = O.disc_logprob(logits, x)
+    ((mode_ref * up_m).sum() + (lp_ref * up_l).sum()).backward()
+    ld = dev(logits.detach())
+    mode, lp = torch.empty(R).cuda(), torch.empty(R).cuda()
+    ops.disc_mode_fwd(ld, mode)
+    ops.disc_logprob_fwd(ld, dev(x), lp)
+    assert_close(mode, mode_ref, what="disc mode")
+    assert_close(lp, lp_ref, what="disc logprob")
+    dl = torch.zeros(R, 255).cuda()
+    ops.disc_mode_bwd(ld, dev(up_m), dl)
+    ops.disc_logprob_bwd(ld, dev(x), dev(up_l), dl, accumulate=True)
+    assert_close(dl, logits.grad, what="disc dlogits")
+
+
+def test_bernoulli_mse_symlog(ops):
+    g = torch.Generator().manual_seed(12)
+    n = 1000
+    l = (3 * torch.randn(n, 1, generator=g)).requires_grad_(True)
+    x = (torch.rand(n, 1, generator=g) > 0.5).float()
+    up = torch.randn(n, generator=g)
+    ref = O.bernoulli_logprob(l, x)
+    (ref * up).sum().backward()
+    out = torch.empty(n).cuda()
+    ld = dev(l.detach().reshape(n))
+    ops.bernoulli_logprob_fwd(ld, dev(x.reshape(n)), out)
+    assert_close(out, ref, what="bern")
+    dl = torch.empty(n).cuda()
+    ops.bernoulli_logprob_bwd(ld, dev(x.reshape(n)), dev(up), dl)
+    assert_close(dl, l.grad.reshape(n), what="bern bwd")
+    # image mse with fused u8 decode
+    img = torch.randint(0, 256, (6, 64, 64, 3), generator=g, dtype=torch.uint8)
+    recon = torch.rand(6, 64, 64, 3, generator=g).requires_grad_(True)
+    loss_ref = ((recon - img.float() / 255.0) ** 2).sum([1, 2, 3])
+    (loss_ref.sum() * 0.25).backward()
+    loss = torch.empty(6).cuda()
+    dr = torch.empty(6, 64, 64, 3).cuda()
+    ops.mse_image(dev(recon.detach()), dev(img), loss, dr, upstream=0.25)
+    assert_close(loss, loss_ref, what="mse")
+    assert_close(dr, recon.grad, what="mse grad")
+    f = torch.empty(6, 64, 64, 3).cuda()
+    ops.image_to_f32(dev(img), f)
+    assert torch.equal(f.cpu(), img.float() / 255.0 - 0.5)
+    # symlog mse
+    mode = torch.randn(40, 9, generator=g).requires_grad_(True)
+    xv = torch.randn(40, 9, generator=g) * 5
+    with torch.no_grad():
+        mode[0, 0] = O.symlog(xv[0, 0])  # exercises the < 1e-8 zeroing
+    ref = -O.symlog_mse_logprob(mode[None], xv[None])[0]
+    (ref.sum() * 0.5).backward()
+    sl = torch.empty(40).cuda()
+    dm = torch.empty(40, 9).cuda()
+    ops.symlog_mse(dev(mode.detach()), dev(xv), sl, dm, upstream=0.5)
+    assert_close(sl, ref, what="symlog mse")
+    assert_close(dm, mode.grad, what="symlog mse grad")
+    y = torch.empty(40, 9).cuda()
+    ops.symlog(dev(xv), y)
+    assert_close(y, O.symlog(xv), what="symlog")
+
+
+def test_actor_normal_fwd_bwd(ops):
+    M, A = 700, 6
+    g = torch.Generator().manual_seed(13)
+    mr = torch.randn(M, A, generator=g).requires_grad_(True)
+    sr = torch.randn(M, A, generator=g).requires_grad_(True)
+    eps = torch.randn(M, A, generator=g) * 1.5
+    mean, std = torch.tanh(mr), 0.9 * torch.sigmoid(sr + 2.0) + 0.1
+    pre = mean + std * eps
+    act_ref = pre * (1.0 / torch.clip(pre.abs(), min=1.0)).detach()
+    ent_ref = (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(std)).sum(-1)
+    fixed = act_ref.detach() + 0.1
+    lp_ref = (-((fixed - mean) ** 2) / (2 * std ** 2) - torch.log(std) - math.log(math.sqrt(2 * math.pi))).sum(-1)
+    da, de, dl = torch.randn(M, A, generator=g), torch.randn(M, generator=g), torch.randn(M, generator=g)
+    ((act_ref * da).sum() + (ent_ref * de).sum() + (lp_ref * dl).sum()).backward()
+    mrd, srd = dev(mr.detach()), dev(sr.detach())
+    action, ent, lp = torch.empty(M, A).cuda(), torch.empty(M).cuda(), torch.empty(M).cuda()
+    ops.actor_normal_fwd(mrd, srd, dev(eps), action, ent)
+    ops.actor_normal_logp(mrd, srd, dev(fixed), lp)
+    assert_close(action, act_ref, what="action")
+    assert_close(ent, ent_ref, what="entropy")
+    assert_close(lp, lp_ref, what="logp")
+    dm, ds = torch.empty(M, A).cuda(), torch.empty(M, A).cuda()
+    ops.actor_normal_bwd(mrd, srd, dm, ds, eps=dev(eps), action=dev(fixed), daction=dev(da), dent=dev(de), dlogp=dev(dl))
+    assert_close(dm, mr.grad, what="dmean_raw")
+    assert_close(ds, sr.grad, what="dstd_raw")
+
+
+def test_lambda_return_fwd_bwd(ops):
+    H, N = 15, 1024
+    g = torch.Generator().manual_seed(14)
+    reward = torch.randn(H, N, 1, generator=g).requires_grad_(True)
+    value = torch.randn(H, N, 1, generator=g)
+    cl = (2 * torch.randn(H, N, 1, generator=g)).requires_grad_(True)
+    disc = 0.997 * torch.sigmoid(cl)
+    tgt_ref = O.lambda_return(reward, value, disc, 0.95)
+    w_ref = torch.cumprod(torch.cat([torch.ones_like(disc[:1]), disc[:-1]], 0), 0)
+    dt = torch.randn(H - 1, N, 1, generator=g)
+    (tgt_ref * dt).sum().backward()
+    target, weights, d_out = torch.empty(H - 1, N).cuda(), torch.empty(H, N).cuda(), torch.empty(H, N).cuda()
+    rd, vd, cd = dev(reward.detach().squeeze(-1)), dev(value.squeeze(-1)), dev(cl.detach().squeeze(-1))
+    ops.lambda_return_fwd(rd, vd, cd, target, weights, d_out, gamma=0.997, lam=0.95)
+    assert_close(target, tgt_ref.squeeze(-1), what="target")
+    assert_close(weights, w_ref.squeeze(-1), what="weights")
+    assert_close(d_out, disc.squeeze(-1), what="disc")
+    dr, dc = torch.empty(H, N).cuda(), torch.empty(H, N).cuda()
+    ops.lambda_return_bwd(dev(dt.squeeze(-1)), vd, cd, target, dr, dc, gamma=0.997, lam=0.95)
+    assert_close(dr, reward.grad.squeeze(-1), what="dreward")
+    assert_close(dc, cl.grad.squeeze(-1), what="dcont")
+
+
+def test_reset_blend_fwd_bwd(ops):
+    B, n = 16, 1030
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(B, n, generator=g).requires_grad_(True)
+    init = torch.randn(n, generator=g).requires_grad_(True)
+    first = (torch.rand(B, generator=g) > 0.6).float()
+    ref = x * (1 - first[:, None]) + init[None] * first[:, None]
+    go = torch.randn(B, n, generator=g)
+    ref.backward(go)
+    out = torch.empty(B, n).cuda()
+    ops.reset_blend(dev(x.detach()), dev(init.detach()), dev(first), out)
+    assert_close(out, ref, what="blend")
+    dx, di = torch.empty(B, n).cuda(), torch.zeros(n).cuda()
+    ops.reset_blend_bwd(dev(go), dev(first), dx, di)
+    assert_close(dx, x.grad, what="dx")
+    assert_close(di, init.grad, what="dinit")
+
+
+def test_adam_clip_matches_oracle(ops):
+    n = 100003
+    g = torch.Generator().manual_seed(16)
+    p0 = torch.randn(n, generator=g)
+    st = dict(step=0, m=[torch.zeros(n)], v=[torch.zeros(n)])
+    p_ref = p0.clone()
+    pd = dev(p0.clone())
+    m, v = torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    state = torch.zeros(4).cuda()
+    for it in range(3):
+        grad = torch.randn(n, generator=g) * (50.0 if it == 1 else 0.01)
+        norm_ref = O.clip_and_adam([p_ref], [grad.clone()], st, lr=1e-2, eps=1e-8, clip=100.0)
+        gd = dev(grad)
+        ops.sumsq_accumulate(gd, state[1:2])
+        ops.adam_step(pd, gd, m, v, state, lr=1e-2, eps=1e-8, clip=100.0)
+        assert abs(state[2].item() - norm_ref.item()) <= 1e-4 * norm_ref.item()
+        assert_close(pd, p_ref, tol=1e-5, what=f"adam it {it}")
+    assert state[0].item() == 3.0 and state[1].item() == 0.0
