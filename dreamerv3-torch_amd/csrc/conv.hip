@@ -1,0 +1,506 @@
+// 64x64 CNN encoder / decoder as implicit GEMMs on the fp32 MFMA tile engine (mfma_gemm.h).
+//
+// Activations are NHWC (channel-last) end to end: the replay image arrives [B,T,64,64,3], the
+// channel LayerNorm reduces over the contiguous dim, the decoder's Linear output is already
+// (h,w,c) (networks.py:571-573) and its mean is returned NHWC (networks.py:580).  Only the
+// encoder's final flatten is (C,H,W) (networks.py:494); dv3_ln_act_fwd(chw_group=16) does that.
+//
+// Three compute kernels cover forward and backward of both stacks:
+//   conv_s2    : Conv2d k4 s2 "same" pad (networks.py:771-798)        = encoder fwd = decoder dgrad
+//   convT_s2   : ConvTranspose2d k4 s2 p1 (networks.py:540-550)       = decoder fwd = encoder dgrad
+//   conv_wgrad : weight gradient of either (split-K, fp32 atomics straight into the reference
+//                [out|in][in|out][4][4] layout)
+// A Conv2d weight [Co][Ci][4][4] read as a ConvTranspose2d weight [in=Co][out=Ci][4][4] is its
+// adjoint, so the same packed images serve forward and backward.
+#include "mfma_gemm.h"
+#include "dv3_common.h"
+
+namespace dv3 {
+
+// ------------------------------------------------------------------------------------------------
+// A loader for conv_s2: row m = (n, oy, ox) of the output grid, k = (ky, kx, ci).
+// ------------------------------------------------------------------------------------------------
+struct ConvA {
+  const float* x;  // [Nimg][H][W][C]
+  int H, W, C, OH, OW;
+  long M;  // Nimg*OH*OW
+  int K;   // 16*C
+};
+
+template <int ROWS, int BK>
+struct ConvATile {
+  static constexpr int kVecs = ROWS * BK / 4 / kThreads;
+  static constexpr int CH = BK / 4, RPP = kThreads / CH;
+  static constexpr int LD = ROWS + (BK == 16 ? 2 : 1);
+  f32x4 v[kVecs];
+  long base[kVecs];  // n*H*W*C, or -1 when the row is out of range
+  int iy0[kVecs], ix0[kVecs];
+
+  __device__ __forceinline__ void init(const ConvA& op, int r0, int tid) {
+    const int rr = tid / CH;
+#pragma unroll
+    for (int p = 0; p < kVecs; ++p) {
+      const long r = (long)r0 + p * RPP + rr;
+      if (r < op.M) {
+        const int ox = (int)(r % op.OW);
+        const long t = r / op.OW;
+        const int oy = (int)(t % op.OH);
+        const long n = t / op.OH;
+        base[p] = n * op.H * op.W * op.C;
+        iy0[p] = 2 * oy - 1;
+        ix0[p] = 2 * ox - 1;
+      } else {
+        base[p] = -1;
+        iy0[p] = ix0[p] = 0;
+      }
+    }
+  }
+  __device__ __forceinline__ float at(const ConvA& op, int p, int k) const {
+    if (base[p] < 0 || k >= op.K) return 0.f;
+    const int c4 = 4 * op.C;
+    const int ky = k / c4, j = k - ky * c4;
+    const int kx = j / op.C, ci = j - kx * op.C;
+    const int iy = iy0[p] + ky, ix = ix0[p] + kx;
+    if (iy < 0 || iy >= op.H || ix < 0 || ix >= op.W) return 0.f;
+    return op.x[base[p] + ((long)iy * op.W + ix) * op.C + ci];
+  }
+  __device__ __forceinline__ void load(const ConvA& op, int, int k0, int tid) {
+    const int c = tid % CH;
+    const int k = k0 + 4 * c;
+    if ((op.C & 3) == 0) {
+      // 4 consecutive k share (ky,kx): one 16-byte gather or zeros
+      const int c4 = 4 * op.C;
+      const int ky = k / c4, j = k - ky * c4;
+      const int kx = j / op.C, ci = j - kx * op.C;
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        const int iy = iy0[p] + ky, ix = ix0[p] + kx;
+        const bool ok = base[p] >= 0 && k < op.K && iy >= 0 && iy < op.H && ix >= 0 && ix < op.W;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (ok) t = *reinterpret_cast<const f32x4u*>(op.x + base[p] + ((long)iy * op.W + ix) * op.C + ci);
+        v[p] = t;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = at(op, p, k + e);
+        v[p] = t;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* s, int tid) const {
+    const int c = tid % CH, rr = tid / CH;
+#pragma unroll
+    for (int p = 0; p < kVecs; ++p) {
+      const int r = p * RPP + rr;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[(4 * c + e) * LD + r] = v[p][e];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// A loader for convT_s2, one output-parity class (py,px) per launch slice: row m = (n, y2, x2) of
+// the INPUT grid, k = (a, b, ci), tap input pixel (y2 + py - a, x2 + px - b), kernel tap
+// (ky, kx) = (1 - py + 2a, 1 - px + 2b).
+// ------------------------------------------------------------------------------------------------
+struct ConvTA {
+  const float* x;  // [Nimg][IH][IW][C]
+  int IH, IW, C, py, px;
+  long M;  // Nimg*IH*IW
+  int K;   // 4*C
+};
+
+template <int ROWS, int BK>
+struct ConvTATile {
+  static constexpr int kVecs = ROWS * BK / 4 / kThreads;
+  static constexpr int CH = BK / 4, RPP = kThreads / CH;
+  static constexpr int LD = ROWS + (BK == 16 ? 2 : 1);
+  f32x4 v[kVecs];
+  long base[kVecs];
+  int y0[kVecs], x0[kVecs];
+
+  __device__ __forceinline__ void init(const ConvTA& op, int r0, int tid) {
+    const int rr = tid / CH;
+#pragma unroll
+    for (int p = 0; p < kVecs; ++p) {
+      const long r = (long)r0 + p * RPP + rr;
+      if (r < op.M) {
+        const int x2 = (int)(r % op.IW);
+        const long t = r / op.IW;
+        const int y2 = (int)(t % op.IH);
+        const long n = t / op.IH;
+        base[p] = n * op.IH * op.IW * op.C;
+        y0[p] = y2 + op.py;
+        x0[p] = x2 + op.px;
+      } else {
+        base[p] = -1;
+        y0[p] = x0[p] = 0;
+      }
+    }
+  }
+  __device__ __forceinline__ float at(const ConvTA& op, int p, int k) const {
+    if (base[p] < 0 || k >= op.K) return 0.f;
+    const int c2 = 2 * op.C;
+    const int a = k / c2, j = k - a * c2;
+    const int b = j / op.C, ci = j - b * op.C;
+    const int iy = y0[p] - a, ix = x0[p] - b;
+    if (iy < 0 || iy >= op.IH || ix < 0 || ix >= op.IW) return 0.f;
+    return op.x[base[p] + ((long)iy * op.IW + ix) * op.C + ci];
+  }
+  __device__ __forceinline__ void load(const ConvTA& op, int, int k0, int tid) {
+    const int c = tid % CH;
+    const int k = k0 + 4 * c;
+    if ((op.C & 3) == 0) {
+      const int c2 = 2 * op.C;
+      const int a = k / c2, j = k - a * c2;
+      const int b = j / op.C, ci = j - b * op.C;
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        const int iy = y0[p] - a, ix = x0[p] - b;
+        const bool ok = base[p] >= 0 && k < op.K && iy >= 0 && iy < op.IH && ix >= 0 && ix < op.IW;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (ok) t = *reinterpret_cast<const f32x4u*>(op.x + base[p] + ((long)iy * op.IW + ix) * op.C + ci);
+        v[p] = t;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = at(op, p, k + e);
+        v[p] = t;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* s, int tid) const {
+    const int c = tid % CH, rr = tid / CH;
+#pragma unroll
+    for (int p = 0; p < kVecs; ++p) {
+      const int r = p * RPP + rr;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[(4 * c + e) * LD + r] = v[p][e];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// B loader for conv_wgrad: reduction index k = output-grid row m = (n, oy, ox); tile column
+// j = (ky, kx, ci) gathers x[n, 2oy+ky-1, 2ox+kx-1, ci].  LDS image Bs[k][j], written 16 B at a time.
+// ------------------------------------------------------------------------------------------------
+struct WgradB {
+  const float* x;  // [Nimg][H][W][C]  (the stride-2-sampled, "fine" tensor)
+  int H, W, C, OH, OW;
+  long Mrows;  // Nimg*OH*OW  (the reduction length)
+  int Ncols;   // 16*C
+};
+
+template <int ROWS, int BK>
+struct WgradBTile {
+  static constexpr int kVecs = ROWS * BK / 4 / kThreads;
+  static constexpr int CH = ROWS / 4, KPP = kThreads / CH;
+  static constexpr int LD = ROWS + 4;
+  static_assert(kThreads % CH == 0 && BK % KPP == 0, "bad tile");
+  f32x4 v[kVecs];
+  int jcol;
+
+  __device__ __forceinline__ void init(const WgradB&, int n0, int tid) { jcol = n0 + 4 * (tid % CH); }
+  __device__ __forceinline__ float at(const WgradB& op, long m, int j) const {
+    if (m >= op.Mrows || j >= op.Ncols) return 0.f;
+    const int c4 = 4 * op.C;
+    const int ky = j / c4, jj = j - ky * c4;
+    const int kx = jj / op.C, ci = jj - kx * op.C;
+    const int ox = (int)(m % op.OW);
+    const long t = m / op.OW;
+    const int oy = (int)(t % op.OH);
+    const long n = t / op.OH;
+    const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+    if (iy < 0 || iy >= op.H || ix < 0 || ix >= op.W) return 0.f;
+    return op.x[((n * op.H + iy) * op.W + ix) * op.C + ci];
+  }
+  __device__ __forceinline__ void load(const WgradB& op, int, int k0, int tid) {
+    const int kr = tid / CH;
+    if ((op.C & 3) == 0) {
+      const int c4 = 4 * op.C;
+      const int ky = jcol / c4, jj = jcol - ky * c4;
+      const int kx = jj / op.C, ci = jj - kx * op.C;
+      const bool colok = jcol < op.Ncols;
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        const long m = (long)k0 + p * KPP + kr;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (colok && m < op.Mrows) {
+          const int ox = (int)(m % op.OW);
+          const long q = m / op.OW;
+          const int oy = (int)(q % op.OH);
+          const long n = q / op.OH;
+          const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+          if (iy >= 0 && iy < op.H && ix >= 0 && ix < op.W)
+            t = *reinterpret_cast<const f32x4u*>(op.x + ((n * op.H + iy) * op.W + ix) * op.C + ci);
+        }
+        v[p] = t;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        const long m = (long)k0 + p * KPP + kr;
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = at(op, m, jcol + e);
+        v[p] = t;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* s, int tid) const {
+    const int c = tid % CH, kr = tid / CH;
+#pragma unroll
+    for (int p = 0; p < kVecs; ++p) *reinterpret_cast<f32x4*>(&s[(p * KPP + kr) * LD + 4 * c]) = v[p];
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+struct ConvParams {
+  const float* x;
+  const float* wp;  // packed weights
+  float* y;
+  const float* bias;
+  float out_add;
+  int Nimg, H, W, Ci, Co;  // H, W: spatial size of the FINE tensor for conv (input), COARSE for convT (input)
+  int tiles_m, tiles_n;
+  int accumulate;
+};
+
+// y[n,oy,ox,co] = sum x[n,2oy+ky-1,2ox+kx-1,ci] * wp[co][(ky,kx,ci)]
+template <class TS>
+__global__ __launch_bounds__(kThreads) void conv_s2_kernel(ConvParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[TS::lds_floats];
+  using ATile = ConvATile<TS::BM, TS::BK>;
+  using BTile = DenseTile<TS::BN, TS::BK, true>;
+  const int OH = p.H / 2, OW = p.W / 2;
+  ConvA aop{p.x, p.H, p.W, p.Ci, OH, OW, (long)p.Nimg * OH * OW, 16 * p.Ci};
+  DenseOperand<true> bop{p.wp, nullptr, 16L * p.Ci, 0, p.Co, 16 * p.Ci, 16 * p.Ci, true};
+  const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int m0 = (wg / p.tiles_n) * TS::BM, n0 = (wg % p.tiles_n) * TS::BN;
+  f32x16 acc[TS::TM][TS::TN];
+  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, 0, aop.K, lds, acc);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / TS::WN, wn = wave % TS::WN, col_l = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < TS::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TS::TN; ++b) {
+      const int n = n0 + (wn * TS::TN + b) * 32 + col_l;
+      if (n >= p.Co) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = (long)m0 + (wm * TS::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < aop.M) {
+          float* o = p.y + m * p.Co + n;
+          *o = p.accumulate ? (*o + acc[a][b][r]) : acc[a][b][r];
+        }
+      }
+    }
+}
+
+// y[n,2y2+py,2x2+px,co] = sum_{a,b,ci} x[n,y2+py-a,x2+px-b,ci] * wp[cls][co][(a,b,ci)] + bias[co] + out_add
+template <class TS>
+__global__ __launch_bounds__(kThreads) void convT_s2_kernel(ConvParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[TS::lds_floats];
+  using ATile = ConvTATile<TS::BM, TS::BK>;
+  using BTile = DenseTile<TS::BN, TS::BK, true>;
+  const int cls = blockIdx.y, py = cls >> 1, px = cls & 1;
+  ConvTA aop{p.x, p.H, p.W, p.Ci, py, px, (long)p.Nimg * p.H * p.W, 4 * p.Ci};
+  DenseOperand<true> bop{p.wp + (long)cls * p.Co * 4 * p.Ci, nullptr, 4L * p.Ci, 0, p.Co, 4 * p.Ci, 4 * p.Ci, true};
+  const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int m0 = (wg / p.tiles_n) * TS::BM, n0 = (wg % p.tiles_n) * TS::BN;
+  f32x16 acc[TS::TM][TS::TN];
+  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, 0, aop.K, lds, acc);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / TS::WN, wn = wave % TS::WN, col_l = lane & 31, h = lane >> 5;
+  const int OH = 2 * p.H, OW = 2 * p.W;
+#pragma unroll
+  for (int a = 0; a < TS::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TS::TN; ++b) {
+      const int n = n0 + (wn * TS::TN + b) * 32 + col_l;
+      if (n >= p.Co) continue;
+      const float add = (p.bias ? p.bias[n] : 0.f) + p.out_add;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = (long)m0 + (wm * TS::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < aop.M) {
+          const int x2 = (int)(m % p.W);
+          const long t = m / p.W;
+          const int y2 = (int)(t % p.H);
+          const long img = t / p.H;
+          float* o = p.y + ((img * OH + 2 * y2 + py) * OW + 2 * x2 + px) * p.Co + n;
+          const float val = acc[a][b][r] + add;
+          *o = p.accumulate ? (*o + val) : val;
+        }
+      }
+    }
+}
+
+struct WgradParams {
+  const float* dy;  // [rows][Co]   coarse-grid tensor (conv: dY; convT: the layer input)
+  const float* x;   // [Nimg][H][W][Ci]  fine-grid tensor (conv: the layer input; convT: dOut)
+  float* dw;        // [Co][Ci][4][4] accumulated with atomics
+  int Nimg, H, W, Ci, Co;
+  int tiles_m, tiles_n, splits, chunk;  // chunk: reduction rows per split (multiple of BK)
+};
+
+// dw[co][ci][ky][kx] += sum_m dy[m][co] * x[n,2oy+ky-1,2ox+kx-1,ci]
+template <class TS>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[TS::lds_floats];
+  using ATile = DenseTile<TS::BM, TS::BK, false>;  // A[k=m][row=co], co-contiguous
+  using BTile = WgradBTile<TS::BN, TS::BK>;
+  const int OH = p.H / 2, OW = p.W / 2;
+  const long rows = (long)p.Nimg * OH * OW;
+  DenseOperand<false> aop{p.dy, nullptr, (long)p.Co, 0, p.Co, (int)rows, (int)rows, true};
+  WgradB bop{p.x, p.H, p.W, p.Ci, OH, OW, rows, 16 * p.Ci};
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+  const int m0 = (tile / p.tiles_n) * TS::BM, n0 = (tile % p.tiles_n) * TS::BN;
+  const long kb = (long)split * p.chunk;
+  long ke = kb + p.chunk;
+  if (ke > rows) ke = rows;
+  f32x16 acc[TS::TM][TS::TN];
+  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, (int)kb, (int)ke, lds, acc);
+  if (kb >= ke) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / TS::WN, wn = wave % TS::WN, col_l = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < TS::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TS::TN; ++b) {
+      const int j = n0 + (wn * TS::TN + b) * 32 + col_l;
+      if (j >= 16 * p.Ci) continue;
+      const int c4 = 4 * p.Ci;
+      const int ky = j / c4, jj = j - ky * c4;
+      const int kx = jj / p.Ci, ci = jj - kx * p.Ci;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + (wm * TS::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < p.Co) atomicAdd(p.dw + (((long)co * p.Ci + ci) * 4 + ky) * 4 + kx, acc[a][b][r]);
+      }
+    }
+}
+
+// Conv2d weight [Co][Ci][4][4] -> [Co][(ky,kx,ci)]
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci) {
+  const long total = (long)Co * Ci * 16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci);
+    long t = i / Ci;
+    const int kx = (int)(t % 4);
+    t /= 4;
+    const int ky = (int)(t % 4);
+    const long co = t / 4;
+    wp[i] = w[((co * Ci + ci) * 4 + ky) * 4 + kx];
+  }
+}
+// ConvTranspose2d weight [Ci][Co][4][4] -> [cls=(py,px)][Co][(a,b,ci)], (ky,kx) = (1-py+2a, 1-px+2b)
+__global__ void pack_convT_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Ci, int Co) {
+  const long total = 4L * Co * 4 * Ci;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci);
+    long t = i / Ci;
+    const int b = (int)(t % 2);
+    t /= 2;
+    const int a = (int)(t % 2);
+    t /= 2;
+    const int co = (int)(t % Co);
+    const int cls = (int)(t / Co);
+    const int py = cls >> 1, px = cls & 1;
+    const int ky = 1 - py + 2 * a, kx = 1 - px + 2 * b;
+    wp[i] = w[(((long)ci * Co + co) * 4 + ky) * 4 + kx];
+  }
+}
+
+using C128 = TileShape<2, 2, 2, 2, 16>;    // 128 x 128
+using C64 = TileShape<2, 2, 1, 1, 32>;     // 64 x 64
+using C128x32 = TileShape<4, 1, 1, 1, 32>;  // 128 x 32 (narrow channel counts)
+
+}  // namespace dv3
+
+using namespace dv3;
+
+static bool pow2_spatial(int H, int W) { return H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0; }
+
+extern "C" int dv3_pack_conv_weight(const float* w, float* wp, int Co, int Ci, int transposed, void* stream) {
+  if (!w || !wp || Co <= 0 || Ci <= 0) return DV3_ERR_ARG;
+  const long total = 16L * Co * Ci;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (transposed) hipLaunchKernelGGL(pack_convT_w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Ci, Co);
+  else hipLaunchKernelGGL(pack_conv_w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Ci);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_conv_s2_fwd(const float* x, const float* w_packed, float* y, int Nimg, int H, int W, int Ci, int Co,
+                               int accumulate, void* stream) {
+  if (Nimg <= 0) return 0;
+  if (!x || !w_packed || !y || Ci <= 0 || Co <= 0 || !pow2_spatial(H, W)) return DV3_ERR_ARG;
+  ConvParams p{x, w_packed, y, nullptr, 0.f, Nimg, H, W, Ci, Co, 0, 0, accumulate};
+  const long M = (long)Nimg * (H / 2) * (W / 2);
+  if (M > 0x7fffffffL - 256) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  auto go = [&](auto ts) {
+    using TS = decltype(ts);
+    p.tiles_m = (int)((M + TS::BM - 1) / TS::BM);
+    p.tiles_n = (Co + TS::BN - 1) / TS::BN;
+    hipLaunchKernelGGL((conv_s2_kernel<TS>), dim3(p.tiles_m * p.tiles_n), dim3(kThreads), 0, s, p);
+  };
+  if (Co <= 32) go(C128x32{});
+  else if (Co <= 64) go(C64{});
+  else go(C128{});
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_convT_s2_fwd(const float* x, const float* w_packed, const float* bias, float out_add, float* y,
+                                int Nimg, int IH, int IW, int Ci, int Co, int accumulate, void* stream) {
+  if (Nimg <= 0) return 0;
+  if (!x || !w_packed || !y || Ci <= 0 || Co <= 0 || IH <= 0 || IW <= 0) return DV3_ERR_ARG;
+  ConvParams p{x, w_packed, y, bias, out_add, Nimg, IH, IW, Ci, Co, 0, 0, accumulate};
+  const long M = (long)Nimg * IH * IW;
+  if (M > 0x7fffffffL - 256) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  auto go = [&](auto ts) {
+    using TS = decltype(ts);
+    p.tiles_m = (int)((M + TS::BM - 1) / TS::BM);
+    p.tiles_n = (Co + TS::BN - 1) / TS::BN;
+    hipLaunchKernelGGL((convT_s2_kernel<TS>), dim3(p.tiles_m * p.tiles_n, 4), dim3(kThreads), 0, s, p);
+  };
+  if (Co <= 32) go(C128x32{});
+  else if (Co <= 64) go(C64{});
+  else go(C128{});
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* dw, int Nimg, int H, int W, int Cfine,
+                                 int Ccoarse, void* stream) {
+  if (Nimg <= 0) return 0;
+  if (!coarse || !fine || !dw || Cfine <= 0 || Ccoarse <= 0 || !pow2_spatial(H, W)) return DV3_ERR_ARG;
+  const long rows = (long)Nimg * (H / 2) * (W / 2);
+  if (rows > 0x7fffffffL - 4096) return DV3_ERR_ARG;
+  WgradParams p{coarse, fine, dw, Nimg, H, W, Cfine, Ccoarse, 0, 0, 0, 0};
+  using TS = C64;
+  p.tiles_m = (Ccoarse + TS::BM - 1) / TS::BM;
+  p.tiles_n = (16 * Cfine + TS::BN - 1) / TS::BN;
+  const int tiles = p.tiles_m * p.tiles_n;
+  // aim at ~1024 workgroups, at least 512 reduction rows each
+  long splits = (1024 + tiles - 1) / tiles;
+  const long max_splits = (rows + 511) / 512;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  long chunk = (rows + splits - 1) / splits;
+  chunk = ((chunk + TS::BK - 1) / TS::BK) * TS::BK;
+  splits = (rows + chunk - 1) / chunk;
+  p.splits = (int)splits;
+  p.chunk = (int)chunk;
+  hipLaunchKernelGGL((conv_wgrad_kernel<TS>), dim3((unsigned)(tiles * splits)), dim3(kThreads), 0, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}

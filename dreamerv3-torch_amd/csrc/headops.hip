@@ -192,12 +192,19 @@ __global__ void bernoulli_logprob_bwd_kernel(const float* __restrict__ l, const 
 
 // Image reconstruction loss on raw u8 pixels: target = u8/255 (models.py:180), loss[img] = sum (recon-t)^2
 // (tools.py:531-540), drecon = 2*up*(recon-t) written in the same pass when drecon != null.
+// recon image index n' = t*B + b reads replay image b*T + t when permB > 0 (time-major activations)
+__device__ __forceinline__ long src_image(long n, int permB, int permT) {
+  if (permB <= 0) return n;
+  const long t = n / permB, b = n - t * permB;
+  return b * permT + t;
+}
 __global__ __launch_bounds__(256) void mse_image_kernel(const float* __restrict__ recon,
-                                                        const unsigned char* __restrict__ image,
+                                                        const unsigned char* __restrict__ image0,
                                                         float* __restrict__ loss, float* __restrict__ drecon, int P,
-                                                        float up) {
+                                                        float up, int permB, int permT) {
   __shared__ float red[4];
   const long base = (long)blockIdx.x * P;
+  const unsigned char* image = image0 + (src_image(blockIdx.x, permB, permT) - (long)blockIdx.x) * P;
   float a = 0.f;
   for (int i = threadIdx.x * 4; i < P; i += 256 * 4) {
     if (i + 3 < P) {
@@ -223,16 +230,62 @@ __global__ __launch_bounds__(256) void mse_image_kernel(const float* __restrict_
 }
 
 // u8 image -> f32 (u8/255 - 0.5), the encoder's input (models.py:180 + networks.py:487)
-__global__ void image_to_f32_kernel(const unsigned char* __restrict__ img, float* __restrict__ out, long n) {
-  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
-    if (i + 3 < n) {
-      const uchar4 u = *reinterpret_cast<const uchar4*>(img + i);
-      float4 o = {(float)u.x / 255.f - 0.5f, (float)u.y / 255.f - 0.5f, (float)u.z / 255.f - 0.5f,
-                  (float)u.w / 255.f - 0.5f};
-      *reinterpret_cast<float4*>(out + i) = o;
-    } else {
-      for (long e = i; e < n; ++e) out[e] = (float)img[e] / 255.f - 0.5f;
-    }
+__global__ void image_to_f32_kernel(const unsigned char* __restrict__ img, float* __restrict__ out, long n_images,
+                                    int P, int permB, int permT) {
+  const long per = P / 4;  // P % 4 == 0 (checked on the host)
+  const long total = n_images * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long n = i / per, j = (i - n * per) * 4;
+    const uchar4 u = *reinterpret_cast<const uchar4*>(img + src_image(n, permB, permT) * P + j);
+    float4 o = {(float)u.x / 255.f - 0.5f, (float)u.y / 255.f - 0.5f, (float)u.z / 255.f - 0.5f,
+                (float)u.w / 255.f - 0.5f};
+    *reinterpret_cast<float4*>(out + n * P + j) = o;
+  }
+}
+
+// [B][T][k] -> [T][B][k] (action / reward / is_first / proprio keys into time-major)
+__global__ void transpose01_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int T, int k) {
+  const long total = (long)B * T * k;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % k);
+    const long r = i / k;
+    const int b = (int)(r % B);
+    const int t = (int)(r / B);
+    y[i] = x[((long)b * T + t) * k + j];
+  }
+}
+
+// out[n] (+)= sum_r x[r][n]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out,
+                                                     long R, int N, int accumulate) {
+  // block handles 64 columns x a slab of rows; 4 waves split the slab, lanes own columns
+  __shared__ float red[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + lane;
+  const long rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const long rb = (long)blockIdx.y * rows_per;
+  long re = rb + rows_per;
+  if (re > R) re = R;
+  float a = 0.f;
+  if (c < N)
+    for (long r = rb + wave; r < re; r += 4) a += x[r * ldx + c];
+  red[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && c < N) {
+    const float s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (gridDim.y == 1 && !accumulate) out[c] = s;
+    else atomicAdd(out + c, s);
+  }
+}
+
+__global__ void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = tanhf(x[i]);
+}
+__global__ void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
+                                long n, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float g = dy[i] * (1.f - y[i] * y[i]);
+    dx[i] = accumulate ? dx[i] + g : g;
   }
 }
 
@@ -457,18 +510,53 @@ extern "C" int dv3_bernoulli_logprob_bwd(const float* logit, const float* x, con
                      accumulate);
   return (int)hipGetLastError();
 }
+static bool perm_ok(long n_images, int permB, int permT) {
+  return (permB <= 0 && permT <= 0) || (permB > 0 && permT > 0 && (long)permB * permT == n_images);
+}
 extern "C" int dv3_mse_image(const float* recon, const unsigned char* image_u8, float* loss, float* drecon,
-                             long n_images, int pixels, float upstream, void* stream) {
+                             long n_images, int pixels, float upstream, int perm_B, int perm_T, void* stream) {
   if (n_images <= 0) return 0;
-  if (!recon || !image_u8 || !loss || pixels <= 0 || (pixels % 4) != 0) return DV3_ERR_ARG;
+  if (!recon || !image_u8 || !loss || pixels <= 0 || (pixels % 4) != 0 || !perm_ok(n_images, perm_B, perm_T))
+    return DV3_ERR_ARG;
   hipLaunchKernelGGL(mse_image_kernel, dim3((unsigned)n_images), dim3(256), 0, S_, recon, image_u8, loss, drecon, pixels,
-                     upstream);
+                     upstream, perm_B, perm_T);
   return (int)hipGetLastError();
 }
-extern "C" int dv3_image_to_f32(const unsigned char* image_u8, float* out, long n, void* stream) {
+extern "C" int dv3_image_to_f32(const unsigned char* image_u8, float* out, long n_images, int pixels, int perm_B,
+                                int perm_T, void* stream) {
+  if (n_images <= 0) return 0;
+  if (!image_u8 || !out || pixels <= 0 || (pixels % 4) != 0 || !perm_ok(n_images, perm_B, perm_T)) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(image_to_f32_kernel, dim3(nblk(n_images * (pixels / 4), 256, 8192)), dim3(256), 0, S_, image_u8, out,
+                     n_images, pixels, perm_B, perm_T);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_transpose01(const float* x, float* y, int B, int T, int k, void* stream) {
+  if (B <= 0 || T <= 0 || k <= 0) return 0;
+  if (!x || !y) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(transpose01_kernel, dim3(nblk((long)B * T * k, 256, 2048)), dim3(256), 0, S_, x, y, B, T, k);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_colsum(const float* x, long ldx, float* out, long R, int N, int accumulate, void* stream) {
+  if (R <= 0 || N <= 0) return 0;
+  if (!x || !out) return DV3_ERR_ARG;
+  const unsigned bx = (unsigned)((N + 63) / 64);
+  long by = (R + 255) / 256;
+  if (by > 64) by = 64;
+  if (by < 1) by = 1;
+  if (by > 1 && !accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * N, S_);
+  hipLaunchKernelGGL(colsum_kernel, dim3(bx, (unsigned)by), dim3(256), 0, S_, x, ldx, out, R, N, accumulate);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_tanh_fwd(const float* x, float* y, long n, void* stream) {
   if (n <= 0) return 0;
-  if (!image_u8 || !out) return DV3_ERR_ARG;
-  hipLaunchKernelGGL(image_to_f32_kernel, dim3(nblk(n, 1024, 4096)), dim3(256), 0, S_, image_u8, out, n);
+  if (!x || !y) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(tanh_fwd_kernel, dim3(nblk(n, 256, 2048)), dim3(256), 0, S_, x, y, n);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_tanh_bwd(const float* y, const float* dy, float* dx, long n, int accumulate, void* stream) {
+  if (n <= 0) return 0;
+  if (!y || !dy || !dx) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(nblk(n, 256, 2048)), dim3(256), 0, S_, y, dy, dx, n, accumulate);
   return (int)hipGetLastError();
 }
 extern "C" int dv3_symlog_mse(const float* mode, const float* x, float* loss, float* dmode, long R, int W,

@@ -63,6 +63,7 @@ struct DenseTile {
   static constexpr int LD = ROWS + (KCONTIG ? (BK == 16 ? 2 : 1) : 4);
   f32x4 v[kVecs];
 
+  __device__ __forceinline__ void init(const DenseOperand<KCONTIG>&, int, int) {}
   __device__ __forceinline__ void load(const DenseOperand<KCONTIG>& op, int r0, int k0, int tid) {
     if constexpr (KCONTIG) {
       constexpr int CH = BK / 4;            // float4 chunks per row
@@ -158,7 +159,7 @@ struct TileShape {
 template <class TS, class ATile, class BTile, class AOp, class BOp>
 __device__ __forceinline__ void mfma_mainloop(const AOp& aop, const BOp& bop, int m0, int n0, int kbeg,
                                               int kend, float* lds, f32x16 (&acc)[TS::TM][TS::TN]) {
-  constexpr int BM = TS::BM, BN = TS::BN, BK = TS::BK;
+  constexpr int BM = TS::BM, BK = TS::BK;
   constexpr int LDA = ATile::LD, LDB = BTile::LD;
   float* As = lds;
   float* Bs = lds + 2 * BK * (BM + 4);
@@ -178,6 +179,8 @@ __device__ __forceinline__ void mfma_mainloop(const AOp& aop, const BOp& bop, in
   BTile bt;
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk <= 0) return;
+  at.init(aop, m0, tid);
+  bt.init(bop, n0, tid);
   at.load(aop, m0, kbeg, tid);
   bt.load(bop, n0, kbeg, tid);
   at.store(As, tid);

@@ -333,15 +333,27 @@ def bernoulli_logprob_bwd(logit, x, up, dlogit, *, accumulate=False):
     _call("dv3_bernoulli_logprob_bwd", _ptr(logit), _ptr(x), _ptr(up), _ptr(dlogit), n, int(accumulate), _stream())
 
 
-def image_to_f32(image_u8, out):
+def _perm(perm):
+    if perm is None:
+        return 0, 0
+    B, T = perm
+    return int(B), int(T)
+
+
+def image_to_f32(image_u8, out, *, n_images, perm=None):
+    """u8 -> u8/255 - 0.5.  perm=(B,T): output image t*B+b reads input image b*T+t."""
     _contig(image_u8, "image", torch.uint8), _contig(out, "out")
-    if out.numel() != image_u8.numel():
+    if out.numel() != image_u8.numel() or image_u8.numel() % n_images:
         raise ValueError("size mismatch")
-    _call("dv3_image_to_f32", _ptr(image_u8), _ptr(out), image_u8.numel(), _stream())
+    pixels = image_u8.numel() // n_images
+    B, T = _perm(perm)
+    if perm is not None and B * T != n_images:
+        raise ValueError("perm does not match n_images")
+    _call("dv3_image_to_f32", _ptr(image_u8), _ptr(out), n_images, pixels, B, T, _stream())
     return out
 
 
-def mse_image(recon, image_u8, loss, drecon=None, *, upstream=0.0):
+def mse_image(recon, image_u8, loss, drecon=None, *, upstream=0.0, perm=None):
     _contig(recon, "recon"), _contig(image_u8, "image", torch.uint8), _contig(loss, "loss")
     n_img = loss.numel()
     if recon.numel() != image_u8.numel() or recon.numel() % max(n_img, 1):
@@ -351,8 +363,101 @@ def mse_image(recon, image_u8, loss, drecon=None, *, upstream=0.0):
         _contig(drecon, "drecon")
         if drecon.numel() != recon.numel():
             raise ValueError("drecon size mismatch")
+    B, T = _perm(perm)
+    if perm is not None and B * T != n_img:
+        raise ValueError("perm does not match n_images")
     _call("dv3_mse_image", _ptr(recon), _ptr(image_u8), _ptr(loss), _ptr(drecon), n_img, pixels, float(upstream),
-          _stream())
+          B, T, _stream())
+
+
+def transpose01(x, y):
+    """[B,T,...] -> [T,B,...] (contiguous copies)."""
+    _contig(x, "x"), _contig(y, "y")
+    B, T = x.shape[0], x.shape[1]
+    k = x.numel() // (B * T)
+    if y.numel() != x.numel() or y.shape[0] != T or y.shape[1] != B:
+        raise ValueError("transpose01 shape mismatch")
+    _call("dv3_transpose01", _ptr(x), _ptr(y), B, T, k, _stream())
+    return y
+
+
+def colsum(x, out, *, accumulate=False):
+    R, N, ldx = _rows2d(x, "x")
+    _contig(out, "out")
+    if out.numel() != N:
+        raise ValueError("out size mismatch")
+    _call("dv3_colsum", _ptr(x), ldx, _ptr(out), R, N, int(accumulate), _stream())
+    return out
+
+
+def tanh_fwd(x, y):
+    _contig(x, "x"), _contig(y, "y")
+    if x.numel() != y.numel():
+        raise ValueError("size mismatch")
+    _call("dv3_tanh_fwd", _ptr(x), _ptr(y), x.numel(), _stream())
+    return y
+
+
+def tanh_bwd(y, dy, dx, *, accumulate=False):
+    _contig(y, "y"), _contig(dy, "dy"), _contig(dx, "dx")
+    if dy.numel() != y.numel() or dx.numel() != y.numel():
+        raise ValueError("size mismatch")
+    _call("dv3_tanh_bwd", _ptr(y), _ptr(dy), _ptr(dx), y.numel(), int(accumulate), _stream())
+
+
+def pack_conv_weight(w, wp, *, transposed):
+    """w: Conv2d [Co,Ci,4,4] (transposed=False) or ConvTranspose2d [Ci,Co,4,4] (transposed=True)."""
+    _contig(w, "w"), _contig(wp, "wp")
+    if w.dim() != 4 or w.shape[2] != 4 or w.shape[3] != 4 or wp.numel() != w.numel():
+        raise ValueError("conv weight must be [*,*,4,4]")
+    if transposed:
+        Ci, Co = w.shape[0], w.shape[1]
+    else:
+        Co, Ci = w.shape[0], w.shape[1]
+    _call("dv3_pack_conv_weight", _ptr(w), _ptr(wp), Co, Ci, int(transposed), _stream())
+    return wp
+
+
+def conv_s2_fwd(x, wp, y, *, Ci, Co, accumulate=False):
+    """x [N,H,W,Ci] NHWC, wp packed [Co,16*Ci], y [N,H/2,W/2,Co]."""
+    _contig(x, "x"), _contig(wp, "wp"), _contig(y, "y")
+    if x.dim() != 4 or x.shape[3] != Ci or x.shape[1] % 2 or x.shape[2] % 2:
+        raise ValueError(f"conv input must be [N,H,W,{Ci}] with even H,W")
+    N, H, W = x.shape[0], x.shape[1], x.shape[2]
+    if wp.numel() != 16 * Ci * Co or y.numel() != N * (H // 2) * (W // 2) * Co:
+        raise ValueError("conv shapes mismatch")
+    _call("dv3_conv_s2_fwd", _ptr(x), _ptr(wp), _ptr(y), N, H, W, Ci, Co, int(accumulate), _stream())
+    return y
+
+
+def convT_s2_fwd(x, wp, y, *, Ci, Co, bias=None, out_add=0.0, accumulate=False):
+    """x [N,IH,IW,Ci] NHWC, wp packed [4,Co,4*Ci], y [N,2IH,2IW,Co]."""
+    _contig(x, "x"), _contig(wp, "wp"), _contig(y, "y")
+    if x.dim() != 4 or x.shape[3] != Ci:
+        raise ValueError(f"convT input must be [N,IH,IW,{Ci}]")
+    N, IH, IW = x.shape[0], x.shape[1], x.shape[2]
+    if wp.numel() != 16 * Ci * Co or y.numel() != N * 4 * IH * IW * Co:
+        raise ValueError("convT shapes mismatch")
+    if bias is not None:
+        _contig(bias, "bias")
+        if bias.numel() != Co:
+            raise ValueError("bias size mismatch")
+    _call("dv3_convT_s2_fwd", _ptr(x), _ptr(wp), _ptr(bias), float(out_add), _ptr(y), N, IH, IW, Ci, Co,
+          int(accumulate), _stream())
+    return y
+
+
+def conv_s2_wgrad(coarse, fine, dw):
+    """dw[Cc,Cf,4,4] += grad.  coarse [N,H/2,W/2,Cc], fine [N,H,W,Cf] (NHWC)."""
+    _contig(coarse, "coarse"), _contig(fine, "fine"), _contig(dw, "dw")
+    if fine.dim() != 4 or coarse.dim() != 4:
+        raise ValueError("wgrad operands must be NHWC 4-D")
+    N, H, W, Cf = fine.shape
+    Cc = coarse.shape[3]
+    if coarse.shape[0] != N or coarse.shape[1] * 2 != H or coarse.shape[2] * 2 != W or dw.numel() != 16 * Cc * Cf:
+        raise ValueError("wgrad shapes mismatch")
+    _call("dv3_conv_s2_wgrad", _ptr(coarse), _ptr(fine), _ptr(dw), N, H, W, Cf, Cc, _stream())
+    return dw
 
 
 def symlog(x, y):

@@ -106,9 +106,39 @@ int dv3_bernoulli_logprob_bwd(const float* logit, const float* x, const float* u
  * dv3_image_to_f32: u8 -> u8/255 - 0.5 (WorldModel.preprocess models.py:180 + ConvEncoder networks.py:487).
  * dv3_mse_image: loss[img] = sum_pixels (recon - u8/255)^2 (tools.MSEDist.log_prob, tools.py:531-540,
  * negated), and, when drecon != NULL, drecon = 2*upstream*(recon - u8/255) in the same pass. */
-int dv3_image_to_f32(const unsigned char* image_u8, float* out, long n, void* stream);
+int dv3_image_to_f32(const unsigned char* image_u8, float* out, long n_images, int pixels, int perm_B, int perm_T,
+                     void* stream);
 int dv3_mse_image(const float* recon, const unsigned char* image_u8, float* loss, float* drecon, long n_images,
-                  int pixels, float upstream, void* stream);
+                  int pixels, float upstream, int perm_B, int perm_T, void* stream);
+/* perm_B/perm_T > 0: activations are time-major -- image n' = t*B + b of out/recon pairs with replay image
+ * b*T + t of image_u8 (the [B,T] -> [T,B] swap of RSSM.observe, networks.py:128-130, folded into the load). */
+
+/* ---- small layout / reduction helpers ---------------------------------------------------------------
+ * dv3_transpose01: [B,T,k] -> [T,B,k] (the same swap for action / reward / is_first / proprio keys).
+ * dv3_colsum: out[N] (+)= sum over rows of x[R,N] (bias gradients of the stat/head Linears).
+ * dv3_tanh_*: RSSM.initial's deter = tanh(W) (networks.py:121) and its backward (from y = tanh x). */
+int dv3_transpose01(const float* x, float* y, int B, int T, int k, void* stream);
+int dv3_colsum(const float* x, long ldx, float* out, long R, int N, int accumulate, void* stream);
+int dv3_tanh_fwd(const float* x, float* y, long n, void* stream);
+int dv3_tanh_bwd(const float* y, const float* dy, float* dx, long n, int accumulate, void* stream);
+
+/* ---- 64x64 CNN stacks as implicit GEMMs (NHWC activations) ---------------------------------------------
+ * dv3_pack_conv_weight: reference weight [A][B][4][4] -> MFMA-friendly image.  transposed=0: Conv2d
+ *   weight [Co][Ci][4][4] -> [Co][(ky,kx,ci)] for dv3_conv_s2_fwd.  transposed=1: ConvTranspose2d weight
+ *   [Ci][Co][4][4] -> [4 parity classes][Co][(a,b,ci)] for dv3_convT_s2_fwd.  (A Conv2d weight passed with
+ *   transposed=1 yields the image its dgrad needs, and vice versa: the two ops are adjoint.)
+ * dv3_conv_s2_fwd : y[N,H/2,W/2,Co] = Conv2d(k4,s2,pad 1)(x[N,H,W,Ci])      ConvEncoder layers, networks.py:466-474, 771-798
+ * dv3_convT_s2_fwd: y[N,2IH,2IW,Co] = ConvTranspose2d(k4,s2,p1)(x[N,IH,IW,Ci]) + bias + out_add
+ *                                                                          ConvDecoder layers, networks.py:540-550, 584
+ * dv3_conv_s2_wgrad: dw[Ccoarse][Cfine][4][4] += sum coarse[m,:]^T (x) gather(fine)  -- the weight gradient of
+ *   either op (conv: coarse=dY, fine=x; convT: coarse=layer input, fine=dOut), in the reference layout. */
+int dv3_pack_conv_weight(const float* w, float* w_packed, int Co, int Ci, int transposed, void* stream);
+int dv3_conv_s2_fwd(const float* x, const float* w_packed, float* y, int Nimg, int H, int W, int Ci, int Co,
+                    int accumulate, void* stream);
+int dv3_convT_s2_fwd(const float* x, const float* w_packed, const float* bias, float out_add, float* y, int Nimg,
+                     int IH, int IW, int Ci, int Co, int accumulate, void* stream);
+int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* dw, int Nimg, int H, int W, int Cfine,
+                      int Ccoarse, void* stream);
 
 /* ---- proprio inputs/outputs -- tools.symlog (tools.py:22-23), tools.SymlogDist (tools.py:543-572) --- */
 int dv3_symlog(const float* x, float* y, long n, void* stream);

@@ -344,11 +344,19 @@ def test_bernoulli_mse_symlog(ops):
     loss = torch.empty(6).cuda()
     dr = torch.empty(6, 64, 64, 3).cuda()
     ops.mse_image(dev(recon.detach()), dev(img), loss, dr, upstream=0.25)
+    # time-major pairing: recon image t*B+b <-> replay image b*T+t
+    B_, T_ = 2, 3
+    recon_tm = recon.detach().reshape(B_, T_, 64, 64, 3).transpose(0, 1).contiguous()
+    loss_tm = torch.empty(6).cuda()
+    ops.mse_image(dev(recon_tm), dev(img), loss_tm, None, perm=(B_, T_))
+    assert_close(loss_tm, loss_ref.detach().reshape(B_, T_).t().reshape(6), what='mse perm')
     assert_close(loss, loss_ref, what="mse")
     assert_close(dr, recon.grad, what="mse grad")
     f = torch.empty(6, 64, 64, 3).cuda()
-    ops.image_to_f32(dev(img), f)
+    ops.image_to_f32(dev(img), f, n_images=6)
     assert torch.equal(f.cpu(), img.float() / 255.0 - 0.5)
+    ops.image_to_f32(dev(img), f, n_images=6, perm=(B_, T_))
+    assert torch.equal(f.cpu(), (img.float() / 255.0 - 0.5).reshape(B_, T_, 64, 64, 3).transpose(0, 1).reshape(6, 64, 64, 3))
     # symlog mse
     mode = torch.randn(40, 9, generator=g).requires_grad_(True)
     xv = torch.randn(40, 9, generator=g) * 5
@@ -452,3 +460,116 @@ def test_adam_clip_matches_oracle(ops):
         assert abs(state[2].item() - norm_ref.item()) <= 1e-4 * norm_ref.item()
         assert_close(pd, p_ref, tol=1e-5, what=f"adam it {it}")
     assert state[0].item() == 3.0 and state[1].item() == 0.0
+
+
+# ------------------------------------------------------------------------------------------ conv stacks
+CONV_CASES = [(4, 64, 64, 3, 32), (3, 32, 32, 32, 64), (2, 16, 16, 64, 128), (5, 8, 8, 128, 256),
+              (3, 64, 64, 3, 2), (3, 32, 32, 2, 4), (2, 8, 8, 8, 16), (1, 4, 4, 6, 5)]
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co", CONV_CASES)
+def test_conv_s2_fwd_dgrad_wgrad(ops, N, H, W, Ci, Co):
+    """Encoder layer: Conv2d(k4,s2,'same') forward, its input gradient (= convT with the same weight)
+    and its weight gradient, against torch CPU conv2d autograd."""
+    g = torch.Generator().manual_seed(N * H + Ci * Co)
+    x = torch.randn(N, Ci, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Co, Ci, 4, 4, generator=g) / math.sqrt(16 * Ci)).requires_grad_(True)
+    dy = torch.randn(N, Co, H // 2, W // 2, generator=g)
+    y_ref = F.conv2d(F.pad(x, [1, 1, 1, 1]), w, None, 2)
+    y_ref.backward(dy)
+    xd, wd, dyd = dev(nhwc(x.detach())), dev(w.detach()), dev(nhwc(dy))
+    wp = torch.empty(Co, 16 * Ci).cuda()
+    ops.pack_conv_weight(wd, wp, transposed=False)
+    y = torch.empty(N, H // 2, W // 2, Co).cuda()
+    ops.conv_s2_fwd(xd, wp, y, Ci=Ci, Co=Co)
+    assert_close(y, nhwc(y_ref), what="conv fwd")
+    # dgrad: ConvTranspose2d with the Conv2d weight read as [in=Co][out=Ci]
+    wpt = torch.empty(4, Ci, 4 * Co).cuda()
+    ops.pack_conv_weight(wd, wpt, transposed=True)
+    dx = torch.empty(N, H, W, Ci).cuda()
+    ops.convT_s2_fwd(dyd, wpt, dx, Ci=Co, Co=Ci)
+    assert_close(dx, nhwc(x.grad), what="conv dgrad")
+    dw = torch.zeros(Co, Ci, 4, 4).cuda()
+    ops.conv_s2_wgrad(dyd, xd, dw)
+    assert_close(dw, w.grad, tol=2e-4, what="conv wgrad")
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co", [(4, 4, 4, 256, 128), (3, 8, 8, 128, 64), (2, 16, 16, 64, 32),
+                                         (3, 32, 32, 32, 3), (2, 4, 4, 16, 8), (2, 32, 32, 2, 3)])
+def test_convT_s2_fwd_dgrad_wgrad(ops, N, H, W, Ci, Co):
+    """Decoder layer: ConvTranspose2d(k4,s2,p1) + bias + 0.5, its input gradient (= conv with the
+    same weight) and its weight gradient."""
+    g = torch.Generator().manual_seed(N + H + Ci + Co)
+    x = torch.randn(N, Ci, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Ci, Co, 4, 4, generator=g) / math.sqrt(4 * Ci)).requires_grad_(True)
+    b = torch.randn(Co, generator=g)
+    dy = torch.randn(N, Co, 2 * H, 2 * W, generator=g)
+    y_ref = F.conv_transpose2d(x, w, b, 2, padding=1) + 0.5
+    y_ref.backward(dy)
+    xd, wd, dyd = dev(nhwc(x.detach())), dev(w.detach()), dev(nhwc(dy))
+    wpt = torch.empty(4, Co, 4 * Ci).cuda()
+    ops.pack_conv_weight(wd, wpt, transposed=True)
+    y = torch.empty(N, 2 * H, 2 * W, Co).cuda()
+    ops.convT_s2_fwd(xd, wpt, y, Ci=Ci, Co=Co, bias=dev(b), out_add=0.5)
+    assert_close(y, nhwc(y_ref), what="convT fwd")
+    # dgrad: Conv2d over dOut with the ConvTranspose2d weight read as [out=Ci][in=Co]
+    wp = torch.empty(Ci, 16 * Co).cuda()
+    ops.pack_conv_weight(wd, wp, transposed=False)
+    dx = torch.empty(N, H, W, Ci).cuda()
+    ops.conv_s2_fwd(dyd, wp, dx, Ci=Co, Co=Ci)
+    assert_close(dx, nhwc(x.grad), what="convT dgrad")
+    dw = torch.zeros(Ci, Co, 4, 4).cuda()
+    ops.conv_s2_wgrad(xd, dyd, dw)
+    assert_close(dw, w.grad, tol=2e-4, what="convT wgrad")
+
+
+def test_conv_full_size_linearity_property(ops):
+    """BASELINE cfg-2 size (1024 frames): conv(a*x1 + x2) == a*conv(x1) + conv(x2) -- a
+    size-independent check where a CPU reference would take too long."""
+    N, H, W, Ci, Co = 1024, 64, 64, 3, 32
+    g = torch.Generator().manual_seed(0)
+    x1 = torch.randn(N, H, W, Ci, generator=g).cuda()
+    x2 = torch.randn(N, H, W, Ci, generator=g).cuda()
+    w = dev(torch.randn(Co, Ci, 4, 4, generator=g) / math.sqrt(48))
+    wp = torch.empty(Co, 16 * Ci).cuda()
+    ops.pack_conv_weight(w, wp, transposed=False)
+    y1, y2, y3 = (torch.empty(N, 32, 32, Co).cuda() for _ in range(3))
+    ops.conv_s2_fwd(x1, wp, y1, Ci=Ci, Co=Co)
+    ops.conv_s2_fwd(x2, wp, y2, Ci=Ci, Co=Co)
+    ops.conv_s2_fwd(0.5 * x1 + x2, wp, y3, Ci=Ci, Co=Co)
+    assert_close(y3, 0.5 * y1 + y2, tol=1e-5, what="linearity")
+    # and the first 2 frames against the CPU reference
+    ref = F.conv2d(F.pad(x1[:2].cpu().permute(0, 3, 1, 2), [1, 1, 1, 1]), w.cpu(), None, 2)
+    assert_close(y1[:2], nhwc(ref), what="first frames")
+
+
+def test_layout_helpers(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 7, 11, generator=g)
+    y = torch.empty(7, 5, 11).cuda()
+    ops.transpose01(dev(x), y)
+    assert torch.equal(y.cpu(), x.transpose(0, 1).contiguous())
+    m = torch.randn(1000, 255, generator=g)
+    out = torch.empty(255).cuda()
+    ops.colsum(dev(m), out)
+    assert_close(out, m.sum(0), what="colsum")
+    ops.colsum(dev(m), out, accumulate=True)
+    assert_close(out, 2 * m.sum(0), what="colsum acc")
+    small = torch.randn(16, 6, generator=g)
+    o2 = torch.empty(6).cuda()
+    ops.colsum(dev(small), o2)
+    assert_close(o2, small.sum(0), what="colsum small")
+    t = torch.randn(1, 512, generator=g).requires_grad_(True)
+    yt = torch.tanh(t)
+    gy = torch.randn(1, 512, generator=g)
+    yt.backward(gy)
+    yd = torch.empty(1, 512).cuda()
+    ops.tanh_fwd(dev(t.detach()), yd)
+    assert_close(yd, yt, what="tanh")
+    dxd = torch.empty(1, 512).cuda()
+    ops.tanh_bwd(yd, dev(gy), dxd)
+    assert_close(dxd, t.grad, what="tanh bwd")
