@@ -457,6 +457,65 @@ __global__ void reset_blend_bwd_kernel(const float* __restrict__ dout, long ldo,
   }
 }
 
+// out[0] += sum_i f(x_i) * w_i ; f = max(., cmin) when use_clip.  (loss / metric reductions)
+__global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ x, const float* __restrict__ w, long n,
+                                                  float* __restrict__ out, int use_clip, float cmin, float scale) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = x[i];
+    if (use_clip) v = fmaxf(v, cmin);
+    a += w ? v * w[i] : v;
+  }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) atomicAdd(out, a * scale);
+}
+
+// Actor loss of ImagBehavior._compute_actor_loss + the entropy bonus (models.py:406-407, 640-681), with
+// its gradients, in one pass.  All [H][N] except target/base grads which use rows 0..H-2.
+//   offset = ema[0], scale = max(ema[1]-ema[0], 1)                                  (models.py:24-25)
+//   dynamics : loss_t = -w_t ((target_t-offset)/scale - (base_t-offset)/scale) - c ent_t ; dtarget = -w_t/(scale*cnt)
+//   reinforce: loss_t = -w_t logp_t (target_t - base_t) - c ent_t                ; dlogp   = -w_t (target_t-base_t)/cnt
+// loss_out[0] += mean over the (H-1)*N entries; dent = -c/cnt on rows < H-1, 0 on the last row.
+__global__ void actor_loss_kernel(const float* __restrict__ target, const float* __restrict__ value,
+                                  const float* __restrict__ weights, const float* __restrict__ ent,
+                                  const float* __restrict__ logp, const float* __restrict__ ema,
+                                  float* __restrict__ loss_out, float* __restrict__ dtarget,
+                                  float* __restrict__ dlogp, float* __restrict__ dent, int H, long N, float ent_coef,
+                                  int reinforce) {
+  __shared__ float red[4];
+  const long cnt = (long)(H - 1) * N;
+  const float inv = 1.f / (float)cnt;
+  const float offset = ema[0], scale = fmaxf(ema[1] - ema[0], 1.f);
+  float a = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)H * N; i += (long)gridDim.x * blockDim.x) {
+    if (i < cnt) {
+      const float w = weights[i];
+      float tgt;
+      if (reinforce) {
+        const float adv = target[i] - value[i];
+        tgt = logp[i] * adv;
+        dlogp[i] = -w * adv * inv;
+      } else {
+        tgt = (target[i] - offset) / scale - (value[i] - offset) / scale;
+        dtarget[i] = -w * inv / scale;
+      }
+      a += -w * tgt - ent_coef * ent[i];
+      dent[i] = -ent_coef * inv;
+    } else {
+      dent[i] = 0.f;
+      if (reinforce) dlogp[i] = 0.f;
+    }
+  }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) atomicAdd(loss_out, a * inv);
+}
+
+// up[i] = -w[i] * inv_count  (the upstream of both critic log-prob terms, models.py:424-429)
+__global__ void scale_neg_kernel(const float* __restrict__ w, float* __restrict__ up, long n, float s) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) up[i] = -w[i] * s;
+}
+
 static unsigned nblk(long n, int per, long cap) {
   long b = (n + per - 1) / per;
   if (b > cap) b = cap;
@@ -631,5 +690,29 @@ extern "C" int dv3_reset_blend_bwd(const float* dout, long ldo, const float* is_
   if (!dout || !is_first) return DV3_ERR_ARG;
   hipLaunchKernelGGL(reset_blend_bwd_kernel, dim3(nblk(n, 256, 2048)), dim3(256), 0, S_, dout, ldo, is_first, dx, ldx,
                      dinit, B, n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_dot_accumulate(const float* x, const float* w, long n, float* out, int use_clip_min, float clip_min,
+                                  float scale, void* stream) {
+  if (n <= 0) return 0;
+  if (!x || !out) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(dot_kernel, dim3(nblk(n, 1024, 512)), dim3(256), 0, S_, x, w, n, out, use_clip_min, clip_min, scale);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_actor_loss(const float* target, const float* value, const float* weights, const float* entropy,
+                              const float* logp, const float* ema_vals, float* loss_out, float* dtarget, float* dlogp,
+                              float* dentropy, int H, long N, float entropy_coef, int reinforce, void* stream) {
+  if (N <= 0) return 0;
+  if (H < 2 || !target || !value || !weights || !entropy || !ema_vals || !loss_out || !dentropy) return DV3_ERR_ARG;
+  if (reinforce ? (!logp || !dlogp) : !dtarget) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(actor_loss_kernel, dim3(nblk((long)H * N, 1024, 512)), dim3(256), 0, S_, target, value, weights,
+                     entropy, logp, ema_vals, loss_out, dtarget, dlogp, dentropy, H, N, entropy_coef, reinforce);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_scale_neg(const float* w, float* out, long n, float s, void* stream) {
+  if (n <= 0) return 0;
+  if (!w || !out) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(scale_neg_kernel, dim3(nblk(n, 256, 2048)), dim3(256), 0, S_, w, out, n, s);
   return (int)hipGetLastError();
 }

@@ -30,16 +30,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    float* __restrict__ state, float lr, float b1, float b2,
-                                                   float eps, float clip, float wd) {
+                                                   float eps, float clip, float wd, float gscale) {
   const float step = state[0] + 1.f;
-  const float norm = sqrtf(state[1]);
+  const float norm = sqrtf(state[1]) * gscale;
   float coef = 1.f;
   if (clip > 0.f) coef = fminf(clip / (norm + 1e-6f), 1.f);
   const float bc1 = 1.f - powf(b1, step);
   const float bc2s = sqrtf(1.f - powf(b2, step));
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float gi = g[i] * coef;
+    const float gi = g[i] * (coef * gscale);
     float pi = p[i];
     if (wd > 0.f) pi *= (1.f - wd);  // tools.py:778-783 (applied before the step, as the reference does)
     const float mi = m[i] + (1.f - b1) * (gi - m[i]);
@@ -51,9 +51,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 // runs after adam_kernel on the same stream: bump the step, publish the norm, clear the accumulator
-__global__ void adam_finish_kernel(float* __restrict__ state) {
+__global__ void adam_finish_kernel(float* __restrict__ state, float gscale) {
   state[0] += 1.f;
-  state[2] = sqrtf(state[1]);
+  state[2] = sqrtf(state[1]) * gscale;
   state[1] = 0.f;
 }
 
@@ -61,6 +61,24 @@ __global__ void adam_finish_kernel(float* __restrict__ state) {
 __global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a, float b) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = a * x[i] + b * y[i];
+}
+
+// N(0,1) fill (Box-Muller over Philox): the actor's rsample noise (torch _standard_normal in the
+// reference, networks.py:697-699) when the caller injects none.  One counter per 4 outputs.
+__global__ void fill_normal_kernel(float* __restrict__ out, long n, const unsigned long long* __restrict__ st) {
+  const unsigned long long seed = st[0], offset = st[1];
+  const long n4 = (n + 3) >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    uint32_t o[4];
+    Philox ph(seed);
+    ph(offset + (unsigned long long)i, 0x6e6f726dULL, o);
+    const float r0 = sqrtf(-2.f * logf(u01(o[0]))), r1 = sqrtf(-2.f * logf(u01(o[2])));
+    const float a0 = 6.283185307179586f * u01(o[1]), a1 = 6.283185307179586f * u01(o[3]);
+    const float z[4] = {r0 * cosf(a0), r0 * sinf(a0), r1 * cosf(a1), r1 * sinf(a1)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * i + e < n) out[4 * i + e] = z[e];
+  }
 }
 
 // advance the Philox offset kept in device memory: rng_state = {seed, offset}
@@ -86,13 +104,13 @@ extern "C" int dv3_sumsq_accumulate(const float* x, long n, float* out, void* st
 
 extern "C" int dv3_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float* state,
                              float lr, float beta1, float beta2, float eps, float clip, float weight_decay,
-                             void* stream) {
+                             float grad_scale, void* stream) {
   if (n <= 0) return 0;
   if (!param || !grad || !exp_avg || !exp_avg_sq || !state) return DV3_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 2048)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, state,
-                     lr, beta1, beta2, eps, clip, weight_decay);
-  hipLaunchKernelGGL(adam_finish_kernel, dim3(1), dim3(1), 0, s, state);
+                     lr, beta1, beta2, eps, clip, weight_decay, grad_scale);
+  hipLaunchKernelGGL(adam_finish_kernel, dim3(1), dim3(1), 0, s, state, grad_scale);
   return (int)hipGetLastError();
 }
 
@@ -106,6 +124,14 @@ extern "C" int dv3_axpby(const float* x, float* y, long n, float a, float b, voi
 extern "C" int dv3_rng_advance(unsigned long long* rng_state, unsigned long long increment, void* stream) {
   if (!rng_state) return DV3_ERR_ARG;
   hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state, increment);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_fill_normal(float* out, long n, const unsigned long long* rng_state, void* stream) {
+  if (n <= 0) return 0;
+  if (!out || !rng_state) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(fill_normal_kernel, dim3(blocks_for((n + 3) / 4, 2048)), dim3(256), 0, (hipStream_t)stream, out, n,
+                     rng_state);
   return (int)hipGetLastError();
 }
 

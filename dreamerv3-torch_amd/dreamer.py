@@ -1,0 +1,84 @@
+"""`Dreamer` agent class with the reference's surface (dreamer.py:35-208), over the MI355X-native
+`models` / `networks` / `tools`.  Only the class is provided: the reference's `main`, env
+construction and CLI (dreamer.py:261-601) are host-side driver code outside the accelerated path and
+keep working against this class unchanged.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+import models
+import tools
+
+to_np = lambda x: x.detach().cpu().numpy()
+
+
+class Dreamer(nn.Module):
+    def __init__(self, obs_space, act_space, config, logger, dataset):
+        super().__init__()
+        self._config = config
+        self._logger = logger
+        self._should_log = tools.Every(config.log_every)
+        batch_steps = config.batch_size * config.batch_length
+        self._should_train = tools.Every(batch_steps / config.train_ratio)
+        self._should_pretrain = tools.Once()
+        self._should_reset = tools.Every(config.reset_every)
+        self._should_expl = tools.Until(int(config.expl_until / config.action_repeat))
+        self._metrics = {}
+        self._step = (logger.step if logger is not None else 0) // config.action_repeat
+        self._update_count = 0
+        self._dataset = dataset
+        if getattr(config, "causal_world_model", False):
+            raise NotImplementedError("causal world models are outside the accelerated path (SURVEY.md §2 #13-14)")
+        self._wm = models.WorldModel(obs_space, act_space, self._step, config)
+        self._task_behavior = models.ImagBehavior(config, self._wm)
+        if config.expl_behavior != "greedy":
+            raise NotImplementedError("only expl_behavior='greedy' is on the accelerated path")
+        self._expl_behavior = self._task_behavior
+
+    def __call__(self, obs, reset, state=None, training=True):
+        step = self._step
+        if training:
+            steps = self._config.pretrain if self._should_pretrain() else self._should_train(step)
+            for _ in range(steps):
+                self._train(next(self._dataset))
+                self._update_count += 1
+                self._metrics["update_count"] = self._update_count
+            if self._should_log(step) and self._logger is not None:
+                for name, values in self._metrics.items():
+                    self._logger.scalar(name, float(np.mean(values)))
+                    self._metrics[name] = []
+                if self._config.video_pred_log:
+                    openl = self._wm.video_pred(next(self._dataset))
+                    self._logger.video("train_openl", to_np(openl))
+                self._logger.write(fps=True)
+        policy_output, state = self._policy(obs, state, training)
+        if training:
+            self._step += len(reset)
+            if self._logger is not None:
+                self._logger.step = self._config.action_repeat * self._step
+        return policy_output, state
+
+    def _policy(self, obs, state, training):
+        latent, action = (None, None) if state is None else state
+        obs = self._wm.preprocess(obs)
+        embed = self._wm.encoder(obs)
+        latent, _ = self._wm.dynamics.obs_step(latent, action, embed, obs["is_first"])
+        feat = self._wm.dynamics.get_feat(latent)
+        actor = self._task_behavior.actor(feat)
+        action = actor.sample() if training else actor.mode()
+        logprob = actor.log_prob(action)
+        latent = {k: v.detach() for k, v in latent.items()}
+        action = action.detach()
+        return {"action": action, "logprob": logprob}, (latent, action)
+
+    def _train(self, data):
+        metrics = {}
+        post, context, mets = self._wm._train(data)
+        metrics.update(mets)
+        reward = lambda f, s, a: self._wm.heads["reward"](self._wm.dynamics.get_feat(s)).mode()
+        metrics.update(self._task_behavior._train(post, reward)[-1])
+        for name, value in metrics.items():
+            self._metrics.setdefault(name, []).append(value)

@@ -1,0 +1,556 @@
+"""Explicit forward/backward engine of the world-model training hot path.
+
+No autograd: every backward below is hand-derived and launches libdv3hip kernels into
+pre-allocated workspaces, so one whole update is a fixed sequence of kernel launches that a
+hipGraph can replay.  Sequential work (the two scans) does only what must be sequential; all
+weight gradients and everything that does not feed the recurrence is batched over time:
+
+  observe (networks.RSSM.observe -> obs_step, networks.py:127-206): per step only
+      blend -> img_in -> GRU -> obs_out(deter part) -> obs_stat -> sample
+  runs in the scan (M = batch rows); the embed half of the obs_out Linear (the largest GEMM of
+  obs_step), the whole prior head (img_out -> ims_stat -> sample) and every wgrad run once over
+  all T*B rows.  Activations are time-major [T,B,...] so each step is a contiguous row block.
+
+  imagine (models.ImagBehavior._imagine, models.py:448-548): per step actor -> sample -> img_step
+  on M = B*T rows; the H-th successor, which the reference computes and discards
+  (models.py:546), is not computed.
+
+Parameter containers hold torch.nn.Parameters whose .grad are views into a flat gradient bucket
+(dv3hip.params.ParamBucket); gradients are accumulated straight into those views.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+F32 = torch.float32
+
+
+class Workspace:
+    """Named device buffers, allocated on first use and reused (no allocation in steady state)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._b: Dict[str, torch.Tensor] = {}
+
+    def get(self, name, shape, dtype=F32) -> torch.Tensor:
+        shape = tuple(int(s) for s in shape)
+        t = self._b.get(name)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._b[name] = t
+        return t
+
+    def zeros(self, name, shape, dtype=F32) -> torch.Tensor:
+        t = self.get(name, shape, dtype)
+        t.zero_()
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._b.values())
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers (plain references to nn.Parameters; .grad are bucket views)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class PLin:
+    W: torch.Tensor
+    b: Optional[torch.Tensor] = None
+
+
+@dataclass
+class PDenseLN:
+    W: torch.Tensor
+    g: torch.Tensor
+    b: torch.Tensor
+
+
+@dataclass
+class PMLP:
+    layers: List[PDenseLN]
+    out: Optional[PLin] = None  # mean_layer
+    out2: Optional[PLin] = None  # std_layer (continuous actor)
+
+
+@dataclass
+class PRSSM:
+    W0: torch.Tensor  # dynamics.W [1,De]
+    img_in: PDenseLN
+    gru: PDenseLN
+    img_out: PDenseLN
+    obs_out: PDenseLN
+    ims: PLin
+    obs: PLin
+
+
+def _g(p):
+    return p.grad
+
+
+def v2(t: torch.Tensor, cols: int) -> torch.Tensor:
+    return t.reshape(-1, cols)
+
+
+# ---------------------------------------------------------------------------------------------
+# Linear(no bias) -> LN -> SiLU on row blocks
+# ---------------------------------------------------------------------------------------------
+def dense_ln_fwd(L: PDenseLN, x1, x2, pre, mean, rstd, y, *, accumulate_pre=False):
+    ops.gemm(x1, L.W, pre, A2=x2, accumulate=accumulate_pre)
+    ops.ln_act_fwd(pre, L.g, L.b, y, mean, rstd, act=True)
+
+
+def dense_ln_bwd_pre(L: PDenseLN, dy, pre, mean, rstd, dpre, *, wgrad: bool):
+    ops.ln_act_bwd(dy, pre, L.g, L.b, mean, rstd, dpre, _g(L.g) if wgrad else None, _g(L.b) if wgrad else None,
+                   act=True)
+
+
+def lin_wgrad(W, dY, x1, x2=None):
+    """W.grad += dY^T @ [x1|x2]."""
+    k1 = x1.shape[1]
+    gW = _g(W)
+    ops.gemm(dY, x1, gW[:, :k1] if x2 is not None else gW, transA=True, transB=False, accumulate=True)
+    if x2 is not None:
+        ops.gemm(dY, x2, gW[:, k1:], transA=True, transB=False, accumulate=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# MLP trunk + head Linears (networks.MLP, networks.py:588-681) on a row block, fwd / bwd
+# ---------------------------------------------------------------------------------------------
+class MLPEngine:
+    """Activations live in [total_rows, .] buffers; forward() may fill a row range of them (the actor is
+    evaluated step by step inside the imagination scan but back-propagated in one batch)."""
+
+    def __init__(self, name: str, P: PMLP, ws: Workspace):
+        self.name, self.P, self.ws = name, P, ws
+        self.total = 0
+
+    def _bufs(self, total):
+        P, ws, nm = self.P, self.ws, self.name
+        self.total = total
+        acts = []
+        for i, L in enumerate(P.layers):
+            U = L.W.shape[0]
+            acts.append((ws.get(f"{nm}.pre{i}", (total, U)), ws.get(f"{nm}.m{i}", (total,)),
+                         ws.get(f"{nm}.r{i}", (total,)), ws.get(f"{nm}.y{i}", (total, U))))
+        out = ws.get(f"{nm}.out", (total, P.out.W.shape[0])) if P.out is not None else None
+        out2 = ws.get(f"{nm}.out2", (total, P.out2.W.shape[0])) if P.out2 is not None else None
+        return acts, out, out2
+
+    def forward(self, x1, x2=None, *, row0=0, total=None):
+        """x = [x1|x2] (R rows) -> (trunk output, mean_layer output, std_layer output) for rows
+        [row0, row0+R) of the engine's buffers."""
+        P = self.P
+        R = x1.shape[0]
+        total = R if total is None else total
+        acts, out, out2 = self._bufs(total)
+        rs = slice(row0, row0 + R)
+        h1, h2 = x1, x2
+        for (pre, mean, rstd, y), L in zip(acts, P.layers):
+            dense_ln_fwd(L, h1, h2, pre[rs], mean[rs], rstd[rs], y[rs])
+            h1, h2 = y[rs], None
+        o = o2 = None
+        if out is not None:
+            o = out[rs]
+            ops.gemm(h1, P.out.W, o, A2=h2, bias=P.out.b)
+        if out2 is not None:
+            o2 = out2[rs]
+            ops.gemm(h1, P.out2.W, o2, bias=P.out2.b)
+        return h1, o, o2
+
+    def backward(self, x1, x2, rows: slice, dout=None, dout2=None, *, wgrad: bool, dx1=None, dx2=None,
+                 acc_dx=False, dh=None):
+        """Back-propagate rows `rows` of the stored activations.  x1/x2: the inputs those rows were computed
+        from (same row count).  dout/dout2: gradients of the head Linears' outputs for those rows; dh: gradient
+        on the trunk output itself (head-less MLPs such as the proprio encoder)."""
+        P, ws, nm = self.P, self.ws, self.name
+        acts, _, _ = self._bufs(self.total)
+        R = x1.shape[0]
+        n_layers = len(P.layers)
+        h = acts[-1][3][rows] if n_layers else x1
+        first = True
+        if dh is not None:
+            first = False
+        else:
+            dh = ws.get(f"{nm}.dh", (R, h.shape[1]))
+        for lin, d in ((P.out, dout), (P.out2, dout2)):
+            if lin is None or d is None:
+                continue
+            ops.gemm(d, lin.W, dh, transB=False, accumulate=not first)
+            first = False
+            if wgrad:
+                lin_wgrad(lin.W, d, h)
+                if lin.b is not None:
+                    ops.colsum(d, _g(lin.b), accumulate=True)
+        if first:
+            raise ValueError("MLP backward without any upstream gradient")
+        dy = dh
+        for i in reversed(range(n_layers)):
+            L = P.layers[i]
+            pre, mean, rstd, _ = acts[i]
+            xin1, xin2 = (acts[i - 1][3][rows], None) if i > 0 else (x1, x2)
+            dpre = ws.get(f"{nm}.dpre{i}", (R, pre.shape[1]))
+            dense_ln_bwd_pre(L, dy, pre[rows], mean[rows], rstd[rows], dpre, wgrad=wgrad)
+            if wgrad:
+                lin_wgrad(L.W, dpre, xin1, xin2)
+            if i > 0:
+                dprev = ws.get(f"{nm}.dy{i - 1}", (R, xin1.shape[1]))
+                ops.gemm(dpre, L.W, dprev, transB=False)
+                dy = dprev
+            else:
+                k1 = x1.shape[1]
+                if dx1 is not None:
+                    ops.gemm(dpre, L.W[:, :k1] if x2 is not None else L.W, dx1, transB=False, accumulate=acc_dx)
+                if dx2 is not None and x2 is not None:
+                    ops.gemm(dpre, L.W[:, k1:], dx2, transB=False, accumulate=acc_dx)
+
+
+# ---------------------------------------------------------------------------------------------
+# RSSM scans
+# ---------------------------------------------------------------------------------------------
+class RSSMEngine:
+    def __init__(self, P: PRSSM, ws: Workspace, *, stoch: int, discrete: int, deter: int, hidden: int,
+                 num_actions: int, embed: int, unimix: float):
+        self.P, self.ws = P, ws
+        self.S, self.D, self.De, self.Hd, self.A, self.E = stoch, discrete, deter, hidden, num_actions, embed
+        self.SD = stoch * discrete
+        self.unimix = unimix
+
+    # -- initial state (networks.py:99-123, 235-239): deter0 = tanh(W), stoch0 = mode(prior head) -----
+    def init_state_fwd(self):
+        P, ws = self.P, self.ws
+        d0 = ws.get("init.deter", (1, self.De))
+        ops.tanh_fwd(P.W0, d0)
+        x0pre = ws.get("init.x0pre", (1, self.Hd))
+        x0 = ws.get("init.x0", (1, self.Hd))
+        m0, r0 = ws.get("init.m", (1,)), ws.get("init.r", (1,))
+        dense_ln_fwd(P.img_out, d0, None, x0pre, m0, r0, x0)
+        l0 = ws.get("init.logit", (1, self.SD))
+        ops.gemm(x0, P.ims.W, l0, bias=P.ims.b)
+        s0 = ws.get("init.stoch", (1, self.SD))
+        ops.onehot_sample(l0.view(self.S, self.D), s0.view(self.S, self.D), unimix=self.unimix, mode=True)
+        return s0, d0
+
+    def init_state_bwd(self, dstoch0, ddeter0):
+        """dstoch0 [SD], ddeter0 [De] (accumulated by the scan) -> grads of W0 and the prior head."""
+        P, ws = self.P, self.ws
+        l0, x0, x0pre, d0 = ws.get("init.logit", (1, self.SD)), ws.get("init.x0", (1, self.Hd)), \
+            ws.get("init.x0pre", (1, self.Hd)), ws.get("init.deter", (1, self.De))
+        m0, r0 = ws.get("init.m", (1,)), ws.get("init.r", (1,))
+        dl0 = ws.get("init.dlogit", (1, self.SD))
+        ops.onehot_st_bwd(l0.view(self.S, self.D), dstoch0.view(self.S, self.D), dl0.view(self.S, self.D),
+                          unimix=self.unimix, mode=True)
+        dx0 = ws.get("init.dx0", (1, self.Hd))
+        ops.gemm(dl0, P.ims.W, dx0, transB=False)
+        lin_wgrad(P.ims.W, dl0, x0)
+        ops.colsum(dl0, _g(P.ims.b), accumulate=True)
+        dx0pre = ws.get("init.dx0pre", (1, self.Hd))
+        dense_ln_bwd_pre(P.img_out, dx0, x0pre, m0, r0, dx0pre, wgrad=True)
+        lin_wgrad(P.img_out.W, dx0pre, d0)
+        dd = ddeter0.view(1, self.De)
+        ops.gemm(dx0pre, P.img_out.W, dd, transB=False, accumulate=True)
+        ops.tanh_bwd(d0, dd, _g(P.W0), accumulate=True)
+
+    # -- observe ------------------------------------------------------------------------------------
+    def observe_fwd(self, embed_tm, action_tm, first_tm, *, q_prior=None, q_post=None, rng=None):
+        """embed_tm [T,B,E], action_tm [T,B,A], first_tm [T,B] (float 0/1; row 0 is forced to 1, as
+        prev_state=None does in networks.py:176-180).  Noise [T,B,S,D] ~ Exp(1) or rng state.
+        Returns dict of time-major buffers."""
+        P, ws = self.P, self.ws
+        T, B = embed_tm.shape[0], embed_tm.shape[1]
+        S, D, SD, De, Hd, A, E = self.S, self.D, self.SD, self.De, self.Hd, self.A, self.E
+        self.T, self.B = T, B
+        TB = T * B
+        s0, d0 = self.init_state_fwd()
+        first = ws.get("obs.first", (T, B))
+        first.copy_(first_tm)
+        first[0].fill_(1.0)
+        g = ws.get
+        sin, din, ain = g("obs.sin", (T, B, SD)), g("obs.din", (T, B, De)), g("obs.ain", (T, B, A))
+        x1pre, x1 = g("obs.x1pre", (T, B, Hd)), g("obs.x1", (T, B, Hd))
+        m1, r1 = g("obs.m1", (T, B)), g("obs.r1", (T, B))
+        gpre, mg, rg = g("obs.gpre", (T, B, 3 * De)), g("obs.mg", (T, B)), g("obs.rg", (T, B))
+        deter = g("obs.deter", (T, B, De))
+        x3pre, x3 = g("obs.x3pre", (T, B, Hd)), g("obs.x3", (T, B, Hd))
+        m3, r3 = g("obs.m3", (T, B)), g("obs.r3", (T, B))
+        post_logit, post_stoch = g("obs.post_logit", (T, B, S, D)), g("obs.post_stoch", (T, B, S, D))
+        # embed half of obs_out for all steps at once: x3pre = embed @ W_obs[:, De:]^T
+        ops.gemm(v2(embed_tm, E), P.obs_out.W[:, De:], v2(x3pre, Hd))
+        for t in range(T):
+            ft = first[t]
+            prev_s = post_stoch[t - 1].view(B, SD) if t > 0 else None
+            prev_d = deter[t - 1] if t > 0 else None
+            ops.reset_blend(prev_s, s0.view(SD), ft, sin[t])
+            ops.reset_blend(prev_d, d0.view(De), ft, din[t])
+            ops.reset_blend(action_tm[t], None, ft, ain[t])
+            dense_ln_fwd(P.img_in, sin[t], ain[t], x1pre[t], m1[t], r1[t], x1[t])
+            ops.gemm(x1[t], P.gru.W, gpre[t], A2=din[t])
+            ops.gru_fwd(gpre[t], P.gru.g, P.gru.b, din[t], deter[t], mg[t], rg[t])
+            ops.gemm(deter[t], P.obs_out.W[:, :De], x3pre[t], accumulate=True)
+            ops.ln_act_fwd(x3pre[t], P.obs_out.g, P.obs_out.b, x3[t], m3[t], r3[t], act=True)
+            ops.gemm(x3[t], P.obs.W, post_logit[t].view(B, SD), bias=P.obs.b)
+            ops.onehot_sample(post_logit[t], post_stoch[t], noise=None if q_post is None else q_post[t],
+                              rng_state=rng, unimix=self.unimix)
+            if q_post is None:
+                ops.rng_advance(rng, B * SD // 4 + 1)
+        # prior head for all steps at once
+        x2pre, x2 = g("obs.x2pre", (T, B, Hd)), g("obs.x2", (T, B, Hd))
+        m2, r2 = g("obs.m2", (T, B)), g("obs.r2", (T, B))
+        prior_logit, prior_stoch = g("obs.prior_logit", (T, B, S, D)), g("obs.prior_stoch", (T, B, S, D))
+        dense_ln_fwd(P.img_out, v2(deter, De), None, v2(x2pre, Hd), m2.view(TB), r2.view(TB), v2(x2, Hd))
+        ops.gemm(v2(x2, Hd), P.ims.W, v2(prior_logit, SD), bias=P.ims.b)
+        ops.onehot_sample(prior_logit, prior_stoch, noise=q_prior, rng_state=rng, unimix=self.unimix)
+        if q_prior is None:
+            ops.rng_advance(rng, TB * SD // 4 + 1)
+        self._embed = embed_tm
+        return dict(post_stoch=post_stoch, post_logit=post_logit, deter=deter, prior_stoch=prior_stoch,
+                    prior_logit=prior_logit, action=ain)
+
+    def observe_bwd(self, dpost_logit, dprior_logit, gs, gd, dembed):
+        """Backward of observe_fwd.
+
+        dpost_logit/dprior_logit [T,B,S,D]: gradient on the logits (from the KL; dpost_logit is updated in
+        place with the straight-through term).  gs [T,B,SD], gd [T,B,De]: gradient on post stoch / deter
+        from the heads (both are used as scratch).  dembed [T,B,E] receives the encoder-output gradient.
+        All RSSM parameter gradients are accumulated into their .grad views."""
+        P, ws = self.P, self.ws
+        T, B, S, D, SD, De, Hd, A, E = self.T, self.B, self.S, self.D, self.SD, self.De, self.Hd, self.A, self.E
+        TB = T * B
+        g = ws.get
+        first = g("obs.first", (T, B))
+        sin, din, ain = g("obs.sin", (T, B, SD)), g("obs.din", (T, B, De)), g("obs.ain", (T, B, A))
+        x1pre, x1 = g("obs.x1pre", (T, B, Hd)), g("obs.x1", (T, B, Hd))
+        m1, r1 = g("obs.m1", (T, B)), g("obs.r1", (T, B))
+        gpre, mg, rg = g("obs.gpre", (T, B, 3 * De)), g("obs.mg", (T, B)), g("obs.rg", (T, B))
+        deter = g("obs.deter", (T, B, De))
+        x3pre, x3 = g("obs.x3pre", (T, B, Hd)), g("obs.x3", (T, B, Hd))
+        m3, r3 = g("obs.m3", (T, B)), g("obs.r3", (T, B))
+        post_logit = g("obs.post_logit", (T, B, S, D))
+        x2pre, x2 = g("obs.x2pre", (T, B, Hd)), g("obs.x2", (T, B, Hd))
+        m2, r2 = g("obs.m2", (T, B)), g("obs.r2", (T, B))
+        # ---- prior head, batched: prior_logit -> ims -> LN/SiLU -> img_out -> deter
+        dx2 = g("obs.dx2", (TB, Hd))
+        dpl2 = v2(dprior_logit, SD)
+        ops.gemm(dpl2, P.ims.W, dx2, transB=False)
+        lin_wgrad(P.ims.W, dpl2, v2(x2, Hd))
+        ops.colsum(dpl2, _g(P.ims.b), accumulate=True)
+        dx2pre = g("obs.dx2pre", (TB, Hd))
+        dense_ln_bwd_pre(P.img_out, dx2, v2(x2pre, Hd), m2.view(TB), r2.view(TB), dx2pre, wgrad=True)
+        lin_wgrad(P.img_out.W, dx2pre, v2(deter, De))
+        ops.gemm(dx2pre, P.img_out.W, v2(gd, De), transB=False, accumulate=True)
+        # ---- reverse scan
+        dx3 = g("obs.dx3", (B, Hd))
+        dx3pre = g("obs.dx3pre", (T, B, Hd))
+        dgpre = g("obs.dgpre", (T, B, 3 * De))
+        dx1 = g("obs.dx1", (B, Hd))
+        dx1pre = g("obs.dx1pre", (T, B, Hd))
+        dsin, ddin = g("obs.dsin", (B, SD)), g("obs.ddin", (B, De))
+        carry_s, carry_d = g("obs.carry_s", (B, SD)), g("obs.carry_d", (B, De))
+        dstoch0, ddeter0 = ws.zeros("obs.dstoch0", (SD,)), ws.zeros("obs.ddeter0", (De,))
+        for t in reversed(range(T)):
+            gs_t, gd_t = gs[t], gd[t]
+            if t < T - 1:
+                ops.axpby(carry_s, gs_t, 1.0, 1.0)
+                ops.axpby(carry_d, gd_t, 1.0, 1.0)
+            ops.onehot_st_bwd(post_logit[t], gs_t.view(B, S, D), dpost_logit[t], unimix=self.unimix, accumulate=True)
+            ops.gemm(dpost_logit[t].view(B, SD), P.obs.W, dx3, transB=False)
+            dense_ln_bwd_pre(P.obs_out, dx3, x3pre[t], m3[t], r3[t], dx3pre[t], wgrad=True)
+            ops.gemm(dx3pre[t], P.obs_out.W[:, :De], gd_t, transB=False, accumulate=True)
+            ops.gru_bwd(gd_t, gpre[t], P.gru.g, P.gru.b, din[t], mg[t], rg[t], dgpre[t], ddin, _g(P.gru.g),
+                        _g(P.gru.b))
+            ops.gemm(dgpre[t], P.gru.W[:, Hd:], ddin, transB=False, accumulate=True)
+            ops.gemm(dgpre[t], P.gru.W[:, :Hd], dx1, transB=False)
+            dense_ln_bwd_pre(P.img_in, dx1, x1pre[t], m1[t], r1[t], dx1pre[t], wgrad=True)
+            ops.gemm(dx1pre[t], P.img_in.W[:, :SD], dsin, transB=False)
+            ops.reset_blend_bwd(dsin, first[t], carry_s, dstoch0)
+            ops.reset_blend_bwd(ddin, first[t], carry_d, ddeter0)
+        # ---- batched weight gradients and the encoder-output gradient
+        dpl = v2(dpost_logit, SD)
+        lin_wgrad(P.obs.W, dpl, v2(x3, Hd))
+        ops.colsum(dpl, _g(P.obs.b), accumulate=True)
+        lin_wgrad(P.obs_out.W, v2(dx3pre, Hd), v2(deter, De), v2(self._embed, E))
+        lin_wgrad(P.gru.W, v2(dgpre, 3 * De), v2(x1, Hd), v2(din, De))
+        lin_wgrad(P.img_in.W, v2(dx1pre, Hd), v2(sin, SD), v2(ain, A))
+        ops.gemm(v2(dx3pre, Hd), P.obs_out.W[:, De:], v2(dembed, E), transB=False)
+        self.init_state_bwd(dstoch0, ddeter0)
+
+    # -- one img_step on a row block (networks.py:208-233), used by the policy path and imagine ---------
+    def img_step_fwd(self, stoch, deter, action, bufs, *, noise=None, rng=None, sample=True):
+        """stoch [M,SD], deter [M,De], action [M,A]; bufs: dict of per-step buffers (see imagine_fwd)."""
+        P = self.P
+        M = stoch.shape[0]
+        dense_ln_fwd(P.img_in, stoch, action, bufs["x1pre"], bufs["m1"], bufs["r1"], bufs["x1"])
+        ops.gemm(bufs["x1"], P.gru.W, bufs["gpre"], A2=deter)
+        ops.gru_fwd(bufs["gpre"], P.gru.g, P.gru.b, deter, bufs["deter"], bufs["mg"], bufs["rg"])
+        dense_ln_fwd(P.img_out, bufs["deter"], None, bufs["x2pre"], bufs["m2"], bufs["r2"], bufs["x2"])
+        ops.gemm(bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD), bias=P.ims.b)
+        ops.onehot_sample(bufs["logit"], bufs["stoch"], noise=noise, rng_state=rng, unimix=self.unimix,
+                          mode=not sample)
+        if sample and noise is None:
+            ops.rng_advance(rng, M * self.SD // 4 + 1)
+
+    def img_step_bwd(self, dstoch, ddeter, prev_deter, bufs, scratch, dprev_stoch, dprev_deter, daction):
+        """Input gradients of img_step_fwd (world-model weights frozen: no wgrad; models.py:335).
+        dstoch [M,SD] / ddeter [M,De]: total gradient on the step's outputs (ddeter is used as scratch).
+        Writes dprev_stoch, dprev_deter, daction."""
+        P = self.P
+        M = dstoch.shape[0]
+        S, D, SD, De, Hd = self.S, self.D, self.SD, self.De, self.Hd
+        dlogit = scratch["dlogit"]
+        ops.onehot_st_bwd(bufs["logit"], dstoch.view(M, S, D), dlogit.view(M, S, D), unimix=self.unimix)
+        ops.gemm(dlogit, P.ims.W, scratch["dx2"], transB=False)
+        dense_ln_bwd_pre(P.img_out, scratch["dx2"], bufs["x2pre"], bufs["m2"], bufs["r2"], scratch["dx2pre"],
+                         wgrad=False)
+        ops.gemm(scratch["dx2pre"], P.img_out.W, ddeter, transB=False, accumulate=True)
+        ops.gru_bwd(ddeter, bufs["gpre"], P.gru.g, P.gru.b, prev_deter, bufs["mg"], bufs["rg"], scratch["dgpre"],
+                    dprev_deter)
+        ops.gemm(scratch["dgpre"], P.gru.W[:, Hd:], dprev_deter, transB=False, accumulate=True)
+        ops.gemm(scratch["dgpre"], P.gru.W[:, :Hd], scratch["dx1"], transB=False)
+        dense_ln_bwd_pre(P.img_in, scratch["dx1"], bufs["x1pre"], bufs["m1"], bufs["r1"], scratch["dx1pre"],
+                         wgrad=False)
+        ops.gemm(scratch["dx1pre"], P.img_in.W[:, :SD], dprev_stoch, transB=False)
+        if daction is not None:
+            ops.gemm(scratch["dx1pre"], P.img_in.W[:, SD:], daction, transB=False)
+
+
+# ---------------------------------------------------------------------------------------------
+# 64x64 conv stacks (networks.ConvEncoder / ConvDecoder, networks.py:448-585), NHWC activations
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class PConvLayer:
+    W: torch.Tensor  # Conv2d [Co,Ci,4,4] (encoder) / ConvTranspose2d [Ci,Co,4,4] (decoder)
+    g: Optional[torch.Tensor] = None  # channel LayerNorm scale / shift (None on the decoder's last layer)
+    b: Optional[torch.Tensor] = None
+    bias: Optional[torch.Tensor] = None  # only the decoder's last layer has a bias
+
+
+class ConvEncoderEngine:
+    def __init__(self, layers: List[PConvLayer], ws: Workspace, size=64):
+        self.L, self.ws, self.size = layers, ws, size
+
+    def forward(self, image_u8=None, perm=None, x_f32=None):
+        """image_u8 [B,T,H,W,C] u8 (or x_f32 [N,H,W,C] already = image/255 - 0.5) -> embed [N, E] in the
+        reference's (C,H,W) flatten order; rows time-major when perm=(B,T) (row t*B+b <- image b*T+t)."""
+        ws = self.ws
+        H = self.size
+        if x_f32 is not None:
+            x, N = x_f32, x_f32.shape[0]
+        else:
+            N = image_u8.shape[0] * image_u8.shape[1]
+            C = image_u8.shape[-1]
+            x = ws.get("enc.x0", (N, H, H, C))
+            ops.image_to_f32(image_u8, x, n_images=N, perm=perm)
+        self._acts = []
+        n_layers = len(self.L)
+        for i, L in enumerate(self.L):
+            Co, Ci = L.W.shape[0], L.W.shape[1]
+            wp = ws.get(f"enc.wp{i}", (Co, 16 * Ci))
+            ops.pack_conv_weight(L.W, wp, transposed=False)
+            OH = H // 2
+            pre = ws.get(f"enc.pre{i}", (N, OH, OH, Co))
+            ops.conv_s2_fwd(x, wp, pre, Ci=Ci, Co=Co)
+            R = N * OH * OH
+            mean, rstd = ws.get(f"enc.m{i}", (R,)), ws.get(f"enc.r{i}", (R,))
+            last = i == n_layers - 1
+            y = ws.get(f"enc.y{i}", (N, Co * OH * OH) if last else (N, OH, OH, Co))
+            ops.ln_act_fwd(pre.view(R, Co), L.g, L.b, y if last else y.view(R, Co), mean, rstd, act=True,
+                           chw_group=OH * OH if last else 0)
+            self._acts.append((x, pre, mean, rstd, y))
+            x, H = y, OH
+        return x
+
+    def backward(self, dembed):
+        ws = self.ws
+        n_layers = len(self.L)
+        dy = dembed
+        for i in reversed(range(n_layers)):
+            L = self.L[i]
+            x, pre, mean, rstd, y = self._acts[i]
+            Co, Ci = L.W.shape[0], L.W.shape[1]
+            N, OH = pre.shape[0], pre.shape[1]
+            R = N * OH * OH
+            last = i == n_layers - 1
+            dpre = ws.get(f"enc.dpre{i}", pre.shape)
+            ops.ln_act_bwd(dy if last else dy.view(R, Co), pre.view(R, Co), L.g, L.b, mean, rstd, dpre.view(R, Co),
+                           _g(L.g), _g(L.b), act=True, chw_group=OH * OH if last else 0)
+            ops.conv_s2_wgrad(dpre, x, _g(L.W))
+            if i > 0:
+                wpt = ws.get(f"enc.wpt{i}", (4, Ci, 4 * Co))
+                ops.pack_conv_weight(L.W, wpt, transposed=True)  # Conv2d weight read as its adjoint
+                dx = ws.get(f"enc.dy{i - 1}", x.shape)
+                ops.convT_s2_fwd(dpre, wpt, dx, Ci=Co, Co=Ci)
+                dy = dx
+
+
+class ConvDecoderEngine:
+    def __init__(self, lin: PLin, layers: List[PConvLayer], ws: Workspace, minres=4):
+        self.lin, self.L, self.ws, self.minres = lin, layers, ws, minres
+
+    def forward(self, x1, x2):
+        """feat = [x1|x2] rows -> mean image [R, 64, 64, 3] (+0.5 folded into the last layer)."""
+        ws = self.ws
+        R = x1.shape[0]
+        E = self.lin.W.shape[0]
+        mr = self.minres
+        C0 = E // (mr * mr)
+        h0 = ws.get("dec.h0", (R, mr, mr, C0))
+        ops.gemm(x1, self.lin.W, h0.view(R, E), A2=x2, bias=self.lin.b)
+        self._x = (x1, x2)
+        self._acts = []
+        x, H = h0, mr
+        for i, L in enumerate(self.L):
+            Ci, Co = L.W.shape[0], L.W.shape[1]
+            wpt = ws.get(f"dec.wpt{i}", (4, Co, 4 * Ci))
+            ops.pack_conv_weight(L.W, wpt, transposed=True)
+            OH = 2 * H
+            if L.g is not None:
+                pre = ws.get(f"dec.pre{i}", (R, OH, OH, Co))
+                ops.convT_s2_fwd(x, wpt, pre, Ci=Ci, Co=Co)
+                rows = R * OH * OH
+                mean, rstd = ws.get(f"dec.m{i}", (rows,)), ws.get(f"dec.r{i}", (rows,))
+                y = ws.get(f"dec.y{i}", (R, OH, OH, Co))
+                ops.ln_act_fwd(pre.view(rows, Co), L.g, L.b, y.view(rows, Co), mean, rstd, act=True)
+                self._acts.append((x, pre, mean, rstd, y))
+            else:
+                y = ws.get("dec.recon", (R, OH, OH, Co))
+                ops.convT_s2_fwd(x, wpt, y, Ci=Ci, Co=Co, bias=L.bias, out_add=0.5)
+                self._acts.append((x, None, None, None, y))
+            x, H = y, OH
+        return x
+
+    def backward(self, drecon, dx1, dx2, *, acc_dx=False):
+        ws = self.ws
+        dy = drecon
+        for i in reversed(range(len(self.L))):
+            L = self.L[i]
+            x, pre, mean, rstd, y = self._acts[i]
+            Ci, Co = L.W.shape[0], L.W.shape[1]
+            R, OH = y.shape[0], y.shape[1]
+            rows = R * OH * OH
+            if L.g is not None:
+                dpre = ws.get(f"dec.dpre{i}", pre.shape)
+                ops.ln_act_bwd(dy.view(rows, Co), pre.view(rows, Co), L.g, L.b, mean, rstd, dpre.view(rows, Co),
+                               _g(L.g), _g(L.b), act=True)
+            else:
+                dpre = dy
+                if L.bias is not None:
+                    ops.colsum(dpre.view(rows, Co), _g(L.bias), accumulate=True)
+            ops.conv_s2_wgrad(x, dpre, _g(L.W))  # coarse = layer input, fine = output gradient
+            wp = ws.get(f"dec.wp{i}", (Ci, 16 * Co))
+            ops.pack_conv_weight(L.W, wp, transposed=False)  # ConvTranspose2d weight read as its adjoint
+            dx = ws.get(f"dec.dx{i}", x.shape)
+            ops.conv_s2_fwd(dpre, wp, dx, Ci=Co, Co=Ci)
+            dy = dx
+        R = dy.shape[0]
+        E = self.lin.W.shape[0]
+        dh0 = dy.view(R, E)
+        x1, x2 = self._x
+        lin_wgrad(self.lin.W, dh0, x1, x2)
+        ops.colsum(dh0, _g(self.lin.b), accumulate=True)
+        k1 = x1.shape[1]
+        ops.gemm(dh0, self.lin.W[:, :k1], dx1, transB=False, accumulate=acc_dx)
+        ops.gemm(dh0, self.lin.W[:, k1:], dx2, transB=False, accumulate=acc_dx)

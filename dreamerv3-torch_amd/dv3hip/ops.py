@@ -598,7 +598,8 @@ def sumsq_accumulate(x, out):
     _call("dv3_sumsq_accumulate", _ptr(x), x.numel(), _ptr(out), _stream())
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, state, *, lr, beta1=0.9, beta2=0.999, eps, clip, weight_decay=0.0):
+def adam_step(param, grad, exp_avg, exp_avg_sq, state, *, lr, beta1=0.9, beta2=0.999, eps, clip, weight_decay=0.0,
+              grad_scale=1.0):
     for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"),
                   (state, "state")):
         _contig(t, nm)
@@ -606,7 +607,8 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, state, *, lr, beta1=0.9, beta2=0
     if grad.numel() != n or exp_avg.numel() != n or exp_avg_sq.numel() != n or state.numel() < 3:
         raise ValueError("size mismatch")
     _call("dv3_adam_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, _ptr(state), float(lr),
-          float(beta1), float(beta2), float(eps), float(clip or 0.0), float(weight_decay or 0.0), _stream())
+          float(beta1), float(beta2), float(eps), float(clip or 0.0), float(weight_decay or 0.0), float(grad_scale),
+          _stream())
 
 
 def axpby(x, y, a, b):
@@ -620,3 +622,45 @@ def axpby(x, y, a, b):
 def rng_advance(rng_state, increment):
     _contig(rng_state, "rng_state", torch.int64)
     _call("dv3_rng_advance", _ptr(rng_state), int(increment), _stream())
+
+
+def fill_normal(out, rng_state):
+    _contig(out, "out"), _contig(rng_state, "rng_state", torch.int64)
+    _call("dv3_fill_normal", _ptr(out), out.numel(), _ptr(rng_state), _stream())
+    return out
+
+
+def dot_accumulate(x, out, *, w=None, clip_min=None, scale=1.0):
+    """out[0] += scale * sum(max(x, clip_min) * w)."""
+    _contig(x, "x"), _contig(out, "out")
+    if w is not None:
+        _contig(w, "w")
+        if w.numel() != x.numel():
+            raise ValueError("w size mismatch")
+    _call("dv3_dot_accumulate", _ptr(x), _ptr(w), x.numel(), _ptr(out), int(clip_min is not None),
+          float(clip_min or 0.0), float(scale), _stream())
+
+
+def actor_loss(target, value, weights, entropy, ema_vals, loss_out, dent, *, dtarget=None, logp=None, dlogp=None,
+               entropy_coef, reinforce):
+    H = value.shape[0]
+    N = value.numel() // H
+    for t, nm, n in ((target, "target", (H - 1) * N), (value, "value", H * N), (weights, "weights", H * N),
+                     (entropy, "entropy", H * N), (dent, "dent", H * N), (ema_vals, "ema_vals", 2),
+                     (loss_out, "loss_out", None), (dtarget, "dtarget", (H - 1) * N), (logp, "logp", H * N),
+                     (dlogp, "dlogp", H * N)):
+        if t is None:
+            continue
+        _contig(t, nm)
+        if n is not None and t.numel() != n:
+            raise ValueError(f"{nm} size mismatch")
+    _call("dv3_actor_loss", _ptr(target), _ptr(value), _ptr(weights), _ptr(entropy), _ptr(logp), _ptr(ema_vals),
+          _ptr(loss_out), _ptr(dtarget), _ptr(dlogp), _ptr(dent), H, N, float(entropy_coef), int(reinforce), _stream())
+
+
+def scale_neg(w, out, s):
+    _contig(w, "w"), _contig(out, "out")
+    if w.numel() != out.numel():
+        raise ValueError("size mismatch")
+    _call("dv3_scale_neg", _ptr(w), _ptr(out), w.numel(), float(s), _stream())
+    return out

@@ -1,0 +1,88 @@
+"""Flat fp32 parameter / gradient buckets -- one per optimizer (model, actor, value).
+
+Every nn.Parameter of a group becomes a view into one contiguous buffer, its .grad a view into a
+second one.  That makes (a) the optimizer step three kernel launches regardless of the number of
+tensors (tools.py:760-776 in the reference walks them one by one), and (b) the data-parallel
+gradient exchange ONE all-reduce per optimizer on the flat gradient -- the RCCL-over-xGMI collective
+SURVEY.md §5.8 asks for, inserted between backward (tools.py:765) and clipping (tools.py:768).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+_ALIGN = 4  # floats: keep every tensor 16-byte aligned inside the bucket
+
+
+class ParamBucket:
+    def __init__(self, name: str, params: Iterable[torch.nn.Parameter]):
+        self.name = name
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        self.flat = None
+        self._layout = None
+
+    # ------------------------------------------------------------------------------------------
+    def _needs_build(self) -> bool:
+        if self.flat is None:
+            return True
+        base, end = self.flat.data_ptr(), self.flat.data_ptr() + self.flat.numel() * 4
+        for p, (off, n) in zip(self.params, self._layout):
+            if p.data_ptr() != base + off * 4 or p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + off * 4:
+                return True
+        return False
+
+    def ensure(self):
+        """(Re)flatten if any parameter no longer lives in the bucket (e.g. after Module.to())."""
+        if not self._needs_build():
+            return self
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError(f"ParamBucket {self.name}: parameters must live on the GPU (got {dev}); "
+                               "the MI355X hot path has no CPU implementation")
+        layout, total = [], 0
+        for p in self.params:
+            n = p.numel()
+            layout.append((total, n))
+            total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        old_m = getattr(self, "exp_avg", None)
+        for p, (off, n) in zip(self.params, layout):
+            flat[off:off + n].copy_(p.data.reshape(-1).to(torch.float32))
+            p.data = flat[off:off + n].view(p.shape)
+            p.grad = grad[off:off + n].view(p.shape)
+        self.flat, self.grad, self._layout = flat, grad, layout
+        if old_m is None or old_m.numel() != total:
+            self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.state = torch.zeros(4, dtype=torch.float32, device=dev)  # step, sumsq, last norm, spare
+        return self
+
+    def numel(self) -> int:
+        return sum(n for _, n in self._layout)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    # ------------------------------------------------------------------------------------------
+    def allreduce(self) -> float:
+        """Sum gradients over ranks (RCCL when the process group is NCCL); returns the scale (1/world)
+        the optimizer must apply.  No-op on a single rank."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+            return 1.0 / dist.get_world_size()
+        return 1.0
+
+    def step(self, *, lr, eps, clip, weight_decay=0.0, grad_scale=1.0):
+        """clip_grad_norm_ + Adam on the whole bucket; the pre-clip norm lands in state[2]."""
+        ops.sumsq_accumulate(self.grad, self.state[1:2])
+        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.state, lr=lr, eps=eps, clip=clip,
+                      weight_decay=weight_decay, grad_scale=grad_scale)
+
+    @property
+    def grad_norm(self) -> torch.Tensor:
+        return self.state[2]

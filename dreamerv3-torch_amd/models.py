@@ -1,0 +1,602 @@
+"""MI355X-native `models` module: RewardEMA, WorldModel, ImagBehavior with the reference's surface.
+
+`WorldModel._train(data)` and `ImagBehavior._train(start, objective)` are the hot path
+(models.py:108-171, 327-446 in the reference).  Here each is one explicit forward + hand-derived
+backward over libdv3hip kernels (dv3hip.engine), gradients landing in flat per-optimizer buckets,
+followed by one all-reduce (data parallel) and one fused clip+Adam launch per optimizer.  There
+is no autograd graph, no host synchronisation and no allocation in steady state.
+
+Row order: activations are time-major inside (row t*B+b); dict entries handed back to callers are
+[B,T,...] views.  Metrics are device scalars wrapped so that float()/np.mean() work lazily.
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import torch
+from torch import nn
+
+import networks
+import tools
+from dv3hip import engine as E
+from dv3hip import ops
+from dv3hip.params import ParamBucket
+
+to_np = lambda x: x.detach().cpu().numpy()
+
+
+class DeviceScalar:
+    """A metric that stays on the GPU until somebody looks at it (one D2H copy at log time instead of a
+    sync per update)."""
+
+    __slots__ = ("_t",)
+
+    def __init__(self, t):
+        self._t = t
+
+    def __float__(self):
+        return float(self._t.item())
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._t.detach().cpu().numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def item(self):
+        return self._t.item()
+
+    def __repr__(self):
+        return f"DeviceScalar({float(self):.6g})"
+
+
+def _wrap(metrics):
+    return {k: (DeviceScalar(v.clone()) if isinstance(v, torch.Tensor) else v) for k, v in metrics.items()}
+
+
+class RewardEMA:
+    """models.py:11-26: EMA of the 5% / 95% quantiles of the lambda-returns."""
+
+    def __init__(self, device, alpha=1e-2):
+        self.device, self.alpha = device, alpha
+        self.range = torch.tensor([0.05, 0.95], device=device)
+
+    def quantiles(self, x):
+        flat = torch.sort(torch.flatten(x.detach()))[0]
+        n = flat.numel()
+        out = []
+        for q in (0.05, 0.95):
+            pos = q * (n - 1)
+            lo, hi = int(np.floor(pos)), int(np.ceil(pos))
+            out.append(flat[lo] + (flat[hi] - flat[lo]) * (pos - lo))
+        return torch.stack(out)
+
+    def __call__(self, x, ema_vals):
+        ops.axpby(self.quantiles(x).contiguous(), ema_vals, self.alpha, 1.0 - self.alpha)
+        scale = torch.clip(ema_vals[1] - ema_vals[0], min=1.0)
+        return ema_vals[0].detach(), scale.detach()
+
+
+class WorldModel(nn.Module):
+    def __init__(self, obs_space, act_space, step, config):
+        super().__init__()
+        self._step = step
+        if config.precision != 32:
+            raise NotImplementedError("the path is fp32 (configs.yaml:18, parity at 1e-4)")
+        self._config = config
+        shapes = {k: tuple(v.shape) for k, v in obs_space.spaces.items()}
+        self.encoder = networks.MultiEncoder(shapes, **config.encoder)
+        self.embed_size = self.encoder.outdim
+        self.dynamics = networks.RSSM(config.dyn_stoch, config.dyn_deter, config.dyn_hidden, config.dyn_rec_depth,
+                                      config.dyn_discrete, config.act, config.norm, config.dyn_mean_act,
+                                      config.dyn_std_act, config.dyn_min_std, config.unimix_ratio, config.initial,
+                                      config.num_actions, self.embed_size, config.device)
+        self.heads = nn.ModuleDict()
+        feat_size = config.dyn_stoch * config.dyn_discrete + config.dyn_deter
+        self.heads["decoder"] = networks.MultiDecoder(feat_size, shapes, **config.decoder)
+        self.heads["reward"] = networks.MLP(
+            feat_size, (255,) if config.reward_head["dist"] == "symlog_disc" else (), config.reward_head["layers"],
+            config.units, config.act, config.norm, dist=config.reward_head["dist"],
+            outscale=config.reward_head["outscale"], device=config.device, name="Reward")
+        self.heads["cont"] = networks.MLP(
+            feat_size, (), config.cont_head["layers"], config.units, config.act, config.norm, dist="binary",
+            outscale=config.cont_head["outscale"], device=config.device, name="Cont")
+        if config.reward_head["dist"] != "symlog_disc":
+            raise NotImplementedError("reward head: symlog_disc only")
+        for name in config.grad_heads:
+            assert name in self.heads, name
+        self._model_opt = tools.Optimizer("model", list(self.parameters()), config.model_lr, config.opt_eps,
+                                          config.grad_clip, config.weight_decay, opt=config.opt, use_amp=False)
+        self._scales = dict(reward=config.reward_head["loss_scale"], cont=config.cont_head["loss_scale"])
+
+    # ------------------------------------------------------------------------------------------
+    def preprocess(self, obs):
+        """models.py:174-190 (public API: float32 tensors on the device, image/255, cont)."""
+        dev = self._config.device
+        obs = {k: torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).to(dev).to(torch.float32)
+               for k, v in obs.items()}
+        obs["image"] = obs["image"] / 255.0
+        if "discount" in obs:
+            obs["discount"] = (obs["discount"] * self._config.discount).unsqueeze(-1)
+        assert "is_first" in obs and "is_terminal" in obs
+        obs["cont"] = (1.0 - obs["is_terminal"]).unsqueeze(-1)
+        return obs
+
+    def _stage(self, data):
+        """Host batch -> device, images kept as uint8 (12.6 MB instead of the reference's 50 MB of f32,
+        models.py:176-180); normalisation happens inside the kernels."""
+        dev = torch.device(self._config.device)
+        out = {}
+        for k, v in data.items():
+            if isinstance(v, torch.Tensor):
+                t = v.to(dev, non_blocking=True)
+            else:
+                t = torch.from_numpy(np.ascontiguousarray(v)).to(dev, non_blocking=True)
+            if k == "image":
+                if t.dtype != torch.uint8:
+                    t = torch.clamp(torch.round(t.to(torch.float32)), 0, 255).to(torch.uint8)
+                out[k] = t.contiguous()
+            else:
+                out[k] = t.to(torch.float32).contiguous()
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def _train(self, data, noise=None):
+        """One world-model update.  `noise` (tests): dict(q_prior, q_post) of [T,B,S,D] Exp(1) draws."""
+        cfg = self._config
+        st = self._stage(data)
+        B, T = st["action"].shape[0], st["action"].shape[1]
+        TB = B * T
+        dev = st["action"].device
+        dyn = self.dynamics
+        rssm = dyn.engine
+        ws = rssm.ws
+        S, D, SD, De = dyn._stoch, dyn._discrete, dyn._stoch * dyn._discrete, dyn._deter
+        nz = noise or {}
+        rng = dyn._rng()
+        self._model_opt.begin()
+
+        # ---- inputs to time-major
+        act_tm = ops.transpose01(st["action"], ws.get("wm.action", (T, B, st["action"].shape[2])))
+        first_tm = ops.transpose01(st["is_first"], ws.get("wm.first", (T, B)))
+        reward_tm = ops.transpose01(st["reward"], ws.get("wm.reward", (T, B)))
+        cont_tm = ws.get("wm.cont", (T, B))
+        ops.transpose01(st["is_terminal"], cont_tm)
+        ops.axpby(ws.get("wm.ones", (T, B)).fill_(1.0), cont_tm, 1.0, -1.0)  # cont = 1 - is_terminal
+
+        # ---- encoder
+        enc = self.encoder
+        if enc.cnn_shapes and enc.mlp_shapes:
+            raise NotImplementedError("mixed image + vector encoders")
+        if enc.cnn_shapes:
+            enc_eng = enc._cnn.engine
+            embed = enc_eng.forward(st["image"], (B, T))
+        else:
+            keys = list(enc.mlp_shapes)
+            widths = [int(np.prod(enc.mlp_shapes[k])) for k in keys]
+            xin = ws.get("wm.mlp_in", (TB, sum(widths)))
+            raw = ws.get("wm.mlp_raw", (TB, sum(widths)))
+            off = 0
+            for k, w in zip(keys, widths):
+                tmp = ops.transpose01(st[k].reshape(B, T, w), ws.get(f"wm.key.{k}", (T, B, w)))
+                raw[:, off:off + w] = tmp.view(TB, w)
+                off += w
+            ops.symlog(raw, xin)
+            enc_eng = enc._mlp.engine_for(".wm")
+            embed, _, _ = enc_eng.forward(xin)
+            self._enc_in = xin
+        E_ = embed.shape[1]
+
+        # ---- RSSM scan
+        out = rssm.observe_fwd(embed.view(T, B, E_), act_tm, first_tm, q_prior=nz.get("q_prior"),
+                               q_post=nz.get("q_post"), rng=rng)
+        ps, dt = out["post_stoch"].view(TB, SD), out["deter"].view(TB, De)
+        kl = ws.get("wm.kl", (T, B))
+        ent_p, ent_q = ws.get("wm.ent_post", (T, B)), ws.get("wm.ent_prior", (T, B))
+        ops.kl_fwd(out["post_logit"], out["prior_logit"], kl, ent_p, ent_q, unimix=dyn._unimix_ratio)
+
+        # ---- heads, losses and their upstream gradients (loss = mean over B*T of the per-row sum)
+        up = 1.0 / TB
+        acc = ws.zeros("wm.acc", (8,))  # [model_loss, image, reward, cont, kl, ent_prior, ent_post, vector]
+        gs, gd = ws.get("wm.gs", (T, B, SD)), ws.get("wm.gd", (T, B, De))
+        wrote = False
+        dec = self.heads["decoder"]
+        grad_heads = cfg.grad_heads
+        if dec.cnn_shapes:
+            dec_eng = dec._cnn.engine
+            recon = dec_eng.forward(ps, dt)
+            limg = ws.get("wm.loss_img", (TB,))
+            drecon = ws.get("wm.drecon", recon.shape)
+            ops.mse_image(recon, st["image"], limg, drecon, upstream=up, perm=(B, T))
+            ops.dot_accumulate(limg, acc[1:2], scale=up)
+            dec_eng.backward(drecon, gs.view(TB, SD), gd.view(TB, De), acc_dx=False)
+            wrote = True
+            if "decoder" not in grad_heads:
+                gs.zero_(), gd.zero_()
+        if dec.mlp_shapes:
+            mdec = dec._mlp
+            deng = mdec.engine_for(".wm")
+            h, _, _ = deng.forward(ps, dt)
+            dh = ws.zeros("wm.dec_dh", h.shape)
+            for k, shp in dec.mlp_shapes.items():
+                lin = mdec.mean_layer[k]
+                w = int(np.prod(shp))
+                mode = ws.get(f"wm.dec.{k}", (TB, w))
+                ops.gemm(h, lin.weight, mode, bias=lin.bias)
+                tgt = ops.transpose01(st[k].reshape(B, T, w), ws.get(f"wm.key.{k}", (T, B, w))).view(TB, w)
+                lk = ws.get(f"wm.loss.{k}", (TB,))
+                dmode = ws.get(f"wm.dmode.{k}", (TB, w))
+                ops.symlog_mse(mode, tgt, lk, dmode, upstream=up)
+                ops.dot_accumulate(lk, acc[7:8], scale=up)
+                ops.gemm(dmode, lin.weight, dh, transB=False, accumulate=True)
+                E.lin_wgrad(lin.weight, dmode, h)
+                ops.colsum(dmode, lin.bias.grad, accumulate=True)
+            gh = "decoder" in grad_heads
+            deng.backward(ps, dt, slice(0, TB), wgrad=True, dh=dh, dx1=gs.view(TB, SD) if gh else None,
+                          dx2=gd.view(TB, De) if gh else None, acc_dx=wrote)
+            wrote = wrote or gh
+        if not wrote:
+            gs.zero_(), gd.zero_()
+        # reward head: -log_prob(reward) under the 255-bucket two-hot head
+        reng = self.heads["reward"].engine_for(".wm")
+        _, r_logits, _ = reng.forward(ps, dt)
+        lp_r = ws.get("wm.lp_r", (TB,))
+        ops.disc_logprob_fwd(r_logits, reward_tm.view(TB), lp_r)
+        ops.dot_accumulate(lp_r, acc[2:3], scale=-up)
+        dr = ws.get("wm.dr_logits", r_logits.shape)
+        up_r = ws.get("wm.up_r", (TB,)).fill_(-up * self._scales["reward"])
+        ops.disc_logprob_bwd(r_logits, reward_tm.view(TB), up_r, dr)
+        g_r = "reward" in grad_heads
+        reng.backward(ps, dt, slice(0, TB), dout=dr, wgrad=True, dx1=gs.view(TB, SD) if g_r else None,
+                      dx2=gd.view(TB, De) if g_r else None, acc_dx=True)
+        # continue head
+        ceng = self.heads["cont"].engine_for(".wm")
+        _, c_logit, _ = ceng.forward(ps, dt)
+        lp_c = ws.get("wm.lp_c", (TB,))
+        ops.bernoulli_logprob_fwd(c_logit.view(TB), cont_tm.view(TB), lp_c)
+        ops.dot_accumulate(lp_c, acc[3:4], scale=-up)
+        dc = ws.get("wm.dc_logit", (TB, 1))
+        up_c = ws.get("wm.up_c", (TB,)).fill_(-up * self._scales["cont"])
+        ops.bernoulli_logprob_bwd(c_logit.view(TB), cont_tm.view(TB), up_c, dc.view(TB))
+        g_c = "cont" in grad_heads
+        ceng.backward(ps, dt, slice(0, TB), dout=dc, wgrad=True, dx1=gs.view(TB, SD) if g_c else None,
+                      dx2=gd.view(TB, De) if g_c else None, acc_dx=True)
+        # KL
+        dpl, dql = ws.get("wm.dpost_logit", (T, B, S, D)), ws.get("wm.dprior_logit", (T, B, S, D))
+        ops.kl_bwd(out["post_logit"], out["prior_logit"], kl, dpl, dql, unimix=dyn._unimix_ratio, free=cfg.kl_free,
+                   dyn_scale=cfg.dyn_scale, rep_scale=cfg.rep_scale, upstream=up)
+        ops.dot_accumulate(kl.view(TB), acc[4:5], clip_min=cfg.kl_free, scale=up)  # mean of the clipped KL
+        # ---- backward through the scan and the encoder
+        dembed = ws.get("wm.dembed", (T, B, E_))
+        rssm.observe_bwd(dpl, dql, gs, gd, dembed)
+        if enc.cnn_shapes:
+            enc_eng.backward(dembed.view(TB, E_))
+        else:
+            enc_eng.backward(self._enc_in, None, slice(0, TB), wgrad=True, dh=dembed.view(TB, E_))
+
+        # ---- scalar loss + optimizer
+        loss = ws.get("wm.loss", (1,))
+        ops.dot_accumulate(kl.view(TB), ws.zeros("wm.kl_mean", (1,)), scale=up)
+        ops.dot_accumulate(ent_q.view(TB), acc[5:6], scale=up)
+        ops.dot_accumulate(ent_p.view(TB), acc[6:7], scale=up)
+        # model_loss = image + vector + reward*scale + cont*scale + (dyn_scale + rep_scale) * clipped KL
+        loss.copy_(acc[1:2] + acc[7:8] + self._scales["reward"] * acc[2:3] + self._scales["cont"] * acc[3:4]
+                   + (cfg.dyn_scale + cfg.rep_scale) * acc[4:5])
+        metrics = self._model_opt.finish(loss[0])
+        if dec.cnn_shapes:
+            metrics["image_loss"] = acc[1]
+        for k in dec.mlp_shapes:
+            metrics[f"{k}_loss"] = acc[7]
+        metrics.update(reward_loss=acc[2], cont_loss=acc[3], kl_free=cfg.kl_free, dyn_scale=cfg.dyn_scale,
+                       rep_scale=cfg.rep_scale, dyn_loss=acc[4], rep_loss=acc[4], kl=ws.get("wm.kl_mean", (1,))[0],
+                       prior_ent=acc[5], post_ent=acc[6])
+        bt = lambda x: x.transpose(0, 1)
+        post = {"stoch": bt(out["post_stoch"]), "deter": bt(out["deter"]), "logit": bt(out["post_logit"])}
+        self._last = dict(out=out, embed=embed.view(T, B, E_), kl=kl, ent_post=ent_p, action_tm=out["action"])
+        context = _LazyContext(self, post)
+        return post, context, _wrap(metrics)
+
+    def video_pred(self, data):
+        """models.py:192-213 (forward-only open-loop prediction for logging)."""
+        data = self.preprocess(data)
+        embed = self.encoder(data)
+        states, _ = self.dynamics.observe(embed[:6, :5], data["action"][:6, :5], data["is_first"][:6, :5])
+        recon = self.heads["decoder"](self.dynamics.get_feat(states))["image"].mode()[:6]
+        init = {k: v[:, -1] for k, v in states.items()}
+        prior = self.dynamics.imagine_with_action(data["action"][:6, 5:], init)
+        openl = self.heads["decoder"](self.dynamics.get_feat(prior))["image"].mode()
+        model = torch.cat([recon[:, :5], openl], 1)
+        truth = data["image"][:6]
+        error = (model - truth + 1.0) / 2.0
+        return torch.cat([truth, model, error], 2)
+
+
+class _LazyContext(dict):
+    """`context` of WorldModel._train (embed, feat, kl, postent), built only if somebody reads it."""
+
+    def __init__(self, wm, post):
+        super().__init__()
+        self._wm, self._post = wm, post
+
+    def __missing__(self, key):
+        last = self._wm._last
+        bt = lambda x: x.transpose(0, 1)
+        if key == "embed":
+            v = bt(last["embed"])
+        elif key == "feat":
+            v = self._wm.dynamics.get_feat(self._post)
+        elif key == "kl":
+            v = bt(last["kl"])
+        elif key == "postent":
+            v = bt(last["ent_post"])
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
+
+
+class ImagBehavior(nn.Module):
+    def __init__(self, config, world_model, future_predictor=None):
+        super().__init__()
+        self._config = config
+        self._world_model = world_model
+        feat_size = config.dyn_stoch * config.dyn_discrete + config.dyn_deter
+        self.actor = networks.MLP(
+            feat_size, (config.num_actions,), config.actor["layers"], config.units, config.act, config.norm,
+            config.actor["dist"], config.actor["std"], config.actor["min_std"], config.actor["max_std"], absmax=1.0,
+            temp=config.actor["temp"], unimix_ratio=config.actor["unimix_ratio"], outscale=config.actor["outscale"],
+            name="Actor")
+        self.value = networks.MLP(
+            feat_size, (255,) if config.critic["dist"] == "symlog_disc" else (), config.critic["layers"], config.units,
+            config.act, config.norm, config.critic["dist"], outscale=config.critic["outscale"], device=config.device,
+            name="Value")
+        if config.critic["dist"] != "symlog_disc" or config.actor["dist"] not in ("normal", "onehot"):
+            raise NotImplementedError("critic symlog_disc; actor normal|onehot")
+        if config.imag_gradient not in ("dynamics", "reinforce"):
+            raise NotImplementedError(config.imag_gradient)
+        if config.critic["slow_target"]:
+            self._slow_value = copy.deepcopy(self.value)
+            self._updates = 0
+        kw = dict(wd=config.weight_decay, opt=config.opt, use_amp=False)
+        self._actor_opt = tools.Optimizer("actor", list(self.actor.parameters()), config.actor["lr"],
+                                          config.actor["eps"], config.actor["grad_clip"], **kw)
+        self._value_opt = tools.Optimizer("value", list(self.value.parameters()), config.critic["lr"],
+                                          config.critic["eps"], config.critic["grad_clip"], **kw)
+        if self._config.reward_EMA:
+            self.register_buffer("ema_vals", torch.zeros((2,), device=self._config.device))
+            self.reward_ema = RewardEMA(device=self._config.device)
+
+    # ------------------------------------------------------------------------------------------
+    def _update_slow_target(self):
+        """models.py:683-689 on the flat buckets: slow = mix*value + (1-mix)*slow."""
+        if self._config.critic["slow_target"]:
+            if self._updates % self._config.critic["slow_target_update"] == 0:
+                mix = self._config.critic["slow_target_fraction"]
+                vb = self._value_opt.bucket.ensure()
+                sb = self._slow_bucket()
+                ops.axpby(vb.flat, sb.flat, mix, 1.0 - mix)
+            self._updates += 1
+
+    def _slow_bucket(self):
+        b = getattr(self, "_slow_b", None)
+        if b is None:
+            b = ParamBucket("slow_value", list(self._slow_value.parameters()))
+            object.__setattr__(self, "_slow_b", b)
+        return b.ensure()
+
+    def _flat_start(self, start):
+        """start {[B,T,...]} -> ([N,SD], [N,De], [N,SD]) without a copy when it is a time-major view."""
+        dyn = self._world_model.dynamics
+        SD = dyn._stoch * dyn._discrete
+        outs = []
+        for k, w in (("stoch", SD), ("deter", dyn._deter), ("logit", SD)):
+            v = start[k]
+            tm = v.transpose(0, 1)
+            src = tm if tm.is_contiguous() else v.contiguous()
+            outs.append(src.reshape(-1, w))
+        return outs
+
+    def _imagine(self, start, policy, horizon, first_action=None, noise=None):
+        """models.py:448-548 (forward only): returns feats [H,N,F], states {[H,N,...]}, actions [H,N,A].
+        Row order follows the memory order of `start` (time-major when it comes from WorldModel._train)."""
+        self._imagine_fwd(start, horizon, noise)
+        st = self._im
+        S, D = self._world_model.dynamics._stoch, self._world_model.dynamics._discrete
+        H, N = st["H"], st["N"]
+        states = {"stoch": st["stoch"].view(H, N, S, D).clone(), "deter": st["deter"].clone(),
+                  "logit": st["logit"].view(H, N, S, D).clone()}
+        feats = torch.cat([st["stoch"], st["deter"]], -1)
+        return feats, states, st["action"].clone()
+
+    def _imagine_fwd(self, start, horizon, noise=None):
+        cfg = self._config
+        dyn = self._world_model.dynamics
+        rssm = dyn.engine
+        ws = rssm.ws
+        S, D, SD, De, Hd, A = dyn._stoch, dyn._discrete, dyn._stoch * dyn._discrete, dyn._deter, dyn._hidden, \
+            dyn._num_actions
+        s0, d0, l0 = self._flat_start(start)
+        N, H = s0.shape[0], horizon
+        nz = noise or {}
+        rng = dyn._rng()
+        g = ws.get
+        stoch, deter, logit = g("im.stoch", (H, N, SD)), g("im.deter", (H, N, De)), g("im.logit", (H, N, SD))
+        stoch[0].copy_(s0), deter[0].copy_(d0), logit[0].copy_(l0)
+        action, ent = g("im.action", (H, N, A)), g("im.ent", (H, N))
+        eps = g("im.eps", (H, N, A))
+        step = dict(x1pre=g("im.x1pre", (H, N, Hd)), m1=g("im.m1", (H, N)), r1=g("im.r1", (H, N)),
+                    x1=g("im.x1", (H, N, Hd)), gpre=g("im.gpre", (H, N, 3 * De)), mg=g("im.mg", (H, N)),
+                    rg=g("im.rg", (H, N)), x2pre=g("im.x2pre", (H, N, Hd)), m2=g("im.m2", (H, N)),
+                    r2=g("im.r2", (H, N)), x2=g("im.x2", (H, N, Hd)))
+        actor_eng = self.actor.engine_for(".imag")
+        normal = cfg.actor["dist"] == "normal"
+        q_img, act_noise = nz.get("q_img"), nz.get("act")
+        for t in range(H):
+            _, mean_raw, std_raw = actor_eng.forward(stoch[t], deter[t], row0=t * N, total=H * N)
+            if normal:
+                if act_noise is not None:
+                    eps[t].copy_(act_noise[t])
+                else:
+                    ops.fill_normal(eps[t], rng)
+                    ops.rng_advance(rng, N * A // 4 + 1)
+                ops.actor_normal_fwd(mean_raw, std_raw, eps[t], action[t], ent[t], min_std=cfg.actor["min_std"],
+                                     max_std=cfg.actor["max_std"])
+            else:
+                ops.onehot_sample(mean_raw, action[t], noise=None if act_noise is None else act_noise[t],
+                                  rng_state=rng, unimix=cfg.actor["unimix_ratio"])
+                if act_noise is None:
+                    ops.rng_advance(rng, N * A // 4 + 1)
+                ops.onehot_ent_logp_fwd(mean_raw, None, ent[t], None, unimix=cfg.actor["unimix_ratio"])
+            if t < H - 1:
+                b = {k: v[t] for k, v in step.items()}
+                b.update(deter=deter[t + 1], logit=logit[t + 1].view(N, S, D), stoch=stoch[t + 1].view(N, S, D))
+                rssm.img_step_fwd(stoch[t], deter[t], action[t], b, noise=None if q_img is None else q_img[t], rng=rng)
+        self._im = dict(H=H, N=N, stoch=stoch, deter=deter, logit=logit, action=action, ent=ent, eps=eps, step=step,
+                        actor=actor_eng)
+
+    # ------------------------------------------------------------------------------------------
+    def _train(self, start, objective=None, noise=None):
+        """One actor + critic update (models.py:327-446).  `objective` is accepted for signature
+        compatibility; the reward is the world model's reward head on the imagined states, which is what
+        dreamer.py passes (dreamer.py:196-199)."""
+        cfg = self._config
+        wm = self._world_model
+        dyn = wm.dynamics
+        rssm = dyn.engine
+        ws = rssm.ws
+        S, D, SD, De, A = dyn._stoch, dyn._discrete, dyn._stoch * dyn._discrete, dyn._deter, dyn._num_actions
+        H = cfg.imag_horizon
+        self._update_slow_target()
+        self._actor_opt.begin()
+        self._value_opt.begin()
+        self._imagine_fwd(start, H, noise)
+        im = self._im
+        N = im["N"]
+        HN, H1N = H * N, (H - 1) * N
+        stoch, deter, action, ent = im["stoch"], im["deter"], im["action"], im["ent"]
+        fs, fd = stoch.view(HN, SD), deter.view(HN, De)
+        g = ws.get
+        # ---- heads over all H*N imagined states
+        reng = wm.heads["reward"].engine_for(".imag")
+        _, r_logits, _ = reng.forward(fs, fd)
+        reward = ops.disc_mode_fwd(r_logits, g("bh.reward", (H, N)))
+        ceng = wm.heads["cont"].engine_for(".imag")
+        _, c_logit, _ = ceng.forward(fs, fd)
+        veng = self.value.engine_for(".imag")
+        _, v_logits, _ = veng.forward(fs, fd)
+        value = ops.disc_mode_fwd(v_logits, g("bh.value", (H, N)))
+        seng = networks.MLP.engine_for(self._slow_value, ".imag")
+        self._slow_bucket()
+        _, s_logits, _ = seng.forward(fs[:H1N], fd[:H1N])
+        slow = ops.disc_mode_fwd(s_logits, g("bh.slow", (H - 1, N)))
+        target, weights, disc = g("bh.target", (H - 1, N)), g("bh.weights", (H, N)), g("bh.disc", (H, N))
+        ops.lambda_return_fwd(reward, value, c_logit.view(H, N), target, weights, disc, gamma=cfg.discount,
+                              lam=cfg.discount_lambda)
+        # ---- actor loss (+ gradients w.r.t. target / entropy / log-prob)
+        if cfg.reward_EMA:
+            self.reward_ema(target, self.ema_vals)
+            ema = self.ema_vals
+        else:
+            ema = g("bh.ema_fixed", (2,))
+            ema[0], ema[1] = 0.0, 1.0
+        acc = ws.zeros("bh.acc", (4,))  # [actor_loss, value_loss, entropy mean, spare]
+        dent = g("bh.dent", (H, N))
+        reinforce = cfg.imag_gradient == "reinforce"
+        normal = cfg.actor["dist"] == "normal"
+        a_mean, a_std = self._actor_heads(im)
+        if reinforce:
+            logp = g("bh.logp", (H, N))
+            if normal:
+                ops.actor_normal_logp(a_mean, a_std, action.view(HN, A), logp.view(HN), min_std=cfg.actor["min_std"],
+                                      max_std=cfg.actor["max_std"])
+            else:
+                ops.onehot_ent_logp_fwd(a_mean, action.view(HN, A), None, logp.view(HN),
+                                        unimix=cfg.actor["unimix_ratio"])
+            dlogp = g("bh.dlogp", (H, N))
+            ops.actor_loss(target, value, weights, ent, ema, acc[0:1], dent, logp=logp, dlogp=dlogp,
+                           entropy_coef=cfg.actor["entropy"], reinforce=True)
+        else:
+            dtarget = g("bh.dtarget", (H - 1, N))
+            ops.actor_loss(target, value, weights, ent, ema, acc[0:1], dent, dtarget=dtarget,
+                           entropy_coef=cfg.actor["entropy"], reinforce=False)
+        # ---- dynamics backprop: target -> reward / cont heads -> imagined states -> actions
+        daction = g("bh.daction", (H, N, A))
+        if not reinforce:
+            dreward, dcl = g("bh.dreward", (H, N)), g("bh.dcont", (H, N))
+            ops.lambda_return_bwd(dtarget, value, c_logit.view(H, N), target, dreward, dcl, gamma=cfg.discount,
+                                  lam=cfg.discount_lambda)
+            gs, gd = g("bh.gs", (H, N, SD)), g("bh.gd", (H, N, De))
+            rows = slice(N, HN)  # step 0 is the (detached) start state: no gradient there
+            drl = g("bh.dr_logits", (H1N, 255))
+            ops.disc_mode_bwd(r_logits[rows], dreward.view(HN)[rows], drl)
+            reng.backward(fs[rows], fd[rows], rows, dout=drl, wgrad=False, dx1=gs.view(HN, SD)[rows],
+                          dx2=gd.view(HN, De)[rows])
+            ceng.backward(fs[rows], fd[rows], rows, dout=dcl.view(HN, 1)[rows], wgrad=False,
+                          dx1=gs.view(HN, SD)[rows], dx2=gd.view(HN, De)[rows], acc_dx=True)
+            Hd = dyn._hidden
+            scratch = dict(dlogit=g("bh.s.dlogit", (N, SD)), dx2=g("bh.s.dx2", (N, Hd)), dx2pre=g("bh.s.dx2pre", (N, Hd)),
+                           dgpre=g("bh.s.dgpre", (N, 3 * De)), dx1=g("bh.s.dx1", (N, Hd)),
+                           dx1pre=g("bh.s.dx1pre", (N, Hd)))
+            cs, cd = g("bh.carry_s", (N, SD)), g("bh.carry_d", (N, De))
+            for t in range(H - 1, 0, -1):
+                if t < H - 1:
+                    ops.axpby(cs, gs[t], 1.0, 1.0)
+                    ops.axpby(cd, gd[t], 1.0, 1.0)
+                b = {k: v[t - 1] for k, v in im["step"].items()}
+                b.update(logit=im["logit"][t].view(N, S, D))
+                rssm.img_step_bwd(gs[t], gd[t], deter[t - 1], b, scratch, cs, cd, daction[t - 1])
+        # ---- actor backward over steps 0..H-2 (the last step's action feeds nothing that is used)
+        R = H1N
+        dmean, dstd = g("bh.dmean", (R, A)), g("bh.dstd", (R, A))
+        if normal:
+            ops.actor_normal_bwd(a_mean[:R], a_std[:R], dmean, dstd, eps=im["eps"].view(HN, A)[:R],
+                                 action=action.view(HN, A)[:R], daction=None if reinforce else daction.view(HN, A)[:R],
+                                 dent=dent.view(HN)[:R], dlogp=dlogp.view(HN)[:R] if reinforce else None,
+                                 min_std=cfg.actor["min_std"], max_std=cfg.actor["max_std"])
+        else:
+            if not reinforce:
+                # sampled one-hot action: straight-through gradient of the sample, plus the entropy term
+                ops.onehot_st_bwd(a_mean[:R], daction.view(HN, A)[:R], dmean, unimix=cfg.actor["unimix_ratio"])
+            ops.onehot_ent_logp_bwd(a_mean[:R], action.view(HN, A)[:R], dent.view(HN)[:R],
+                                    dlogp.view(HN)[:R] if reinforce else None, dmean,
+                                    unimix=cfg.actor["unimix_ratio"], accumulate=not reinforce)
+            dstd = None
+        im["actor"].backward(fs[:R], fd[:R], slice(0, R), dout=dmean, dout2=dstd, wgrad=True)
+        # ---- critic: -log_prob(target) - log_prob(slow.mode), weighted by the cumulative discount
+        inv = 1.0 / H1N
+        up_v = ops.scale_neg(weights.view(HN)[:R], g("bh.up_v", (R,)), inv)
+        lp = g("bh.lp_v", (R,))
+        dvl = g("bh.dv_logits", (R, 255))
+        ops.disc_logprob_fwd(v_logits[:R], target.view(R), lp)
+        ops.dot_accumulate(lp, acc[1:2], w=up_v)
+        ops.disc_logprob_bwd(v_logits[:R], target.view(R), up_v, dvl)
+        if cfg.critic["slow_target"]:
+            ops.disc_logprob_fwd(v_logits[:R], slow.view(R), lp)
+            ops.dot_accumulate(lp, acc[1:2], w=up_v)
+            ops.disc_logprob_bwd(v_logits[:R], slow.view(R), up_v, dvl, accumulate=True)
+        veng.backward(fs[:R], fd[:R], slice(0, R), dout=dvl, wgrad=True)
+        # ---- metrics + optimizers
+        ops.dot_accumulate(ent.view(HN), acc[2:3], scale=1.0 / HN)
+        metrics = {}
+        metrics.update(tools.tensorstats(value, "value"))
+        metrics.update(tools.tensorstats(target, "target"))
+        metrics.update(tools.tensorstats(reward, "imag_reward"))
+        if normal:
+            metrics.update(tools.tensorstats(action, "imag_action"))
+        else:
+            metrics.update(tools.tensorstats(torch.argmax(action, dim=-1).float(), "imag_action"))
+        if cfg.reward_EMA:
+            scale = torch.clip(ema[1] - ema[0], min=1.0)
+            metrics.update(tools.tensorstats((target - ema[0]) / scale, "normed_target"))
+            metrics["EMA_005"], metrics["EMA_095"] = ema[0], ema[1]
+        metrics["actor_entropy"] = acc[2]
+        metrics.update(self._actor_opt.finish(acc[0]))
+        metrics.update(self._value_opt.finish(acc[1]))
+        self._last = dict(reward=reward, value=value, target=target, weights=weights, disc=disc, slow=slow)
+        S_, D_ = S, D
+        imag_state = {"stoch": stoch.view(H, N, S_, D_), "deter": deter, "logit": im["logit"].view(H, N, S_, D_)}
+        return None, imag_state, action, weights.view(H, N, 1), _wrap(metrics)
+
+    def _actor_heads(self, im):
+        eng = im["actor"]
+        _, out, out2 = eng._bufs(eng.total)
+        return out, out2

@@ -1,0 +1,479 @@
+"""Hot-path subset of the reference's `tools` module, re-implemented over libdv3hip.
+
+Same names, argument meaning and return shapes as the reference (tools.py) for everything the
+world-model training path touches: the distribution wrappers returned by heads / RSSM.get_dist,
+`lambda_return`, `Optimizer`, `RequiresGrad`, `static_scan`, initialisers and schedules.  The
+reference's host-side I/O helpers (Logger, simulate, replay loading) are out of scope (SURVEY.md
+§2 #11) and are not provided here.
+
+Distribution objects are forward-only views over kernel outputs: training never differentiates
+through them (models.WorldModel._train / ImagBehavior._train run the hand-derived backward in
+dv3hip.engine); acting and logging only need values.
+"""
+from __future__ import annotations
+
+import math
+import re
+
+import numpy as np
+import torch
+from torch import nn
+
+from dv3hip import ops
+from dv3hip.params import ParamBucket
+
+to_np = lambda x: x.detach().cpu().numpy()
+
+
+def _dev_f32(x, device=None):
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(np.asarray(x))
+    if device is not None and x.device != torch.device(device):
+        x = x.to(device)
+    return x.to(torch.float32).contiguous()
+
+
+def symlog(x):  # tools.py:22-23
+    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    return ops.symlog(x.contiguous(), out)
+
+
+def symexp(x):  # tools.py:26-27 (host-side convenience; the kernels fuse it)
+    return torch.sign(x) * (torch.exp(torch.abs(x)) - 1.0)
+
+
+class RequiresGrad:  # tools.py:30-38
+    def __init__(self, model):
+        self._model = model
+
+    def __enter__(self):
+        self._model.requires_grad_(requires_grad=True)
+
+    def __exit__(self, *args):
+        self._model.requires_grad_(requires_grad=False)
+
+
+# ---------------------------------------------------------------------------------------------
+# distributions
+# ---------------------------------------------------------------------------------------------
+class OneHotDist:
+    """tools.py:436-460: one-hot categorical over the last dim with `unimix_ratio` uniform mixing."""
+
+    def __init__(self, logits=None, probs=None, unimix_ratio=0.0, rng=None):
+        if logits is None:
+            raise NotImplementedError("OneHotDist needs logits")
+        self._logits = logits.contiguous()
+        self._unimix = float(unimix_ratio)
+        self._rng = rng
+
+    @property
+    def logits(self):
+        return self._logits
+
+    def mode(self):
+        out = torch.empty_like(self._logits)
+        return ops.onehot_sample(self._logits, out, unimix=self._unimix, mode=True)
+
+    def sample(self, sample_shape=(), seed=None, noise=None):
+        if seed is not None:
+            raise ValueError("need to check")
+        if tuple(sample_shape) != ():
+            raise NotImplementedError("sample_shape")
+        out = torch.empty_like(self._logits)
+        rng = self._rng if noise is None else None
+        if noise is None and rng is None:
+            rng = default_rng(self._logits.device)
+        ops.onehot_sample(self._logits, out, noise=noise, rng_state=rng, unimix=self._unimix)
+        if noise is None:
+            ops.rng_advance(rng, self._logits.numel() // 4 + 1)
+        return out
+
+    def entropy(self):
+        """Entropy per categorical group (callers wrap in Independent to sum over groups)."""
+        ent = torch.empty(self._logits.shape[:-1], device=self._logits.device)
+        ops.onehot_ent_logp_fwd(self._logits, None, ent, None, unimix=self._unimix)
+        return ent
+
+    def log_prob(self, x):
+        lp = torch.empty(self._logits.shape[:-1], device=self._logits.device)
+        ops.onehot_ent_logp_fwd(self._logits, x.contiguous(), None, lp, unimix=self._unimix)
+        return lp
+
+
+class IndependentOneHot:
+    """Independent(OneHotDist, 1), what RSSM.get_dist returns (networks.py:161-166)."""
+
+    def __init__(self, base: OneHotDist):
+        self.base_dist = base
+
+    def sample(self, sample_shape=(), noise=None):
+        return self.base_dist.sample(sample_shape, noise=noise)
+
+    def mode(self):
+        return self.base_dist.mode()
+
+    def entropy(self):
+        return self.base_dist.entropy().sum(-1)
+
+    def log_prob(self, x):
+        return self.base_dist.log_prob(x).sum(-1)
+
+
+class DiscDist:
+    """tools.py:463-517: 255-bucket symlog two-hot head."""
+
+    def __init__(self, logits, low=-20.0, high=20.0, transfwd=None, transbwd=None, device=None):
+        if logits.shape[-1] != 255 or (low, high) != (-20.0, 20.0):
+            raise NotImplementedError("DiscDist kernels are specialised for linspace(-20, 20, 255)")
+        self.logits = logits.contiguous()
+
+    def mean(self):
+        out = torch.empty(self.logits.shape[:-1] + (1,), device=self.logits.device)
+        return ops.disc_mode_fwd(self.logits, out)
+
+    mode = mean
+
+    def log_prob(self, x):
+        x = x.to(torch.float32)
+        if x.dim() == self.logits.dim() and x.shape[-1] == 1:
+            x = x[..., 0]
+        out = torch.empty(self.logits.shape[:-1], device=self.logits.device)
+        return ops.disc_logprob_fwd(self.logits, x.contiguous(), out)
+
+
+class MSEDist:
+    """tools.py:520-540 (agg='sum')."""
+
+    def __init__(self, mode, agg="sum"):
+        if agg != "sum":
+            raise NotImplementedError(agg)
+        self._mode = mode
+
+    def mode(self):
+        return self._mode
+
+    def mean(self):
+        return self._mode
+
+    def log_prob(self, value):
+        assert self._mode.shape == value.shape, (self._mode.shape, value.shape)
+        d = (self._mode - value) ** 2
+        return -d.sum(list(range(d.dim()))[2:])
+
+
+class SymlogDist:
+    """tools.py:543-572 (dist='mse', agg='sum')."""
+
+    def __init__(self, mode, dist="mse", agg="sum", tol=1e-8):
+        if dist != "mse" or agg != "sum":
+            raise NotImplementedError((dist, agg))
+        self._mode = mode.contiguous()
+
+    def mode(self):
+        return symexp(self._mode)
+
+    def mean(self):
+        return symexp(self._mode)
+
+    def log_prob(self, value):
+        assert self._mode.shape == value.shape
+        loss = torch.empty(self._mode.shape[:-1], device=self._mode.device)
+        ops.symlog_mse(self._mode, value.to(torch.float32).contiguous(), loss)
+        return -loss
+
+
+class ContDist:
+    """tools.py:575-601 around Normal(tanh(mean), std) with absmax -- the continuous actor
+    (networks.py:693-700).  Holds the two raw head outputs."""
+
+    def __init__(self, mean_raw, std_raw, min_std, max_std, absmax=None, rng=None):
+        if absmax not in (None, 1.0):
+            raise NotImplementedError("absmax other than 1.0")
+        self._mr, self._sr = mean_raw.contiguous(), std_raw.contiguous()
+        self._min, self._max = float(min_std), float(max_std)
+        self.absmax = absmax
+        self._rng = rng
+
+    @property
+    def mean(self):
+        return torch.tanh(self._mr)
+
+    def mode(self):
+        out = torch.tanh(self._mr)
+        if self.absmax is not None:
+            out = out * (self.absmax / torch.clip(torch.abs(out), min=self.absmax))
+        return out
+
+    def sample(self, sample_shape=(), noise=None):
+        if tuple(sample_shape) != ():
+            raise NotImplementedError("sample_shape")
+        if noise is None:
+            rng = self._rng if self._rng is not None else default_rng(self._mr.device)
+            noise = torch.empty_like(self._mr)
+            ops.fill_normal(noise, rng)
+            ops.rng_advance(rng, noise.numel() // 4 + 1)
+        action = torch.empty_like(self._mr)
+        ops.actor_normal_fwd(self._mr, self._sr, noise.contiguous(), action, None, min_std=self._min,
+                             max_std=self._max)
+        return action
+
+    def entropy(self):
+        ent = torch.empty(self._mr.shape[:-1], device=self._mr.device)
+        ops.actor_normal_fwd(self._mr, self._sr, None, None, ent, min_std=self._min, max_std=self._max)
+        return ent
+
+    def log_prob(self, x):
+        lp = torch.empty(self._mr.shape[:-1], device=self._mr.device)
+        ops.actor_normal_logp(self._mr, self._sr, x.to(torch.float32).contiguous(), lp, min_std=self._min,
+                              max_std=self._max)
+        return lp
+
+
+class Bernoulli:
+    """tools.py:604-628 over logits [..., 1]."""
+
+    def __init__(self, logits):
+        self._logits = logits.contiguous()
+
+    @property
+    def mean(self):
+        return torch.sigmoid(self._logits)
+
+    def mode(self):
+        return torch.round(torch.sigmoid(self._logits))
+
+    def log_prob(self, x):
+        out = torch.empty_like(self._logits)
+        ops.bernoulli_logprob_fwd(self._logits, x.to(torch.float32).contiguous(), out)
+        return out.sum(-1)
+
+
+_DEFAULT_RNG = {}
+
+
+def default_rng(device, seed=0):
+    """Device-resident Philox state {seed, offset} shared by every sampler without injected noise."""
+    key = str(device)
+    if key not in _DEFAULT_RNG:
+        _DEFAULT_RNG[key] = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+    return _DEFAULT_RNG[key]
+
+
+def set_seed_everywhere(seed):  # tools.py:961-966
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    for k in list(_DEFAULT_RNG):
+        _DEFAULT_RNG[k][0] = seed
+        _DEFAULT_RNG[k][1] = 0
+
+
+# ---------------------------------------------------------------------------------------------
+# returns
+# ---------------------------------------------------------------------------------------------
+def lambda_return(reward, value, pcont, bootstrap, lambda_, axis):
+    """tools.py:702-728 for the layout ImagBehavior uses (axis 0, tensors [H-1, N, 1]).
+
+    reward = r[1:], value = v[:-1], pcont = disc[1:], bootstrap = v[-1]; returns [H-1, N, 1]."""
+    if axis != 0:
+        raise NotImplementedError("axis != 0")
+    h1 = reward.shape[0]
+    n = reward[0].numel()
+    dev = reward.device
+    full_r = torch.zeros(h1 + 1, n, device=dev)
+    full_r[1:] = reward.reshape(h1, n)
+    full_v = torch.empty(h1 + 1, n, device=dev)
+    full_v[:-1] = value.reshape(h1, n)
+    full_v[-1] = bootstrap.reshape(n)
+    # the kernel takes the continue LOGIT; disc = 1 * sigmoid(logit) => logit = log(d / (1 - d))
+    d = pcont.reshape(h1, n).clamp(1e-7, 1 - 1e-7)
+    full_c = torch.zeros(h1 + 1, n, device=dev)
+    full_c[1:] = torch.log(d) - torch.log1p(-d)
+    target = torch.empty(h1, n, device=dev)
+    weights = torch.empty(h1 + 1, n, device=dev)
+    ops.lambda_return_fwd(full_r, full_v, full_c, target, weights, None, gamma=1.0, lam=float(lambda_))
+    return target.reshape(reward.shape)
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizer
+# ---------------------------------------------------------------------------------------------
+class Optimizer:
+    """tools.py:731-783 surface over a flat bucket: zero_grad / (caller runs backward into .grad) /
+    all-reduce / clip / Adam.  `__call__(loss, params)` of the reference is split in two because the
+    backward here is explicit: `begin()` before it, `finish(loss)` after it."""
+
+    def __init__(self, name, parameters, lr, eps=1e-4, clip=None, wd=None, wd_pattern=r".*", opt="adam",
+                 use_amp=False):
+        assert 0 <= (wd or 0) < 1
+        assert not clip or 1 <= clip
+        if opt != "adam":
+            raise NotImplementedError(f"{opt} is not implemented")
+        if use_amp:
+            raise NotImplementedError("precision 16 is not supported: the path is fp32 (configs.yaml:18)")
+        if wd_pattern != r".*":
+            raise NotImplementedError
+        self._name, self._lr, self._eps, self._clip, self._wd = name, float(lr), float(eps), clip, wd or 0.0
+        self.bucket = ParamBucket(name, parameters)
+
+    def begin(self):
+        self.bucket.ensure().zero_grad()
+
+    def finish(self, loss):
+        """loss: 0-d device tensor (metric only).  Returns the reference's metric dict with device scalars."""
+        scale = self.bucket.allreduce()
+        self.bucket.step(lr=self._lr, eps=self._eps, clip=self._clip, weight_decay=self._wd, grad_scale=scale)
+        return {f"{self._name}_loss": loss, f"{self._name}_grad_norm": self.bucket.grad_norm}
+
+    def state_dict(self):
+        b = self.bucket.ensure()
+        return {"exp_avg": b.exp_avg, "exp_avg_sq": b.exp_avg_sq, "state": b.state}
+
+    def load_state_dict(self, sd):
+        b = self.bucket.ensure()
+        b.exp_avg.copy_(sd["exp_avg"])
+        b.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        b.state.copy_(sd["state"])
+
+
+# ---------------------------------------------------------------------------------------------
+# scan, schedules, init
+# ---------------------------------------------------------------------------------------------
+def static_scan(fn, inputs, start):
+    """tools.py:806-850 semantics (fold + stack on a new dim 0) without the quadratic re-concatenation."""
+    last = start
+    outs = []
+    for i in range(inputs[0].shape[0]):
+        last = fn(last, *[inp[i] for inp in inputs])
+        outs.append(last)
+    first = outs[0]
+    if isinstance(first, dict):
+        return [{k: torch.stack([o[k] for o in outs], 0) for k in first}]
+    res = []
+    for j in range(len(first)):
+        if isinstance(first[j], dict):
+            res.append({k: torch.stack([o[j][k] for o in outs], 0) for k in first[j]})
+        else:
+            res.append(torch.stack([o[j] for o in outs], 0))
+    return res
+
+
+class Every:  # tools.py:853-868
+    def __init__(self, every):
+        self._every, self._last = every, None
+
+    def __call__(self, step):
+        if not self._every:
+            return 0
+        if self._last is None:
+            self._last = step
+            return 1
+        count = int((step - self._last) / self._every)
+        self._last += self._every * count
+        return count
+
+
+class Once:  # tools.py:871-879
+    def __init__(self):
+        self._once = True
+
+    def __call__(self):
+        if self._once:
+            self._once = False
+            return True
+        return False
+
+
+class Until:  # tools.py:882-887
+    def __init__(self, until):
+        self._until = until
+
+    def __call__(self, step):
+        return True if not self._until else step < self._until
+
+
+def _fans(m):
+    if isinstance(m, nn.Linear):
+        return m.in_features, m.out_features
+    space = m.kernel_size[0] * m.kernel_size[1]
+    return space * m.in_channels, space * m.out_channels
+
+
+def weight_init(m):
+    """tools.py:890-917: truncated normal, std = sqrt(1/avg_fan)/0.8796, cut at 2 std; LN -> (1, 0)."""
+    if isinstance(m, (nn.Linear, nn.Conv2d, nn.ConvTranspose2d)):
+        fin, fout = _fans(m)
+        std = math.sqrt(1.0 / ((fin + fout) / 2.0)) / 0.87962566103423978
+        nn.init.trunc_normal_(m.weight.data, mean=0.0, std=std, a=-2.0 * std, b=2.0 * std)
+        if getattr(m, "bias", None) is not None:
+            m.bias.data.fill_(0.0)
+    elif isinstance(m, nn.LayerNorm):
+        m.weight.data.fill_(1.0)
+        m.bias.data.fill_(0.0)
+
+
+def uniform_weight_init(given_scale):
+    """tools.py:920-946: uniform(+-sqrt(3*scale/avg_fan))."""
+
+    def f(m):
+        if isinstance(m, (nn.Linear, nn.Conv2d, nn.ConvTranspose2d)):
+            fin, fout = _fans(m)
+            limit = math.sqrt(3 * given_scale / ((fin + fout) / 2.0))
+            nn.init.uniform_(m.weight.data, a=-limit, b=limit)
+            if getattr(m, "bias", None) is not None:
+                m.bias.data.fill_(0.0)
+        elif isinstance(m, nn.LayerNorm):
+            m.weight.data.fill_(1.0)
+            m.bias.data.fill_(0.0)
+
+    return f
+
+
+def tensorstats(tensor, prefix=None):  # tools.py:949-958 (device scalars; converted lazily)
+    metrics = {"mean": torch.mean(tensor), "std": torch.std(tensor), "min": torch.min(tensor),
+               "max": torch.max(tensor)}
+    return {f"{prefix}_{k}": v for k, v in metrics.items()} if prefix else metrics
+
+
+def args_type(default):  # tools.py:786-803
+    def parse_string(x):
+        if default is None:
+            return x
+        if isinstance(default, bool):
+            return bool(["False", "True"].index(x))
+        if isinstance(default, int):
+            return float(x) if ("e" in x or "." in x) else int(x)
+        if isinstance(default, (list, tuple)):
+            return tuple(args_type(default[0])(y) for y in x.split(","))
+        return type(default)(x)
+
+    def parse_object(x):
+        return tuple(x) if isinstance(default, (list, tuple)) else x
+
+    return lambda x: parse_string(x) if isinstance(x, str) else parse_object(x)
+
+
+def load_config(path, blocks):
+    """configs.yaml loader (dreamer.py:578-596 semantics): `defaults` then each named block, merged
+    recursively; PyYAML reads 1e6-style numbers as strings, so coerce them."""
+    import yaml
+
+    raw = yaml.safe_load(open(path))
+
+    def coerce(x):
+        if isinstance(x, dict):
+            return {k: coerce(v) for k, v in x.items()}
+        if isinstance(x, str) and re.fullmatch(r"-?\d+(\.\d*)?[eE][-+]?\d+", x):
+            return float(x)
+        return x
+
+    def merge(base, other):
+        for k, v in other.items():
+            if isinstance(v, dict) and isinstance(base.get(k), dict):
+                merge(base[k], v)
+            else:
+                base[k] = v
+
+    cfg = {}
+    for name in ["defaults"] + list(blocks):
+        merge(cfg, coerce(raw[name]))
+    return cfg

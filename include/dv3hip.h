@@ -165,6 +165,20 @@ int dv3_lambda_return_fwd(const float* reward, const float* value, const float* 
 int dv3_lambda_return_bwd(const float* dtarget, const float* value, const float* cont_logit, const float* target,
                           float* dreward, float* dcont_logit, int H, long N, float gamma, float lam, void* stream);
 
+/* ---- loss assembly --------------------------------------------------------------------------------------
+ * dv3_dot_accumulate: out[0] += scale * sum_i f(x_i) * w_i, f = max(., clip_min) if use_clip_min (w may be
+ *   NULL = ones) -- the torch.mean / torch.clip(min=free) reductions of models.py:147-148, networks.py:286-288.
+ * dv3_actor_loss: ImagBehavior._compute_actor_loss + entropy bonus (models.py:406-407, 640-681) and its
+ *   gradients in one pass; target/value/weights/entropy/logp [H,N] (target: H-1 rows used), ema_vals [2].
+ *   reinforce=0 ('dynamics'): writes dtarget [H-1,N]; reinforce=1: writes dlogp [H,N]. loss_out[0] += loss.
+ * dv3_scale_neg: out = -s*w (upstream of the two critic log-prob terms, models.py:424-429). */
+int dv3_dot_accumulate(const float* x, const float* w, long n, float* out, int use_clip_min, float clip_min,
+                       float scale, void* stream);
+int dv3_actor_loss(const float* target, const float* value, const float* weights, const float* entropy,
+                   const float* logp, const float* ema_vals, float* loss_out, float* dtarget, float* dlogp,
+                   float* dentropy, int H, long N, float entropy_coef, int reinforce, void* stream);
+int dv3_scale_neg(const float* w, float* out, long n, float s, void* stream);
+
 /* ---- is_first reset -- RSSM.obs_step (networks.py:176-193), branch-free -----------------------------
  * out[b,:] = x[b,:]*(1-m_b) + init[:]*m_b  (x or init may be NULL = zeros).  bwd: dx = dout*(1-m)
  * (dx may be NULL), dinit += sum_b dout[b,:]*m_b (dinit may be NULL). */
@@ -180,9 +194,14 @@ int dv3_reset_blend_bwd(const float* dout, long ldo, const float* is_first, floa
  * clears the accumulator -- all on device.  dv3_axpby: y = a*x + b*y (slow critic, models.py:683-689). */
 int dv3_sumsq_accumulate(const float* x, long n, float* out, void* stream);
 int dv3_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float* state,
-                  float lr, float beta1, float beta2, float eps, float clip, float weight_decay, void* stream);
+                  float lr, float beta1, float beta2, float eps, float clip, float weight_decay, float grad_scale,
+                  void* stream);
+/* grad_scale multiplies every gradient (and the norm) first: 1/world_size after a SUM all-reduce. */
 int dv3_axpby(const float* x, float* y, long n, float a, float b, void* stream);
 int dv3_rng_advance(unsigned long long* rng_state, unsigned long long increment, void* stream);
+/* out[n] ~ N(0,1) from Philox(rng_state) -- the actor's rsample noise when none is injected
+ * (torch.distributions.utils._standard_normal behind networks.py:697-699); consumes ceil(n/4) counters. */
+int dv3_fill_normal(float* out, long n, const unsigned long long* rng_state, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,127 @@
+"""Shared test scaffolding: build the MI355X-native models for a named shape config, load the
+deterministic weights, and compute the oracle's expectation of one full update on the CPU."""
+from __future__ import annotations
+
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from oracle import dv3_oracle as O
+from tests.golden import common
+
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dreamerv3-torch_amd")
+WM_PREFIXES = ("encoder", "dynamics", "heads")
+
+
+class _Space:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class _ObsSpace:
+    def __init__(self, spaces):
+        self.spaces = spaces
+
+
+def make_config(name, device="cuda:0"):
+    import tools
+
+    s = common.SHAPES[name]
+    blocks = ["dmc_proprio"] if s["encoder"] == "mlp" else ["dmc_vision"]
+    cfg = tools.load_config(os.path.join(PKG, "configs.yaml"), blocks)
+    cfg.update(device=device, num_actions=s["A"], dyn_stoch=s["stoch"], dyn_discrete=s["discrete"],
+               dyn_deter=s["deter"], dyn_hidden=s["hidden"], units=s["units"], batch_size=s["B"],
+               batch_length=s["T"], imag_horizon=s["H"], imag_gradient=s["imag_gradient"])
+    cfg["encoder"]["cnn_depth"] = s["cnn_depth"]
+    cfg["decoder"]["cnn_depth"] = s["cnn_depth"]
+    if s["actor_dist"] == "onehot":
+        cfg["actor"].update(dist="onehot", std="none")
+    if s["encoder"] == "mlp":
+        for d in (cfg["encoder"], cfg["decoder"]):
+            d.update(mlp_units=s["enc_mlp_units"], mlp_layers=s["enc_mlp_layers"])
+    return argparse.Namespace(**cfg)
+
+
+def obs_space(name):
+    s = common.SHAPES[name]
+    spaces = {}
+    if s["encoder"] == "mlp":
+        for k, w in common.PROPRIO_KEYS:
+            spaces[k] = _Space((w,))
+    spaces["image"] = _Space((64, 64, 3))
+    spaces["is_first"] = _Space((1,))
+    spaces["is_terminal"] = _Space((1,))
+    return _ObsSpace(spaces)
+
+
+def build_models(name, device="cuda:0", weights=None):
+    """-> (config, WorldModel, ImagBehavior) on the GPU with common.make_weights(name) loaded."""
+    import models
+
+    cfg = make_config(name, device)
+    wm = models.WorldModel(obs_space(name), None, 0, cfg).to(device)
+    beh = models.ImagBehavior(cfg, wm).to(device)
+    w = weights if weights is not None else common.make_weights(name)
+    sd = {k: torch.from_numpy(v) for k, v in w.items() if k.split(".")[0] in WM_PREFIXES}
+    missing = set(wm.state_dict().keys()) ^ set(sd.keys())
+    assert not missing, missing
+    wm.load_state_dict(sd)
+    bsd = beh.state_dict()
+    for k in list(bsd):
+        if k.startswith("_world_model.") or k == "ema_vals":
+            continue
+        bsd[k] = torch.from_numpy(w[k])
+    beh.load_state_dict(bsd)
+    wm.requires_grad_(False)
+    beh.requires_grad_(False)
+    return cfg, wm, beh
+
+
+def to_time_major_rows(x, B, T):
+    """[..., N=b*T+t, ...] on dim 1 -> rows ordered t*B+b (how the GPU path lays out imagination rows)."""
+    sh = x.shape
+    return x.reshape((sh[0], B, T) + tuple(sh[2:])).transpose(1, 2).reshape(sh)
+
+
+def from_time_major_rows(x, B, T):
+    sh = x.shape
+    return x.reshape((sh[0], T, B) + tuple(sh[2:])).transpose(1, 2).reshape(sh)
+
+
+def oracle_update(name, threads=None):
+    """One full update in the oracle (WM step, slow-critic EMA, behaviour on the UPDATED world model,
+    as dreamer.py:194-200).  Returns everything the GPU tests compare against."""
+    if threads:
+        torch.set_num_threads(threads)
+    cfg = common.path_config(name)
+    p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in common.make_weights(name).items()}
+    n = {k: torch.from_numpy(v) for k, v in common.make_noise(name).items()}
+    data = common.make_batch(name)
+    out = O.wm_forward(cfg, p, data, n["q_prior"], n["q_post"])
+    wkeys = [k for k in p if k.split(".")[0] in WM_PREFIXES]
+    grads = torch.autograd.grad(out["model_loss"], [p[k] for k in wkeys])
+    res = dict(cfg=cfg, wm=out, wm_grads={k: g.clone() for k, g in zip(wkeys, grads)})
+    with torch.no_grad():
+        st = dict(step=0, m=[torch.zeros_like(p[k]) for k in wkeys], v=[torch.zeros_like(p[k]) for k in wkeys])
+        res["model_grad_norm"] = O.clip_and_adam([p[k] for k in wkeys], list(grads), st, lr=1e-4, eps=1e-8, clip=1000.0)
+        for k in list(p):
+            if k.startswith("value."):
+                sk = "_slow_value." + k[len("value."):]
+                p[sk].copy_(cfg.slow_target_fraction * p[k] + (1 - cfg.slow_target_fraction) * p[sk])
+    start = {k: v.detach() for k, v in out["post"].items()}
+    ema = torch.zeros(2)
+    bout = O.behavior_forward(cfg, p, start, n["act"], n["q_img"], ema)
+    akeys = [k for k in p if k.startswith("actor.")]
+    vkeys = [k for k in p if k.startswith("value.")]
+    ga = torch.autograd.grad(bout["actor_loss"], [p[k] for k in akeys], retain_graph=True)
+    gv = torch.autograd.grad(bout["value_loss"], [p[k] for k in vkeys])
+    res.update(beh=bout, ema=ema, actor_grads=dict(zip(akeys, ga)), value_grads=dict(zip(vkeys, gv)))
+    with torch.no_grad():
+        for keys, gr, nm in ((akeys, ga, "actor"), (vkeys, gv, "value")):
+            st = dict(step=0, m=[torch.zeros_like(p[k]) for k in keys], v=[torch.zeros_like(p[k]) for k in keys])
+            res[nm + "_grad_norm"] = O.clip_and_adam([p[k] for k in keys], list(gr), st, lr=3e-5, eps=1e-5, clip=100.0)
+    res["params_after"] = {k: v.detach() for k, v in p.items()}
+    res["data"], res["noise"] = data, n
+    return res

@@ -1,0 +1,99 @@
+"""End-to-end parity of the MI355X path: one full training update (world model, then actor/critic on
+the updated world model) through models.WorldModel._train / ImagBehavior._train against the CPU
+oracle on the same minibatch, weights and injected sampling noise.  fp32, 1e-4 (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as Hh
+from tests.golden import common
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def close(got, ref, tol=TOL, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item() if got.numel() else 0.0
+    scale = max(1.0, ref.abs().max().item() if ref.numel() else 1.0)
+    assert err <= tol * scale, f"{what}: max err {err:.3e} (scale {scale:.3e})"
+
+
+def gpu_noise(name):
+    s = common.SHAPES[name]
+    n = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(name).items()}
+    wm_noise = dict(q_prior=n["q_prior"].contiguous(), q_post=n["q_post"].contiguous())
+    im_noise = dict(act=Hh.to_time_major_rows(n["act"], s["B"], s["T"]).contiguous(),
+                    q_img=Hh.to_time_major_rows(n["q_img"], s["B"], s["T"]).contiguous())
+    return wm_noise, im_noise
+
+
+@pytest.fixture(scope="module", params=["tiny", "tiny_onehot", "tiny_proprio"])
+def tiny_run(request):
+    name = request.param
+    exp = Hh.oracle_update(name)
+    cfg, wm, beh = Hh.build_models(name)
+    wm_noise, im_noise = gpu_noise(name)
+    post, context, mets = wm._train(common.make_batch(name), noise=wm_noise)
+    wm_grads = {k: p.grad.clone() for k, p in wm.named_parameters()}
+    wm_after = {k: v.clone() for k, v in wm.state_dict().items()}
+    post = {k: v.clone() for k, v in post.items()}
+    bres = beh._train(post, None, noise=im_noise)
+    torch.cuda.synchronize()
+    return dict(name=name, exp=exp, wm=wm, beh=beh, post=post, mets=mets, wm_grads=wm_grads, wm_after=wm_after,
+                bres=bres)
+
+
+def test_world_model_forward(tiny_run):
+    exp, post = tiny_run["exp"]["wm"], tiny_run["post"]
+    assert torch.equal(post["stoch"].cpu(), exp["post"]["stoch"].detach()), "sampled posterior differs"
+    close(post["logit"], exp["post"]["logit"], what="post logit")
+    close(post["deter"], exp["post"]["deter"], what="deter")
+    m = tiny_run["mets"]
+    close(torch.tensor(float(m["model_loss"])), exp["model_loss"], tol=1e-5, what="model_loss")
+    close(torch.tensor(float(m["kl"])), exp["kl"].mean(), what="kl")
+    close(torch.tensor(float(m["prior_ent"])), exp["prior_ent"].mean(), what="prior_ent")
+    close(torch.tensor(float(m["post_ent"])), exp["post_ent"].mean(), what="post_ent")
+    close(torch.tensor(float(m["reward_loss"])), exp["losses"]["reward"].mean(), what="reward_loss")
+    close(torch.tensor(float(m["cont_loss"])), exp["losses"]["cont"].mean(), what="cont_loss")
+
+
+def test_world_model_gradients_and_adam_step(tiny_run):
+    exp = tiny_run["exp"]
+    for k, g in exp["wm_grads"].items():
+        close(tiny_run["wm_grads"][k], g, tol=3e-4, what="grad " + k)
+    close(torch.tensor(float(tiny_run["mets"]["model_grad_norm"])), exp["model_grad_norm"], tol=2e-4, what="grad norm")
+    for k, v in tiny_run["wm_after"].items():
+        close(v, exp["params_after"][k], tol=1e-6, what="after " + k)
+
+
+def test_behaviour_update(tiny_run):
+    exp, beh = tiny_run["exp"], tiny_run["beh"]
+    s = common.SHAPES[tiny_run["name"]]
+    B, T = s["B"], s["T"]
+    _, imag_state, action, weights, mets = tiny_run["bres"]
+    eb = exp["beh"]
+    unperm = lambda x: Hh.from_time_major_rows(x, B, T)
+    assert torch.equal(unperm(imag_state["stoch"]).cpu(), eb["states"]["stoch"].detach()), "imagined samples differ"
+    close(unperm(imag_state["deter"]), eb["states"]["deter"], what="imag deter")
+    close(unperm(action), eb["actions"], what="imag action")
+    close(unperm(weights), eb["weights"], what="weights")
+    close(unperm(beh._last["target"]), eb["target"].squeeze(-1), what="target")
+    close(unperm(beh._last["reward"]), eb["reward"].squeeze(-1), what="reward")
+    close(unperm(beh._last["value"]), eb["value"].squeeze(-1), what="value")
+    close(torch.tensor(float(mets["actor_loss"])), eb["actor_loss"], tol=1e-5, what="actor_loss")
+    close(torch.tensor(float(mets["value_loss"])), eb["value_loss"], tol=1e-5, what="value_loss")
+    close(beh.ema_vals, exp["ema"], what="ema_vals")
+    for k, g in exp["actor_grads"].items():
+        close(dict(beh.named_parameters())[k].grad, g, tol=3e-4, what="grad " + k)
+    for k, g in exp["value_grads"].items():
+        close(dict(beh.named_parameters())[k].grad, g, tol=3e-4, what="grad " + k)
+    close(torch.tensor(float(mets["actor_grad_norm"])), exp["actor_grad_norm"], tol=3e-4, what="actor_grad_norm")
+    close(torch.tensor(float(mets["value_grad_norm"])), exp["value_grad_norm"], tol=3e-4, what="value_grad_norm")
+    sd = beh.state_dict()
+    for k in sd:
+        if k.startswith("_world_model.") or k == "ema_vals":
+            continue
+        close(sd[k], exp["params_after"][k], tol=1e-6, what="after " + k)
