@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native DreamerV3 world-model training hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2]
+
+A "step" is ONE full training update of the reference's Dreamer._train (dreamer.py:192-200) on one
+synthetic replay minibatch already resident in HBM: world-model forward/backward (CNN encoder, RSSM
+observe scan over T, decoder + reward + cont heads, KL), its clip+Adam step, then the behaviour
+update on the updated world model (imagination over H, lambda-returns, actor and critic
+forward/backward, two clip+Adam steps) -- and, for N > 1, one gradient all-reduce (RCCL) per
+optimizer.  The metric is BASELINE.json's: imagination-steps/s = N_gpus * B*T*H / time per update.
+
+Prints ONE JSON line on rank 0 with the `roofline` (dominant MFMA kernel, measured live with HIP
+events on the launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores)
+objects described in DESIGN.md.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "dreamerv3-torch_amd")
+for _p in (REPO, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix = 256 CU x 256 flop/clk x 2.4 GHz
+METRIC = "imagination-steps/sec"
+
+
+def synthetic_batch(shape, seed, device):
+    """RandomState(seed); image u8, continuous action uniform(-1,1) / one-hot, reward randn,
+    is_first[:,0] plus one extra reset on every other row, staged on the device before timing."""
+    from tests.golden import common
+
+    rs = np.random.RandomState(seed)
+    B, T, A = shape["B"], shape["T"], shape["A"]
+    data = {"image": rs.randint(0, 256, size=(B, T, 64, 64, 3)).astype(np.uint8)}
+    if shape["actor_dist"] == "onehot":
+        data["action"] = np.eye(A, dtype=np.float32)[rs.randint(0, A, size=(B, T))]
+    else:
+        data["action"] = rs.uniform(-1, 1, size=(B, T, A)).astype(np.float32)
+    data["reward"] = rs.randn(B, T).astype(np.float32)
+    data["discount"] = np.ones((B, T), np.float32)
+    first = np.zeros((B, T), np.float32)
+    first[:, 0] = 1.0
+    for b in range(0, B, 2):
+        first[b, rs.randint(1, T)] = 1.0
+    data["is_first"] = first
+    data["is_terminal"] = np.zeros((B, T), np.float32)
+    if shape["encoder"] == "mlp":
+        for k, w in common.PROPRIO_KEYS:
+            data[k] = rs.randn(B, T, w).astype(np.float32)
+    return {k: torch.from_numpy(v).to(device) for k, v in data.items()}
+
+
+def cpu_baseline(name, updates=2):
+    """The oracle (CPU port of the reference's path, parity-pinned by tests/golden) timed on this host."""
+    from oracle import dv3_oracle as O
+    from tests import helpers as Hh
+    from tests.golden import common
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    s = common.SHAPES[name]
+    t_all = []
+    Hh.oracle_update(name)  # warm-up (allocator, thread pool)
+    for _ in range(updates):
+        t0 = time.perf_counter()
+        Hh.oracle_update(name)
+        t_all.append(time.perf_counter() - t0)
+    t = float(np.median(t_all))
+    units = s["B"] * s["T"] * s["H"]
+    return {"value": units / t, "unit": "imagination-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{updates} full updates of {name} (after 1 warm-up), torch CPU fp32, {cores} threads; "
+                      f"median {t:.2f} s/update (includes building the noise/batch arrays, < 2 %)",
+            "sec_per_update": t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from dv3hip import ops
+    from tests import helpers as Hh
+    from tests.golden import common
+    import tools
+
+    name = args.config
+    shape = common.SHAPES[name]
+    B, T, H = shape["B"], shape["T"], shape["H"]
+    torch.manual_seed(0)  # identical random-init replica on every rank (reference init scheme, tools.py:890-946)
+    import models
+
+    cfg = Hh.make_config(name, str(device))
+    wm = models.WorldModel(Hh.obs_space(name), None, 0, cfg).to(device)
+    beh = models.ImagBehavior(cfg, wm).to(device)
+    wm.requires_grad_(False), beh.requires_grad_(False)
+    tools.default_rng(device, seed=1234 + rank)
+    data = synthetic_batch(shape, seed=rank, device=device)
+
+    from dv3hip.graph import UpdateRunner
+
+    runner = UpdateRunner(wm, beh, use_graph=not args.no_graph)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        runner.step(data)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step(data)
+    sync()
+    elapsed = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    loss = float(runner.last_metrics["model_loss"])
+    if not np.isfinite(loss):
+        raise SystemExit("non-finite loss in the timed region")
+
+    # ---- roofline leg: per-launch HIP-event timing of one more (eager) update on the launch stream
+    roofline = None
+    if rank == 0:
+        ops.PROFILE.start()
+        runner.step(data, eager=True)
+        prof = ops.PROFILE.stop()
+        mf = {k: v for k, v in prof.items() if v["flops"] > 0}
+        dom = max(mf, key=lambda k: mf[k]["ms"])
+        d = mf[dom]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        tot_fl, tot_ms = sum(v["flops"] for v in mf.values()), sum(v["ms"] for v in mf.values())
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "launches_per_update": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+                    "flops_per_launch": d["flops"] / d["launches"],
+                    "all_mfma_kernels": {"achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
+                                         "gflop_per_update": tot_fl / 1e9, "ms_per_update": tot_ms},
+                    "by_kernel": {k: {"ms": round(v["ms"], 3), "n": v["launches"],
+                                      "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
+                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:16]}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(name)
+
+    if rank == 0:
+        units = world * B * T * H
+        out = {
+            "metric": METRIC, "value": units * args.steps / elapsed, "unit": "imagination-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}: dmc_vision 64x64x3 replay, RSSM deter={shape['deter']} stoch="
+                                   f"{shape['stoch']}x{shape['discrete']}, batch {B} x seq {T} per GPU, horizon {H}; "
+                                   "one step = full Dreamer._train update (world model + actor + critic fwd/bwd, "
+                                   "gradient all-reduce, 3x clip+Adam)",
+                       "global_batch": B * world, "seq_len": T, "horizon": H, "parallelism": f"dp{world}",
+                       "launch": "eager" if args.no_graph else "hipGraph replay"},
+            "model_loss": loss,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

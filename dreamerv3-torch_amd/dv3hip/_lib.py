@@ -65,6 +65,10 @@ def load() -> ctypes.CDLL:
     global _lib, _decls
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; import it FIRST so this process has exactly one HIP runtime and
+    # the streams / device pointers torch hands us belong to the runtime our kernels launch on.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not built. Run `python dreamerv3-torch_amd/csrc/build.py` (needs hipcc, gfx950). "

@@ -45,9 +45,57 @@ def _contig(t: torch.Tensor, name: str, dtype=F32) -> None:
         raise TypeError(f"{name}: expected a contiguous CUDA/HIP {dtype} tensor")
 
 
-def _call(fn_name: str, *args) -> None:
+class _Profile:
+    """Optional per-launch accounting (bench.py's roofline leg): HIP events around every launch on the
+    launch stream, keyed by kernel, with the algorithmic FLOPs / bytes the caller declares."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}  # key -> [launches, flops, bytes, [event pairs]]
+
+    def start(self):
+        self.enabled, self.records = True, {}
+
+    def stop(self):
+        """-> {key: dict(launches, flops, bytes, ms)} (synchronises)."""
+        self.enabled = False
+        torch.cuda.synchronize()
+        out = {}
+        for k, (n, fl, by, evs) in self.records.items():
+            out[k] = dict(launches=n, flops=fl, bytes=by, ms=sum(a.elapsed_time(b) for a, b in evs))
+        return out
+
+
+PROFILE = _Profile()
+
+
+def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
     lib = _lib.load()
+    if PROFILE.enabled:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.check(getattr(lib, fn_name)(*args), fn_name)
+        b.record()
+        rec = PROFILE.records.setdefault(key or fn_name, [0, 0.0, 0.0, []])
+        rec[0] += 1
+        rec[1] += flops
+        rec[2] += nbytes
+        rec[3].append((a, b))
+        return
     _lib.check(getattr(lib, fn_name)(*args), fn_name)
+
+
+_TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32"}
+
+
+def pick_gemm_tile(M: int, N: int) -> int:
+    """Same rule as csrc/gemm.hip pick_tile: minimise (waves of workgroups over 256 CUs) x (MFMAs per
+    wave per k-step)."""
+    if M <= 32:
+        return 2
+    c128 = ((-(-M // 128) * -(-N // 128)) + 255) // 256 * 4
+    c64 = ((-(-M // 64) * -(-N // 64)) + 255) // 256 * 1
+    return 1 if c64 < c128 else 0
 
 
 # ---------------------------------------------------------------------------------------------
@@ -83,8 +131,12 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         gemm(A, Bv1, C, transA=False, transB=transB, bias=bias, accumulate=accumulate, tile=tile)
         gemm(A2, Bv2, C, transA=False, transB=transB, accumulate=True, tile=tile)
         return C
+    if tile < 0:
+        tile = pick_gemm_tile(M, N)
     _call("dv3_gemm_f32", int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(A2), lda2, K1, _ptr(B), ldb,
-          _ptr(C), ldc, _ptr(bias), int(accumulate), tile, s)
+          _ptr(C), ldc, _ptr(bias), int(accumulate), tile, s,
+          key=f"gemm_kernel<{_TILE_NAMES[tile]},tA={int(transA)},tB={int(transB)}>", flops=2.0 * M * N * K,
+          nbytes=4.0 * (M * K + N * K + M * N))
     return C
 
 
@@ -426,7 +478,9 @@ def conv_s2_fwd(x, wp, y, *, Ci, Co, accumulate=False):
     N, H, W = x.shape[0], x.shape[1], x.shape[2]
     if wp.numel() != 16 * Ci * Co or y.numel() != N * (H // 2) * (W // 2) * Co:
         raise ValueError("conv shapes mismatch")
-    _call("dv3_conv_s2_fwd", _ptr(x), _ptr(wp), _ptr(y), N, H, W, Ci, Co, int(accumulate), _stream())
+    _call("dv3_conv_s2_fwd", _ptr(x), _ptr(wp), _ptr(y), N, H, W, Ci, Co, int(accumulate), _stream(),
+          key=f"conv_s2_kernel<Co={Co}>", flops=2.0 * N * (H // 2) * (W // 2) * 16 * Ci * Co,
+          nbytes=4.0 * (x.numel() + y.numel() + wp.numel()))
     return y
 
 
@@ -443,7 +497,8 @@ def convT_s2_fwd(x, wp, y, *, Ci, Co, bias=None, out_add=0.0, accumulate=False):
         if bias.numel() != Co:
             raise ValueError("bias size mismatch")
     _call("dv3_convT_s2_fwd", _ptr(x), _ptr(wp), _ptr(bias), float(out_add), _ptr(y), N, IH, IW, Ci, Co,
-          int(accumulate), _stream())
+          int(accumulate), _stream(), key=f"convT_s2_kernel<Co={Co}>", flops=2.0 * N * IH * IW * 16 * Ci * Co,
+          nbytes=4.0 * (x.numel() + y.numel() + wp.numel()))
     return y
 
 
@@ -456,7 +511,9 @@ def conv_s2_wgrad(coarse, fine, dw):
     Cc = coarse.shape[3]
     if coarse.shape[0] != N or coarse.shape[1] * 2 != H or coarse.shape[2] * 2 != W or dw.numel() != 16 * Cc * Cf:
         raise ValueError("wgrad shapes mismatch")
-    _call("dv3_conv_s2_wgrad", _ptr(coarse), _ptr(fine), _ptr(dw), N, H, W, Cf, Cc, _stream())
+    _call("dv3_conv_s2_wgrad", _ptr(coarse), _ptr(fine), _ptr(dw), N, H, W, Cf, Cc, _stream(),
+          key="conv_wgrad_kernel", flops=2.0 * N * (H // 2) * (W // 2) * 16 * Cf * Cc,
+          nbytes=4.0 * (coarse.numel() + fine.numel() + dw.numel()))
     return dw
 
 

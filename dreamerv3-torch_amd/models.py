@@ -141,7 +141,20 @@ class WorldModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _train(self, data, noise=None):
-        """One world-model update.  `noise` (tests): dict(q_prior, q_post) of [T,B,S,D] Exp(1) draws."""
+        """One world-model update (models.py:108-171).  `noise` (tests): dict(q_prior, q_post) of
+        [T,B,S,D] Exp(1) draws.  = train_fwd_bwd (forward, losses, explicit backward into the flat gradient
+        bucket) + train_opt (all-reduce, clip, Adam); split so that a hipGraph can hold each half with the
+        collective between them."""
+        self.train_fwd_bwd(data, noise)
+        return self.train_opt()
+
+    def train_opt(self):
+        post, context, metrics, loss = self._pending
+        metrics = dict(metrics)
+        metrics.update(self._model_opt.finish(loss))
+        return post, context, _wrap(metrics)
+
+    def train_fwd_bwd(self, data, noise=None):
         cfg = self._config
         st = self._stage(data)
         B, T = st["action"].shape[0], st["action"].shape[1]
@@ -281,7 +294,7 @@ class WorldModel(nn.Module):
         # model_loss = image + vector + reward*scale + cont*scale + (dyn_scale + rep_scale) * clipped KL
         loss.copy_(acc[1:2] + acc[7:8] + self._scales["reward"] * acc[2:3] + self._scales["cont"] * acc[3:4]
                    + (cfg.dyn_scale + cfg.rep_scale) * acc[4:5])
-        metrics = self._model_opt.finish(loss[0])
+        metrics = {}
         if dec.cnn_shapes:
             metrics["image_loss"] = acc[1]
         for k in dec.mlp_shapes:
@@ -293,7 +306,7 @@ class WorldModel(nn.Module):
         post = {"stoch": bt(out["post_stoch"]), "deter": bt(out["deter"]), "logit": bt(out["post_logit"])}
         self._last = dict(out=out, embed=embed.view(T, B, E_), kl=kl, ent_post=ent_p, action_tm=out["action"])
         context = _LazyContext(self, post)
-        return post, context, _wrap(metrics)
+        self._pending = (post, context, metrics, loss[0])
 
     def video_pred(self, data):
         """models.py:192-213 (forward-only open-loop prediction for logging)."""
@@ -458,6 +471,17 @@ class ImagBehavior(nn.Module):
         """One actor + critic update (models.py:327-446).  `objective` is accepted for signature
         compatibility; the reward is the world model's reward head on the imagined states, which is what
         dreamer.py passes (dreamer.py:196-199)."""
+        self.train_fwd_bwd(start, noise)
+        return self.train_opt()
+
+    def train_opt(self):
+        ret, metrics, losses = self._pending
+        metrics = dict(metrics)
+        metrics.update(self._actor_opt.finish(losses[0]))
+        metrics.update(self._value_opt.finish(losses[1]))
+        return ret + (_wrap(metrics),)
+
+    def train_fwd_bwd(self, start, noise=None):
         cfg = self._config
         wm = self._world_model
         dyn = wm.dynamics
@@ -589,12 +613,9 @@ class ImagBehavior(nn.Module):
             metrics.update(tools.tensorstats((target - ema[0]) / scale, "normed_target"))
             metrics["EMA_005"], metrics["EMA_095"] = ema[0], ema[1]
         metrics["actor_entropy"] = acc[2]
-        metrics.update(self._actor_opt.finish(acc[0]))
-        metrics.update(self._value_opt.finish(acc[1]))
         self._last = dict(reward=reward, value=value, target=target, weights=weights, disc=disc, slow=slow)
-        S_, D_ = S, D
-        imag_state = {"stoch": stoch.view(H, N, S_, D_), "deter": deter, "logit": im["logit"].view(H, N, S_, D_)}
-        return None, imag_state, action, weights.view(H, N, 1), _wrap(metrics)
+        imag_state = {"stoch": stoch.view(H, N, S, D), "deter": deter, "logit": im["logit"].view(H, N, S, D)}
+        self._pending = ((None, imag_state, action, weights.view(H, N, 1)), metrics, (acc[0], acc[1]))
 
     def _actor_heads(self, im):
         eng = im["actor"]
