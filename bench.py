@@ -62,25 +62,40 @@ def synthetic_batch(shape, seed, device):
     return {k: torch.from_numpy(v).to(device) for k, v in data.items()}
 
 
+def host_cores() -> int:
+    """CPU share of this process: cgroup quota if set, else affinity, capped at 16 (the GPU box gives one
+    GPU's job a 16-core share; asking torch for more threads than that oversubscribes and stalls)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(name, updates=2):
     """The oracle (CPU port of the reference's path, parity-pinned by tests/golden) timed on this host."""
     from oracle import dv3_oracle as O
     from tests import helpers as Hh
     from tests.golden import common
 
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: timing the oracle on {cores} host threads ...", file=sys.stderr, flush=True)
     s = common.SHAPES[name]
     t_all = []
     Hh.oracle_update(name)  # warm-up (allocator, thread pool)
-    for _ in range(updates):
+    for i in range(updates):
         t0 = time.perf_counter()
         Hh.oracle_update(name)
         t_all.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline update {i}: {t_all[-1]:.2f} s", file=sys.stderr, flush=True)
     t = float(np.median(t_all))
     units = s["B"] * s["T"] * s["H"]
     return {"value": units / t, "unit": "imagination-steps/s", "cores": cores, "kind": "port",
