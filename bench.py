@@ -142,7 +142,7 @@ def main():
     wm = models.WorldModel(Hh.obs_space(name), None, 0, cfg).to(device)
     beh = models.ImagBehavior(cfg, wm).to(device)
     wm.requires_grad_(False), beh.requires_grad_(False)
-    tools.default_rng(device, seed=1234 + rank)
+    tools.default_rng(device, seed=1234 + rank)  # per-rank sampling stream
     data = synthetic_batch(shape, seed=rank, device=device)
 
     from dv3hip.graph import UpdateRunner

@@ -26,14 +26,15 @@ __global__ __launch_bounds__(256) void onehot_sample_kernel(const float* __restr
                                                             const float* __restrict__ noise,
                                                             const unsigned long long* __restrict__ rng_state,
                                                             float* __restrict__ out, int* __restrict__ idx_out,
-                                                            long R, int D, float unimix, int mode) {
+                                                            long R, int D, float unimix, int mode,
+                                                            unsigned long long offset_add) {
   constexpr int GPB = 256 / G;
   const int sub = threadIdx.x / G, d = threadIdx.x % G;
   const bool valid = d < D;
   unsigned long long seed = 0, offset = 0;
   if (!mode && !noise) {
     seed = rng_state[0];
-    offset = rng_state[1];
+    offset = rng_state[1] + offset_add;
   }
   for (long r0 = (long)blockIdx.x * GPB; r0 < R; r0 += (long)gridDim.x * GPB) {
     const long r = r0 + sub;
@@ -264,13 +265,14 @@ static unsigned cap_blocks(long n, long per_block, long cap) {
 using namespace dv3;
 
 extern "C" int dv3_onehot_sample_fwd(const float* logit, const float* noise, const unsigned long long* rng_state,
-                                     float* onehot, int* idx, long R, int D, float unimix, int mode, void* stream) {
+                                     unsigned long long rng_offset, float* onehot, int* idx, long R, int D,
+                                     float unimix, int mode, void* stream) {
   if (R <= 0) return 0;
   if (D <= 0 || D > 64 || !logit || !onehot) return DV3_ERR_ARG;
   if (!mode && !noise && !rng_state) return DV3_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_sample_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
-                                       logit, noise, rng_state, onehot, idx, R, D, unimix, mode));
+                                       logit, noise, rng_state, onehot, idx, R, D, unimix, mode, rng_offset));
   return (int)hipGetLastError();
 }
 

@@ -64,6 +64,13 @@ struct ConvATile {
     if (iy < 0 || iy >= op.H || ix < 0 || ix >= op.W) return 0.f;
     return op.x[base[p] + ((long)iy * op.W + ix) * op.C + ci];
   }
+  // every tile goes through the same predicated gather (padding taps make guards inherent); the guard
+  // selects the ADDRESS, not the control flow, so the loads stay in flight across the MFMAs
+  __device__ __forceinline__ static int full_tiles(const ConvA& op, int kbeg, int kend) {
+    return ((op.C & 3) == 0) ? (kend - kbeg + BK - 1) / BK : 0;
+  }
+  __device__ __forceinline__ void load_full(const ConvA& op, int r0, int k0, int tid) { load(op, r0, k0, tid); }
+  __device__ __forceinline__ void load_tail(const ConvA& op, int r0, int k0, int tid) { load(op, r0, k0, tid); }
   __device__ __forceinline__ void load(const ConvA& op, int, int k0, int tid) {
     const int c = tid % CH;
     const int k = k0 + 4 * c;
@@ -76,9 +83,9 @@ struct ConvATile {
       for (int p = 0; p < kVecs; ++p) {
         const int iy = iy0[p] + ky, ix = ix0[p] + kx;
         const bool ok = base[p] >= 0 && k < op.K && iy >= 0 && iy < op.H && ix >= 0 && ix < op.W;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (ok) t = *reinterpret_cast<const f32x4u*>(op.x + base[p] + ((long)iy * op.W + ix) * op.C + ci);
-        v[p] = t;
+        const float* src = ok ? op.x + base[p] + ((long)iy * op.W + ix) * op.C + ci : op.x;
+        const f32x4 t = *reinterpret_cast<const f32x4u*>(src);
+        v[p] = t * (ok ? 1.f : 0.f);  // multiply keeps the gather unconditional (no exec-mask branch)
       }
     } else {
 #pragma unroll
@@ -150,6 +157,11 @@ struct ConvTATile {
     if (iy < 0 || iy >= op.IH || ix < 0 || ix >= op.IW) return 0.f;
     return op.x[base[p] + ((long)iy * op.IW + ix) * op.C + ci];
   }
+  __device__ __forceinline__ static int full_tiles(const ConvTA& op, int kbeg, int kend) {
+    return ((op.C & 3) == 0) ? (kend - kbeg + BK - 1) / BK : 0;
+  }
+  __device__ __forceinline__ void load_full(const ConvTA& op, int r0, int k0, int tid) { load(op, r0, k0, tid); }
+  __device__ __forceinline__ void load_tail(const ConvTA& op, int r0, int k0, int tid) { load(op, r0, k0, tid); }
   __device__ __forceinline__ void load(const ConvTA& op, int, int k0, int tid) {
     const int c = tid % CH;
     const int k = k0 + 4 * c;
@@ -161,9 +173,9 @@ struct ConvTATile {
       for (int p = 0; p < kVecs; ++p) {
         const int iy = y0[p] - a, ix = x0[p] - b;
         const bool ok = base[p] >= 0 && k < op.K && iy >= 0 && iy < op.IH && ix >= 0 && ix < op.IW;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (ok) t = *reinterpret_cast<const f32x4u*>(op.x + base[p] + ((long)iy * op.IW + ix) * op.C + ci);
-        v[p] = t;
+        const float* src = ok ? op.x + base[p] + ((long)iy * op.IW + ix) * op.C + ci : op.x;
+        const f32x4 t = *reinterpret_cast<const f32x4u*>(src);
+        v[p] = t * (ok ? 1.f : 0.f);  // multiply keeps the gather unconditional (no exec-mask branch)
       }
     } else {
 #pragma unroll
@@ -220,6 +232,11 @@ struct WgradBTile {
     if (iy < 0 || iy >= op.H || ix < 0 || ix >= op.W) return 0.f;
     return op.x[((n * op.H + iy) * op.W + ix) * op.C + ci];
   }
+  __device__ __forceinline__ static int full_tiles(const WgradB& op, int kbeg, int kend) {
+    return ((op.C & 3) == 0) ? (kend - kbeg + BK - 1) / BK : 0;
+  }
+  __device__ __forceinline__ void load_full(const WgradB& op, int r0, int k0, int tid) { load(op, r0, k0, tid); }
+  __device__ __forceinline__ void load_tail(const WgradB& op, int r0, int k0, int tid) { load(op, r0, k0, tid); }
   __device__ __forceinline__ void load(const WgradB& op, int, int k0, int tid) {
     const int kr = tid / CH;
     if ((op.C & 3) == 0) {
@@ -230,17 +247,16 @@ struct WgradBTile {
 #pragma unroll
       for (int p = 0; p < kVecs; ++p) {
         const long m = (long)k0 + p * KPP + kr;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (colok && m < op.Mrows) {
-          const int ox = (int)(m % op.OW);
-          const long q = m / op.OW;
-          const int oy = (int)(q % op.OH);
-          const long n = q / op.OH;
-          const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
-          if (iy >= 0 && iy < op.H && ix >= 0 && ix < op.W)
-            t = *reinterpret_cast<const f32x4u*>(op.x + ((n * op.H + iy) * op.W + ix) * op.C + ci);
-        }
-        v[p] = t;
+        const long mc = (m < op.Mrows) ? m : 0;
+        const int ox = (int)(mc % op.OW);
+        const long q = mc / op.OW;
+        const int oy = (int)(q % op.OH);
+        const long n = q / op.OH;
+        const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+        const bool ok = colok && m < op.Mrows && iy >= 0 && iy < op.H && ix >= 0 && ix < op.W;
+        const float* src = ok ? op.x + ((n * op.H + iy) * op.W + ix) * op.C + ci : op.x;
+        const f32x4 t = *reinterpret_cast<const f32x4u*>(src);
+        v[p] = t * (ok ? 1.f : 0.f);  // multiply keeps the gather unconditional (no exec-mask branch)
       }
     } else {
 #pragma unroll

@@ -73,6 +73,126 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMM for the observe scan: M <= 32 rows (the replay batch) against a full weight matrix.
+// Weight-streaming bound (every step re-reads ~11 MB of weights from L2 / Infinity Cache), so the
+// shape is one 16-column output tile per workgroup with K split over its 4 waves (LDS reduce):
+// N/16 workgroups stream disjoint weight rows at full width, operands go straight from global memory
+// to the v_mfma_f32_16x16x4_f32 operand registers (no LDS staging: nothing is reused across waves).
+// Per 16-k chunk a lane (i = l&15, q = l>>4) loads A[i][k+4q..+3] and B[n0+i][k+4q..+3] (16 B each)
+// and issues 4 MFMAs; element g of both fragments is k = k+4q+g, so the k-order is permuted
+// identically for A and B (still an exact fp32 fma chain, in a different order).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSkinnyWaves = 8;   // K is split over the waves of a workgroup
+constexpr int kSkinnyBatch = 4;   // 16-k chunks whose loads are issued together before their MFMAs
+
+template <bool TB, int MT>
+__global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmParams p) {
+  __shared__ float red[kSkinnyWaves][MT][256];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  // K range of this wave, in 16-k chunks
+  const int chunks = (p.K + 15) >> 4;
+  const int per = (chunks + kSkinnyWaves - 1) / kSkinnyWaves;
+  const int cb = wave * per, ce = min(chunks, cb + per);
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int ncol = n0 + i;
+  const bool colok = ncol < p.N;
+  const float* bcol = p.B + (TB ? (long)(colok ? ncol : 0) * p.ldb : (long)(colok ? ncol : 0));
+  const float bmask = colok ? 1.f : 0.f;
+  float amask[MT];
+  const float* arow[MT];
+  const float* arow2[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int row = i + 16 * t;
+    const bool ok = row < p.M;
+    amask[t] = ok ? 1.f : 0.f;
+    arow[t] = p.A + (long)(ok ? row : 0) * p.lda;
+    arow2[t] = p.A2 ? p.A2 + (long)(ok ? row : 0) * p.lda2 : nullptr;
+  }
+  // chunks whose 4-element groups are entirely inside K (and inside their A segment) take the fast path
+  for (int c0 = cb; c0 < ce; c0 += kSkinnyBatch) {
+    f32x4 a[kSkinnyBatch][MT], b[kSkinnyBatch];
+    const bool fast = (c0 + kSkinnyBatch <= ce) && ((c0 + kSkinnyBatch) * 16 <= p.K) &&
+                      ((c0 * 16 >= p.K1) || ((c0 + kSkinnyBatch) * 16 <= p.K1));
+    if (fast) {
+      const bool seg2 = c0 * 16 >= p.K1;
+#pragma unroll
+      for (int u = 0; u < kSkinnyBatch; ++u) {
+        const int k = ((c0 + u) << 4) + 4 * q;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          a[u][t] = *reinterpret_cast<const f32x4u*>(seg2 ? arow2[t] + (k - p.K1) : arow[t] + k);
+        if (TB) {
+          b[u] = *reinterpret_cast<const f32x4u*>(bcol + k);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[u][e] = bcol[(long)(k + e) * p.ldb];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kSkinnyBatch; ++u) {
+        const int c = c0 + u;
+        const int k = (c << 4) + 4 * q;
+        const bool seg2 = k >= p.K1;
+        const int ka = seg2 ? k - p.K1 : k;
+        const int kend = seg2 ? p.K - p.K1 : p.K1;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          const float* src = (seg2 ? arow2[t] : arow[t]) + ka;
+          if (c < ce) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (ka + e < kend) v[e] = src[e];
+          }
+          a[u][t] = v;
+        }
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (c < ce) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < p.K) w[e] = TB ? bcol[k + e] : bcol[(long)(k + e) * p.ldb];
+        }
+        b[u] = w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSkinnyBatch; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t][g] * amask[t], b[u][g] * bmask, acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][t][r * 64 + lane] = acc[t][r];
+  __syncthreads();
+  // finish the MT*256 outputs: element x = r*64 + lane -> row 4*(lane>>4)+r (+16 t), col lane&15
+  for (int e = tid; e < MT * 256; e += 64 * kSkinnyWaves) {
+    const int t = e >> 8, x = e & 255;
+    const int r = x >> 6, l = x & 63;
+    const int row = 16 * t + 4 * (l >> 4) + r, col = n0 + (l & 15);
+    if (row < p.M && col < p.N) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < kSkinnyWaves; ++w) v += red[w][t][x];
+      if (p.bias) v += p.bias[col];
+      float* o = p.C + (long)row * p.ldc + col;
+      if (p.accumulate) v += *o;
+      *o = v;
+    }
+  }
+}
+
 template <class TS>
 static hipError_t launch_ts(const GemmParams& p0, int transA, int transB, hipStream_t s) {
   GemmParams p = p0;
@@ -117,13 +237,26 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   p.accumulate = accumulate;
   if (A2) {
     if (transA) return DV3_ERR_ARG;             // K-concat only for the k-contiguous orientation
-    if (K1 <= 0 || K1 >= K || (K1 % 32) != 0) return DV3_ERR_ARG;  // segment edge on a BK boundary
+    if (K1 <= 0 || K1 >= K || (K1 % 32) != 0) return DV3_ERR_ARG;  // segment edge on a K-tile boundary
   }
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
-  const int t = (tile >= 0 && tile <= 2) ? tile : pick_tile(M, N);
+  const int t = (tile >= 0 && tile <= 3) ? tile : pick_tile(M, N);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
+  if (t == 3) {
+    // skinny path: M <= 32, A k-contiguous; segment edge on a 16-k chunk boundary
+    if (M > 32 || transA || (A2 && (K1 % 16) != 0)) return DV3_ERR_ARG;
+    dim3 grid((N + 15) / 16), block(64 * kSkinnyWaves);
+    if (M <= 16) {
+      if (transB) hipLaunchKernelGGL((gemm_skinny_kernel<true, 1>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((gemm_skinny_kernel<false, 1>), grid, block, 0, s, p);
+    } else {
+      if (transB) hipLaunchKernelGGL((gemm_skinny_kernel<true, 2>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((gemm_skinny_kernel<false, 2>), grid, block, 0, s, p);
+    }
+    return (int)hipGetLastError();
+  }
   if (t == 0) e = launch_ts<T128>(p, transA, transB, s);
   else if (t == 1) e = launch_ts<T64>(p, transA, transB, s);
   else e = launch_ts<T32x128>(p, transA, transB, s);

@@ -278,6 +278,74 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// narrow matrices (N <= 32, e.g. the 3-channel image bias or the 1-wide continue head): every thread
+// keeps one column (its global index modulo N is fixed because the stride is a multiple of N)
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* __restrict__ x, long ldx,
+                                                            float* __restrict__ out, long R, int N) {
+  __shared__ float red[32];
+  if (threadIdx.x < 32) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  const long total = R * N;
+  const long stride = (long)gridDim.x * blockDim.x;  // host guarantees stride % N == 0
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(i0 % N);
+  float a = 0.f;
+  if (ldx == N) {
+    for (long i = i0; i < total; i += stride) a += x[i];
+  } else {
+    for (long i = i0; i < total; i += stride) a += x[(i / N) * ldx + c];
+  }
+  atomicAdd(&red[c], a);
+  __syncthreads();
+  if (threadIdx.x < N) atomicAdd(out + threadIdx.x, red[threadIdx.x]);
+}
+
+// One launch for the three is_first blends of an observe step (networks.py:181-193): stoch / deter
+// against the learned initial state, action against zero.
+__global__ void obs_blend_kernel(const float* __restrict__ ps, const float* __restrict__ s0,
+                                 const float* __restrict__ pd, const float* __restrict__ d0,
+                                 const float* __restrict__ act, const float* __restrict__ first,
+                                 float* __restrict__ os, float* __restrict__ od, float* __restrict__ oa, int B,
+                                 int SD, int De, int A) {
+  const int W = SD + De + A;
+  const long total = (long)B * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / W), j = (int)(i % W);
+    const float m = first[b];
+    if (j < SD) os[(long)b * SD + j] = (ps ? ps[(long)b * SD + j] : 0.f) * (1.f - m) + s0[j] * m;
+    else if (j < SD + De) {
+      const int k = j - SD;
+      od[(long)b * De + k] = (pd ? pd[(long)b * De + k] : 0.f) * (1.f - m) + d0[k] * m;
+    } else {
+      const int k = j - SD - De;
+      oa[(long)b * A + k] = act[(long)b * A + k] * (1.f - m);
+    }
+  }
+}
+// backward of the stoch / deter blends: gs_prev += dsin*(1-m), gd_prev += ddin*(1-m) (skipped when NULL),
+// dstoch0 += sum_b dsin*m, ddeter0 += sum_b ddin*m
+__global__ void obs_blend_bwd_kernel(const float* __restrict__ dsin, const float* __restrict__ ddin,
+                                     const float* __restrict__ first, float* __restrict__ gs_prev,
+                                     float* __restrict__ gd_prev, float* __restrict__ ds0,
+                                     float* __restrict__ dd0, int B, int SD, int De) {
+  const int W = SD + De;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W; j += gridDim.x * blockDim.x) {
+    const bool is_s = j < SD;
+    const int k = is_s ? j : j - SD;
+    const int w = is_s ? SD : De;
+    const float* src = is_s ? dsin : ddin;
+    float* prev = is_s ? gs_prev : gd_prev;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float m = first[b];
+      const float g = src[(long)b * w + k];
+      if (prev) prev[(long)b * w + k] += g * (1.f - m);
+      acc += g * m;
+    }
+    (is_s ? ds0 : dd0)[k] += acc;
+  }
+}
+
 __global__ void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = tanhf(x[i]);
 }
@@ -598,6 +666,14 @@ extern "C" int dv3_transpose01(const float* x, float* y, int B, int T, int k, vo
 extern "C" int dv3_colsum(const float* x, long ldx, float* out, long R, int N, int accumulate, void* stream) {
   if (R <= 0 || N <= 0) return 0;
   if (!x || !out) return DV3_ERR_ARG;
+  if (N <= 32 && R >= 4096) {
+    if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * N, S_);
+    long blocks = (R * N + 256L * 64 - 1) / (256L * 64);
+    if (blocks > 1024) blocks = 1024;
+    blocks = ((blocks + N - 1) / N) * N;  // stride = blocks*256 must be a multiple of N ... 256*blocks % N == 0
+    hipLaunchKernelGGL(colsum_narrow_kernel, dim3((unsigned)blocks), dim3(256), 0, S_, x, ldx, out, R, N);
+    return (int)hipGetLastError();
+  }
   const unsigned bx = (unsigned)((N + 63) / 64);
   long by = (R + 255) / 256;
   if (by > 64) by = 64;
@@ -714,5 +790,25 @@ extern "C" int dv3_scale_neg(const float* w, float* out, long n, float s, void* 
   if (n <= 0) return 0;
   if (!w || !out) return DV3_ERR_ARG;
   hipLaunchKernelGGL(scale_neg_kernel, dim3(nblk(n, 256, 2048)), dim3(256), 0, S_, w, out, n, s);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_obs_blend(const float* prev_stoch, const float* init_stoch, const float* prev_deter,
+                             const float* init_deter, const float* action, const float* is_first, float* out_stoch,
+                             float* out_deter, float* out_action, int B, int SD, int De, int A, void* stream) {
+  if (B <= 0) return 0;
+  if (!init_stoch || !init_deter || !action || !is_first || !out_stoch || !out_deter || !out_action) return DV3_ERR_ARG;
+  if ((prev_stoch == nullptr) != (prev_deter == nullptr)) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(obs_blend_kernel, dim3(nblk((long)B * (SD + De + A), 256, 1024)), dim3(256), 0, S_, prev_stoch,
+                     init_stoch, prev_deter, init_deter, action, is_first, out_stoch, out_deter, out_action, B, SD, De, A);
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_obs_blend_bwd(const float* dsin, const float* ddin, const float* is_first, float* gs_prev,
+                                 float* gd_prev, float* dstoch0, float* ddeter0, int B, int SD, int De, void* stream) {
+  if (B <= 0) return 0;
+  if (!dsin || !ddin || !is_first || !dstoch0 || !ddeter0) return DV3_ERR_ARG;
+  if ((gs_prev == nullptr) != (gd_prev == nullptr)) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(obs_blend_bwd_kernel, dim3(nblk(SD + De, 256, 1024)), dim3(256), 0, S_, dsin, ddin, is_first, gs_prev,
+                     gd_prev, dstoch0, ddeter0, B, SD, De);
   return (int)hipGetLastError();
 }

@@ -62,57 +62,106 @@ struct DenseTile {
   // sources are written with ds_write_b128 and need a 16-byte multiple.
   static constexpr int LD = ROWS + (KCONTIG ? (BK == 16 ? 2 : 1) : 4);
   f32x4 v[kVecs];
+  float mask[kVecs];  // 1 for rows inside the matrix, 0 past its edge (KCONTIG tiles; loop-invariant)
 
-  __device__ __forceinline__ void init(const DenseOperand<KCONTIG>&, int, int) {}
-  __device__ __forceinline__ void load(const DenseOperand<KCONTIG>& op, int r0, int k0, int tid) {
+  __device__ __forceinline__ void init(const DenseOperand<KCONTIG>& op, int r0, int tid) {
     if constexpr (KCONTIG) {
-      constexpr int CH = BK / 4;            // float4 chunks per row
-      constexpr int RPP = kThreads / CH;    // rows per pass
+      constexpr int RPP = kThreads / (BK / 4);
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) mask[p] = (r0 + p * RPP + tid / (BK / 4) < op.R) ? 1.f : 0.f;
+    }
+  }
+
+  // number of leading K-tiles of [kbeg, kend) that need no k guard (segment edges sit on tile edges)
+  __device__ __forceinline__ static int full_tiles(const DenseOperand<KCONTIG>& op, int kbeg, int kend) {
+    if (kend > op.K) kend = op.K;
+    return (kend > kbeg) ? (kend - kbeg) / BK : 0;
+  }
+
+  // Steady-state load: the tile's k range is entirely valid.  Rows past the edge are handled without
+  // control flow (load from a safe address, select zero) so that the loop body stays straight-line and
+  // the compiler keeps every global load of the tile in flight across the MFMAs.
+  __device__ __forceinline__ void load_full(const DenseOperand<KCONTIG>& op, int r0, int k0, int tid) {
+    if constexpr (KCONTIG) {
+      constexpr int CH = BK / 4;
+      constexpr int RPP = kThreads / CH;
+      const float* base = op.p;
+      long ld = op.ld;
+      int kk0 = k0;
+      if (k0 >= op.K1) { base = op.p2; ld = op.ld2; kk0 = k0 - op.K1; }
+      const int c = tid % CH, rr = tid / CH;
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        const int r = r0 + p * RPP + rr;
+        // rows past the edge read a safe address; store() multiplies them by mask = 0.  (A multiply, not
+        // a select or a branch: the load stays unconditional and nothing consumes it before the MFMAs,
+        // so all of the tile's global loads stay in flight across them.)
+        const float* src = (mask[p] != 0.f) ? base + (long)r * ld + (kk0 + 4 * c) : base;
+        v[p] = *reinterpret_cast<const f32x4u*>(src);
+      }
+    } else {
+      constexpr int CH = ROWS / 4;
+      constexpr int KPP = kThreads / CH;
+      static_assert(kThreads % CH == 0 && BK % KPP == 0, "bad tile");
+      const int c = tid % CH, kr = tid / CH;
+      const int r = r0 + 4 * c;
+      const bool ok4 = r + 3 < op.R;
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        const int k = k0 + p * KPP + kr;
+        const float* q = op.p + (long)k * op.ld + r;
+        if (ok4) {
+          v[p] = *reinterpret_cast<const f32x4u*>(q);
+        } else {
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (r + e < op.R) t[e] = q[e];
+          v[p] = t;
+        }
+      }
+    }
+  }
+
+  // Fully guarded load (the one partial K-tile at the end of a segment).
+  __device__ __forceinline__ void load_tail(const DenseOperand<KCONTIG>& op, int r0, int k0, int tid) {
+    if constexpr (KCONTIG) {
+      constexpr int CH = BK / 4;
+      constexpr int RPP = kThreads / CH;
       const float* base = op.p;
       long ld = op.ld;
       int kk0 = k0, kend = op.K1;
       if (k0 >= op.K1) { base = op.p2; ld = op.ld2; kk0 = k0 - op.K1; kend = op.K - op.K1; }
-      const bool interior = (r0 + ROWS <= op.R) && (kk0 + BK <= kend) && op.vec_ok;
       const int c = tid % CH, rr = tid / CH;
 #pragma unroll
       for (int p = 0; p < kVecs; ++p) {
         const int r = r0 + p * RPP + rr;
         const int k = kk0 + 4 * c;
-        if (interior) {
-          v[p] = *reinterpret_cast<const f32x4u*>(base + (long)r * ld + k);
-        } else {
-          f32x4 t = {0.f, 0.f, 0.f, 0.f};
-          if (r < op.R) {
-            const float* q = base + (long)r * ld + k;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (r < op.R) {
+          const float* q = base + (long)r * ld + k;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (k + e < kend) t[e] = q[e];
-          }
-          v[p] = t;
+          for (int e = 0; e < 4; ++e)
+            if (k + e < kend) t[e] = q[e];
         }
+        v[p] = t;
       }
     } else {
-      constexpr int CH = ROWS / 4;          // float4 chunks per k-row
-      constexpr int KPP = kThreads / CH;    // k-rows per pass
-      static_assert(kThreads % CH == 0 && BK % KPP == 0, "bad tile");
-      const bool interior = (r0 + ROWS <= op.R) && (k0 + BK <= op.K) && op.vec_ok;
+      constexpr int CH = ROWS / 4;
+      constexpr int KPP = kThreads / CH;
       const int c = tid % CH, kr = tid / CH;
 #pragma unroll
       for (int p = 0; p < kVecs; ++p) {
         const int k = k0 + p * KPP + kr;
         const int r = r0 + 4 * c;
-        if (interior) {
-          v[p] = *reinterpret_cast<const f32x4u*>(op.p + (long)k * op.ld + r);
-        } else {
-          f32x4 t = {0.f, 0.f, 0.f, 0.f};
-          if (k < op.K) {
-            const float* q = op.p + (long)k * op.ld + r;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (k < op.K) {
+          const float* q = op.p + (long)k * op.ld + r;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (r + e < op.R) t[e] = q[e];
-          }
-          v[p] = t;
+          for (int e = 0; e < 4; ++e)
+            if (r + e < op.R) t[e] = q[e];
         }
+        v[p] = t;
       }
     }
   }
@@ -127,7 +176,7 @@ struct DenseTile {
       for (int p = 0; p < kVecs; ++p) {
         const int r = p * RPP + rr;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[(4 * c + e) * LD + r] = v[p][e];
+        for (int e = 0; e < 4; ++e) s[(4 * c + e) * LD + r] = v[p][e] * mask[p];
       }
     } else {
       constexpr int CH = ROWS / 4;
@@ -153,9 +202,39 @@ struct TileShape {
   static constexpr int lds_floats = 2 * BK * (BM + 4) + 2 * BK * (BN + 4);  // upper bound on any pad
 };
 
-// The K loop.  ATile/BTile: staged-tile types with load(op, r0, k0, tid) / store(lds, tid).
+// The K loop.  ATile/BTile: staged-tile types with init / full_tiles / load_full / load_tail / store.
 // acc[tm][tn] on exit holds C(m0 + wm*TM*32 + tm*32 + row(reg,lane), n0 + ... + (lane&31)),
 // row(reg, lane) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+//
+// Shape of the loop: all K-tiles that need no k guard run in a branch-free steady state (global loads of
+// tile t+1 issued, every LDS fragment of tile t read up front, MFMAs, LDS store, one barrier); the at most
+// one guarded tail tile is peeled off behind it.
+template <class TS, class ATile, class BTile>
+__device__ __forceinline__ void mfma_tile_compute(const float* as, const float* bs, int h,
+                                                  f32x16 (&acc)[TS::TM][TS::TN]) {
+  constexpr int BK = TS::BK, LDA = ATile::LD, LDB = BTile::LD;
+  constexpr int NS = BK / 2;
+  float av[NS][TS::TM], bv[NS][TS::TN];
+  // every LDS fragment of the tile is requested before the first MFMA (pinned with sched_barrier: left
+  // alone, hipcc sinks each pair of ds_reads next to its MFMAs and waits lgkmcnt(0) 8x per tile)
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+#pragma unroll
+    for (int a = 0; a < TS::TM; ++a) av[s][a] = as[(2 * s + h) * LDA + a * 32];
+#pragma unroll
+    for (int b = 0; b < TS::TN; ++b) bv[s][b] = bs[(2 * s + h) * LDB + b * 32];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int a = 0; a < TS::TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TS::TN; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], bv[s][b], acc[a][b], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <class TS, class ATile, class BTile, class AOp, class BOp>
 __device__ __forceinline__ void mfma_mainloop(const AOp& aop, const BOp& bop, int m0, int n0, int kbeg,
                                               int kend, float* lds, f32x16 (&acc)[TS::TM][TS::TN]) {
@@ -175,46 +254,50 @@ __device__ __forceinline__ void mfma_mainloop(const AOp& aop, const BOp& bop, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  ATile at;
-  BTile bt;
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk <= 0) return;
+  int n_full = ATile::full_tiles(aop, kbeg, kend);
+  const int nfb = BTile::full_tiles(bop, kbeg, kend);
+  if (nfb < n_full) n_full = nfb;
+  if (n_full > nk) n_full = nk;
+
+  ATile at;
+  BTile bt;
   at.init(aop, m0, tid);
   bt.init(bop, n0, tid);
-  at.load(aop, m0, kbeg, tid);
-  bt.load(bop, n0, kbeg, tid);
+  if (n_full > 0) {
+    at.load_full(aop, m0, kbeg, tid);
+    bt.load_full(bop, n0, kbeg, tid);
+  } else {
+    at.load_tail(aop, m0, kbeg, tid);
+    bt.load_tail(bop, n0, kbeg, tid);
+  }
   at.store(As, tid);
   bt.store(Bs, tid);
   __syncthreads();
   int cur = 0;
-  for (int t = 0; t < nk; ++t) {
-    const bool more = (t + 1 < nk);
-    if (more) {
-      at.load(aop, m0, kbeg + (t + 1) * BK, tid);
-      bt.load(bop, n0, kbeg + (t + 1) * BK, tid);
-    }
-    const float* as = As + cur * BK * LDA + wm * TS::TM * 32 + i;
-    const float* bs = Bs + cur * BK * LDB + wn * TS::TN * 32 + i;
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float av[TS::TM], bv[TS::TN];
-#pragma unroll
-      for (int a = 0; a < TS::TM; ++a) av[a] = as[(kk + h) * LDA + a * 32];
-#pragma unroll
-      for (int b = 0; b < TS::TN; ++b) bv[b] = bs[(kk + h) * LDB + b * 32];
-#pragma unroll
-      for (int a = 0; a < TS::TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TS::TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-    }
-    if (more) {
-      at.store(As + (cur ^ 1) * BK * LDA, tid);
-      bt.store(Bs + (cur ^ 1) * BK * LDB, tid);
-    }
+  const int aoff = wm * TS::TM * 32 + i, boff = wn * TS::TN * 32 + i;
+  for (int t = 0; t + 1 < n_full; ++t) {
+    at.load_full(aop, m0, kbeg + (t + 1) * BK, tid);
+    bt.load_full(bop, n0, kbeg + (t + 1) * BK, tid);
+    mfma_tile_compute<TS, ATile, BTile>(As + cur * BK * LDA + aoff, Bs + cur * BK * LDB + boff, h, acc);
+    at.store(As + (cur ^ 1) * BK * LDA, tid);
+    bt.store(Bs + (cur ^ 1) * BK * LDB, tid);
     __syncthreads();
     cur ^= 1;
   }
+  // guarded tiles behind the steady state (one for dense operands; all of them for loaders that report no
+  // unguarded tiles, e.g. the 3-channel first conv layer)
+  for (int u = (n_full > 0 ? n_full : 1); u < nk; ++u) {
+    at.load_tail(aop, m0, kbeg + u * BK, tid);
+    bt.load_tail(bop, n0, kbeg + u * BK, tid);
+    mfma_tile_compute<TS, ATile, BTile>(As + cur * BK * LDA + aoff, Bs + cur * BK * LDB + boff, h, acc);
+    at.store(As + (cur ^ 1) * BK * LDA, tid);
+    bt.store(Bs + (cur ^ 1) * BK * LDB, tid);
+    __syncthreads();
+    cur ^= 1;
+  }
+  mfma_tile_compute<TS, ATile, BTile>(As + cur * BK * LDA + aoff, Bs + cur * BK * LDB + boff, h, acc);
 }
 
 }  // namespace dv3

@@ -65,8 +65,9 @@ __global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y,
 
 // N(0,1) fill (Box-Muller over Philox): the actor's rsample noise (torch _standard_normal in the
 // reference, networks.py:697-699) when the caller injects none.  One counter per 4 outputs.
-__global__ void fill_normal_kernel(float* __restrict__ out, long n, const unsigned long long* __restrict__ st) {
-  const unsigned long long seed = st[0], offset = st[1];
+__global__ void fill_normal_kernel(float* __restrict__ out, long n, const unsigned long long* __restrict__ st,
+                                   unsigned long long offset_add) {
+  const unsigned long long seed = st[0], offset = st[1] + offset_add;
   const long n4 = (n + 3) >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     uint32_t o[4];
@@ -127,11 +128,12 @@ extern "C" int dv3_rng_advance(unsigned long long* rng_state, unsigned long long
   return (int)hipGetLastError();
 }
 
-extern "C" int dv3_fill_normal(float* out, long n, const unsigned long long* rng_state, void* stream) {
+extern "C" int dv3_fill_normal(float* out, long n, const unsigned long long* rng_state, unsigned long long rng_offset,
+                               void* stream) {
   if (n <= 0) return 0;
   if (!out || !rng_state) return DV3_ERR_ARG;
   hipLaunchKernelGGL(fill_normal_kernel, dim3(blocks_for((n + 3) / 4, 2048)), dim3(256), 0, (hipStream_t)stream, out, n,
-                     rng_state);
+                     rng_state, rng_offset);
   return (int)hipGetLastError();
 }
 

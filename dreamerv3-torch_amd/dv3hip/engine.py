@@ -284,28 +284,22 @@ class RSSMEngine:
             ft = first[t]
             prev_s = post_stoch[t - 1].view(B, SD) if t > 0 else None
             prev_d = deter[t - 1] if t > 0 else None
-            ops.reset_blend(prev_s, s0.view(SD), ft, sin[t])
-            ops.reset_blend(prev_d, d0.view(De), ft, din[t])
-            ops.reset_blend(action_tm[t], None, ft, ain[t])
+            ops.obs_blend(prev_s, s0.view(SD), prev_d, d0.view(De), action_tm[t], ft, sin[t], din[t], ain[t])
             dense_ln_fwd(P.img_in, sin[t], ain[t], x1pre[t], m1[t], r1[t], x1[t])
             ops.gemm(x1[t], P.gru.W, gpre[t], A2=din[t])
             ops.gru_fwd(gpre[t], P.gru.g, P.gru.b, din[t], deter[t], mg[t], rg[t])
             ops.gemm(deter[t], P.obs_out.W[:, :De], x3pre[t], accumulate=True)
             ops.ln_act_fwd(x3pre[t], P.obs_out.g, P.obs_out.b, x3[t], m3[t], r3[t], act=True)
             ops.gemm(x3[t], P.obs.W, post_logit[t].view(B, SD), bias=P.obs.b)
-            ops.onehot_sample(post_logit[t], post_stoch[t], noise=None if q_post is None else q_post[t],
-                              rng_state=rng, unimix=self.unimix)
-            if q_post is None:
-                ops.rng_advance(rng, B * SD // 4 + 1)
+            ops.onehot_sample(post_logit[t], post_stoch[t], noise=None if q_post is None else q_post[t], rng=rng,
+                              unimix=self.unimix)
         # prior head for all steps at once
         x2pre, x2 = g("obs.x2pre", (T, B, Hd)), g("obs.x2", (T, B, Hd))
         m2, r2 = g("obs.m2", (T, B)), g("obs.r2", (T, B))
         prior_logit, prior_stoch = g("obs.prior_logit", (T, B, S, D)), g("obs.prior_stoch", (T, B, S, D))
         dense_ln_fwd(P.img_out, v2(deter, De), None, v2(x2pre, Hd), m2.view(TB), r2.view(TB), v2(x2, Hd))
         ops.gemm(v2(x2, Hd), P.ims.W, v2(prior_logit, SD), bias=P.ims.b)
-        ops.onehot_sample(prior_logit, prior_stoch, noise=q_prior, rng_state=rng, unimix=self.unimix)
-        if q_prior is None:
-            ops.rng_advance(rng, TB * SD // 4 + 1)
+        ops.onehot_sample(prior_logit, prior_stoch, noise=q_prior, rng=rng, unimix=self.unimix)
         self._embed = embed_tm
         return dict(post_stoch=post_stoch, post_logit=post_logit, deter=deter, prior_stoch=prior_stoch,
                     prior_logit=prior_logit, action=ain)
@@ -349,13 +343,9 @@ class RSSMEngine:
         dx1 = g("obs.dx1", (B, Hd))
         dx1pre = g("obs.dx1pre", (T, B, Hd))
         dsin, ddin = g("obs.dsin", (B, SD)), g("obs.ddin", (B, De))
-        carry_s, carry_d = g("obs.carry_s", (B, SD)), g("obs.carry_d", (B, De))
         dstoch0, ddeter0 = ws.zeros("obs.dstoch0", (SD,)), ws.zeros("obs.ddeter0", (De,))
         for t in reversed(range(T)):
-            gs_t, gd_t = gs[t], gd[t]
-            if t < T - 1:
-                ops.axpby(carry_s, gs_t, 1.0, 1.0)
-                ops.axpby(carry_d, gd_t, 1.0, 1.0)
+            gs_t, gd_t = gs[t], gd[t]  # already hold the carry from step t+1 (folded in by obs_blend_bwd)
             ops.onehot_st_bwd(post_logit[t], gs_t.view(B, S, D), dpost_logit[t], unimix=self.unimix, accumulate=True)
             ops.gemm(dpost_logit[t].view(B, SD), P.obs.W, dx3, transB=False)
             dense_ln_bwd_pre(P.obs_out, dx3, x3pre[t], m3[t], r3[t], dx3pre[t], wgrad=True)
@@ -366,8 +356,8 @@ class RSSMEngine:
             ops.gemm(dgpre[t], P.gru.W[:, :Hd], dx1, transB=False)
             dense_ln_bwd_pre(P.img_in, dx1, x1pre[t], m1[t], r1[t], dx1pre[t], wgrad=True)
             ops.gemm(dx1pre[t], P.img_in.W[:, :SD], dsin, transB=False)
-            ops.reset_blend_bwd(dsin, first[t], carry_s, dstoch0)
-            ops.reset_blend_bwd(ddin, first[t], carry_d, ddeter0)
+            ops.obs_blend_bwd(dsin, ddin, first[t], gs[t - 1] if t > 0 else None, gd[t - 1] if t > 0 else None,
+                              dstoch0, ddeter0)
         # ---- batched weight gradients and the encoder-output gradient
         dpl = v2(dpost_logit, SD)
         lin_wgrad(P.obs.W, dpl, v2(x3, Hd))
@@ -388,15 +378,13 @@ class RSSMEngine:
         ops.gru_fwd(bufs["gpre"], P.gru.g, P.gru.b, deter, bufs["deter"], bufs["mg"], bufs["rg"])
         dense_ln_fwd(P.img_out, bufs["deter"], None, bufs["x2pre"], bufs["m2"], bufs["r2"], bufs["x2"])
         ops.gemm(bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD), bias=P.ims.b)
-        ops.onehot_sample(bufs["logit"], bufs["stoch"], noise=noise, rng_state=rng, unimix=self.unimix,
-                          mode=not sample)
-        if sample and noise is None:
-            ops.rng_advance(rng, M * self.SD // 4 + 1)
+        ops.onehot_sample(bufs["logit"], bufs["stoch"], noise=noise, rng=rng, unimix=self.unimix, mode=not sample)
 
-    def img_step_bwd(self, dstoch, ddeter, prev_deter, bufs, scratch, dprev_stoch, dprev_deter, daction):
+    def img_step_bwd(self, dstoch, ddeter, prev_deter, bufs, scratch, dprev_stoch, dprev_deter, daction,
+                     accumulate_prev=False):
         """Input gradients of img_step_fwd (world-model weights frozen: no wgrad; models.py:335).
         dstoch [M,SD] / ddeter [M,De]: total gradient on the step's outputs (ddeter is used as scratch).
-        Writes dprev_stoch, dprev_deter, daction."""
+        Writes (or, with accumulate_prev, adds into) dprev_stoch / dprev_deter; writes daction."""
         P = self.P
         M = dstoch.shape[0]
         S, D, SD, De, Hd = self.S, self.D, self.SD, self.De, self.Hd
@@ -407,12 +395,12 @@ class RSSMEngine:
                          wgrad=False)
         ops.gemm(scratch["dx2pre"], P.img_out.W, ddeter, transB=False, accumulate=True)
         ops.gru_bwd(ddeter, bufs["gpre"], P.gru.g, P.gru.b, prev_deter, bufs["mg"], bufs["rg"], scratch["dgpre"],
-                    dprev_deter)
+                    dprev_deter, accumulate_dh=accumulate_prev)
         ops.gemm(scratch["dgpre"], P.gru.W[:, Hd:], dprev_deter, transB=False, accumulate=True)
         ops.gemm(scratch["dgpre"], P.gru.W[:, :Hd], scratch["dx1"], transB=False)
         dense_ln_bwd_pre(P.img_in, scratch["dx1"], bufs["x1pre"], bufs["m1"], bufs["r1"], scratch["dx1pre"],
                          wgrad=False)
-        ops.gemm(scratch["dx1pre"], P.img_in.W[:, :SD], dprev_stoch, transB=False)
+        ops.gemm(scratch["dx1pre"], P.img_in.W[:, :SD], dprev_stoch, transB=False, accumulate=accumulate_prev)
         if daction is not None:
             ops.gemm(scratch["dx1pre"], P.img_in.W[:, SD:], daction, transB=False)
 

@@ -85,7 +85,7 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
     _lib.check(getattr(lib, fn_name)(*args), fn_name)
 
 
-_TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32"}
+_TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16"}
 
 
 def pick_gemm_tile(M: int, N: int) -> int:
@@ -133,6 +133,8 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         return C
     if tile < 0:
         tile = pick_gemm_tile(M, N)
+        if M <= 32 and not transA:
+            tile = 3
     _call("dv3_gemm_f32", int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(A2), lda2, K1, _ptr(B), ldb,
           _ptr(C), ldc, _ptr(bias), int(accumulate), tile, s,
           key=f"gemm_kernel<{_TILE_NAMES[tile]},tA={int(transA)},tB={int(transB)}>", flops=2.0 * M * N * K,
@@ -235,25 +237,49 @@ def _groups(t, name, D):
     return t.numel() // D
 
 
-def onehot_sample(logit, out, *, noise=None, rng_state=None, idx=None, unimix=0.01, mode=False):
+class RngStream:
+    """Device-resident Philox state {seed, offset} plus a host cursor.  Samplers `take()` disjoint counter
+    ranges (a launch argument, so the sequence is static under hipGraph replay); `commit()` advances the
+    device offset once for everything taken since the last commit."""
+
+    def __init__(self, device, seed=0):
+        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        self.cursor = 0
+
+    def take(self, n_elems: int) -> int:
+        off = self.cursor
+        self.cursor += n_elems // 4 + 1
+        return off
+
+    def commit(self):
+        if self.cursor:
+            rng_advance(self.state, self.cursor)
+            self.cursor = 0
+
+    def reseed(self, seed: int):
+        self.state[0] = seed
+        self.state[1] = 0
+        self.cursor = 0
+
+
+def onehot_sample(logit, out, *, noise=None, rng=None, idx=None, unimix=0.01, mode=False):
     D = logit.shape[-1]
     R = _groups(logit, "logit", D)
     if _groups(out, "out", D) != R:
         raise ValueError("out size mismatch")
     if noise is not None and _groups(noise, "noise", D) != R:
         raise ValueError("noise size mismatch")
-    if rng_state is not None:
-        _contig(rng_state, "rng_state", torch.int64)
-        if rng_state.numel() < 2:
-            raise ValueError("rng_state needs {seed, offset}")
+    rng_state, rng_off = None, 0
+    if not mode and noise is None:
+        if rng is None:
+            raise ValueError("sampling needs noise or an RngStream")
+        rng_state, rng_off = rng.state, rng.take(R * D)
     if idx is not None:
         _contig(idx, "idx", torch.int32)
         if idx.numel() != R:
             raise ValueError("idx size mismatch")
-    if not mode and noise is None and rng_state is None:
-        raise ValueError("sampling needs noise or rng_state")
-    _call("dv3_onehot_sample_fwd", _ptr(logit), _ptr(noise), _ptr(rng_state), _ptr(out), _ptr(idx), R, D,
-          float(unimix), int(mode), _stream())
+    _call("dv3_onehot_sample_fwd", _ptr(logit), _ptr(noise), _ptr(rng_state), int(rng_off), _ptr(out), _ptr(idx), R,
+          D, float(unimix), int(mode), _stream())
     return out
 
 
@@ -681,10 +707,40 @@ def rng_advance(rng_state, increment):
     _call("dv3_rng_advance", _ptr(rng_state), int(increment), _stream())
 
 
-def fill_normal(out, rng_state):
-    _contig(out, "out"), _contig(rng_state, "rng_state", torch.int64)
-    _call("dv3_fill_normal", _ptr(out), out.numel(), _ptr(rng_state), _stream())
+def fill_normal(out, rng: RngStream):
+    _contig(out, "out")
+    _call("dv3_fill_normal", _ptr(out), out.numel(), _ptr(rng.state), int(rng.take(out.numel())), _stream())
     return out
+
+
+def obs_blend(prev_stoch, init_stoch, prev_deter, init_deter, action, is_first, out_stoch, out_deter, out_action):
+    B, SD = out_stoch.shape
+    De, A = out_deter.shape[1], out_action.shape[1]
+    for t, nm, n in ((prev_stoch, "prev_stoch", B * SD), (init_stoch, "init_stoch", SD), (prev_deter, "prev_deter", B * De),
+                     (init_deter, "init_deter", De), (action, "action", B * A), (is_first, "is_first", B),
+                     (out_stoch, "out_stoch", B * SD), (out_deter, "out_deter", B * De), (out_action, "out_action", B * A)):
+        if t is None:
+            continue
+        _contig(t, nm)
+        if t.numel() != n:
+            raise ValueError(nm + " size mismatch")
+    _call("dv3_obs_blend", _ptr(prev_stoch), _ptr(init_stoch), _ptr(prev_deter), _ptr(init_deter), _ptr(action),
+          _ptr(is_first), _ptr(out_stoch), _ptr(out_deter), _ptr(out_action), B, SD, De, A, _stream())
+
+
+def obs_blend_bwd(dsin, ddin, is_first, gs_prev, gd_prev, dstoch0, ddeter0):
+    B, SD = dsin.shape
+    De = ddin.shape[1]
+    for t, nm, n in ((dsin, "dsin", B * SD), (ddin, "ddin", B * De), (is_first, "is_first", B),
+                     (gs_prev, "gs_prev", B * SD), (gd_prev, "gd_prev", B * De), (dstoch0, "dstoch0", SD),
+                     (ddeter0, "ddeter0", De)):
+        if t is None:
+            continue
+        _contig(t, nm)
+        if t.numel() != n:
+            raise ValueError(nm + " size mismatch")
+    _call("dv3_obs_blend_bwd", _ptr(dsin), _ptr(ddin), _ptr(is_first), _ptr(gs_prev), _ptr(gd_prev), _ptr(dstoch0),
+          _ptr(ddeter0), B, SD, De, _stream())
 
 
 def dot_accumulate(x, out, *, w=None, clip_min=None, scale=1.0):

@@ -306,6 +306,7 @@ class WorldModel(nn.Module):
         post = {"stoch": bt(out["post_stoch"]), "deter": bt(out["deter"]), "logit": bt(out["post_logit"])}
         self._last = dict(out=out, embed=embed.view(T, B, E_), kl=kl, ent_post=ent_p, action_tm=out["action"])
         context = _LazyContext(self, post)
+        rng.commit()
         self._pending = (post, context, metrics, loss[0])
 
     def video_pred(self, data):
@@ -450,19 +451,17 @@ class ImagBehavior(nn.Module):
                     eps[t].copy_(act_noise[t])
                 else:
                     ops.fill_normal(eps[t], rng)
-                    ops.rng_advance(rng, N * A // 4 + 1)
                 ops.actor_normal_fwd(mean_raw, std_raw, eps[t], action[t], ent[t], min_std=cfg.actor["min_std"],
                                      max_std=cfg.actor["max_std"])
             else:
-                ops.onehot_sample(mean_raw, action[t], noise=None if act_noise is None else act_noise[t],
-                                  rng_state=rng, unimix=cfg.actor["unimix_ratio"])
-                if act_noise is None:
-                    ops.rng_advance(rng, N * A // 4 + 1)
+                ops.onehot_sample(mean_raw, action[t], noise=None if act_noise is None else act_noise[t], rng=rng,
+                                  unimix=cfg.actor["unimix_ratio"])
                 ops.onehot_ent_logp_fwd(mean_raw, None, ent[t], None, unimix=cfg.actor["unimix_ratio"])
             if t < H - 1:
                 b = {k: v[t] for k, v in step.items()}
                 b.update(deter=deter[t + 1], logit=logit[t + 1].view(N, S, D), stoch=stoch[t + 1].view(N, S, D))
                 rssm.img_step_fwd(stoch[t], deter[t], action[t], b, noise=None if q_img is None else q_img[t], rng=rng)
+        rng.commit()
         self._im = dict(H=H, N=N, stoch=stoch, deter=deter, logit=logit, action=action, ent=ent, eps=eps, step=step,
                         actor=actor_eng)
 
@@ -560,14 +559,13 @@ class ImagBehavior(nn.Module):
             scratch = dict(dlogit=g("bh.s.dlogit", (N, SD)), dx2=g("bh.s.dx2", (N, Hd)), dx2pre=g("bh.s.dx2pre", (N, Hd)),
                            dgpre=g("bh.s.dgpre", (N, 3 * De)), dx1=g("bh.s.dx1", (N, Hd)),
                            dx1pre=g("bh.s.dx1pre", (N, Hd)))
-            cs, cd = g("bh.carry_s", (N, SD)), g("bh.carry_d", (N, De))
             for t in range(H - 1, 0, -1):
-                if t < H - 1:
-                    ops.axpby(cs, gs[t], 1.0, 1.0)
-                    ops.axpby(cd, gd[t], 1.0, 1.0)
                 b = {k: v[t - 1] for k, v in im["step"].items()}
                 b.update(logit=im["logit"][t].view(N, S, D))
-                rssm.img_step_bwd(gs[t], gd[t], deter[t - 1], b, scratch, cs, cd, daction[t - 1])
+                # state gradients flow straight into gs/gd[t-1] (which already hold the heads' gradient);
+                # step 0 is the detached start state: its slot is scratch
+                rssm.img_step_bwd(gs[t], gd[t], deter[t - 1], b, scratch, gs[t - 1], gd[t - 1], daction[t - 1],
+                                  accumulate_prev=t > 1)
         # ---- actor backward over steps 0..H-2 (the last step's action feeds nothing that is used)
         R = H1N
         dmean, dstd = g("bh.dmean", (R, A)), g("bh.dstd", (R, A))

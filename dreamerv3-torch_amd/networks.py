@@ -158,6 +158,7 @@ class RSSM(nn.Module):
         self.engine.img_step_fwd(st.view(M, -1), prev_state["deter"].contiguous(),
                                  prev_action.to(torch.float32).contiguous(), b, noise=noise,
                                  rng=self._rng(), sample=sample)
+        self._rng().commit()
         return {"stoch": b["stoch"], "deter": b["deter"], "logit": b["logit"]}
 
     def obs_step(self, prev_state, prev_action, embed, is_first, sample=True, noise=None):
@@ -191,10 +192,9 @@ class RSSM(nn.Module):
         logit = torch.empty(B, S, D, device=dev)
         ops.gemm(x3, p.obs.W, logit.view(B, SD), bias=p.obs.b)
         stoch = torch.empty(B, S, D, device=dev)
-        ops.onehot_sample(logit, stoch, noise=nz.get("post"), rng_state=self._rng(), unimix=self._unimix_ratio,
+        ops.onehot_sample(logit, stoch, noise=nz.get("post"), rng=self._rng(), unimix=self._unimix_ratio,
                           mode=not sample)
-        if sample and nz.get("post") is None:
-            ops.rng_advance(self._rng(), B * SD // 4 + 1)
+        self._rng().commit()
         post = {"stoch": stoch, "deter": b["deter"], "logit": logit}
         return post, prior
 
@@ -209,6 +209,7 @@ class RSSM(nn.Module):
         nz = noise or {}
         out = self.engine.observe_fwd(tm(embed), tm(action), tm(is_first), q_prior=nz.get("q_prior"),
                                       q_post=nz.get("q_post"), rng=self._rng())
+        self._rng().commit()
         bt = lambda x: x.transpose(0, 1).clone()
         post = {"stoch": bt(out["post_stoch"]), "deter": bt(out["deter"]), "logit": bt(out["post_logit"])}
         prior = {"stoch": bt(out["prior_stoch"]), "deter": bt(out["deter"]), "logit": bt(out["prior_logit"])}

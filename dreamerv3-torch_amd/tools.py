@@ -80,12 +80,12 @@ class OneHotDist:
         if tuple(sample_shape) != ():
             raise NotImplementedError("sample_shape")
         out = torch.empty_like(self._logits)
-        rng = self._rng if noise is None else None
-        if noise is None and rng is None:
-            rng = default_rng(self._logits.device)
-        ops.onehot_sample(self._logits, out, noise=noise, rng_state=rng, unimix=self._unimix)
+        rng = None
         if noise is None:
-            ops.rng_advance(rng, self._logits.numel() // 4 + 1)
+            rng = self._rng if self._rng is not None else default_rng(self._logits.device)
+        ops.onehot_sample(self._logits, out, noise=noise, rng=rng, unimix=self._unimix)
+        if rng is not None:
+            rng.commit()
         return out
 
     def entropy(self):
@@ -211,7 +211,7 @@ class ContDist:
             rng = self._rng if self._rng is not None else default_rng(self._mr.device)
             noise = torch.empty_like(self._mr)
             ops.fill_normal(noise, rng)
-            ops.rng_advance(rng, noise.numel() // 4 + 1)
+            rng.commit()
         action = torch.empty_like(self._mr)
         ops.actor_normal_fwd(self._mr, self._sr, noise.contiguous(), action, None, min_std=self._min,
                              max_std=self._max)
@@ -251,11 +251,13 @@ class Bernoulli:
 _DEFAULT_RNG = {}
 
 
-def default_rng(device, seed=0):
-    """Device-resident Philox state {seed, offset} shared by every sampler without injected noise."""
-    key = str(device)
+def default_rng(device, seed=None):
+    """Device-resident Philox stream shared by every sampler that gets no injected noise."""
+    key = str(torch.device(device))
     if key not in _DEFAULT_RNG:
-        _DEFAULT_RNG[key] = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        _DEFAULT_RNG[key] = ops.RngStream(torch.device(device), seed or 0)
+    elif seed is not None:
+        _DEFAULT_RNG[key].reseed(seed)
     return _DEFAULT_RNG[key]
 
 
@@ -263,8 +265,7 @@ def set_seed_everywhere(seed):  # tools.py:961-966
     torch.manual_seed(seed)
     np.random.seed(seed)
     for k in list(_DEFAULT_RNG):
-        _DEFAULT_RNG[k][0] = seed
-        _DEFAULT_RNG[k][1] = 0
+        _DEFAULT_RNG[k].reseed(seed)
 
 
 # ---------------------------------------------------------------------------------------------

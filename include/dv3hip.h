@@ -32,7 +32,8 @@ int dv3_version(void);
  *   transA=0: A[m*lda+k]   transA=1: A[k*lda+m]      transB=1: B[n*ldb+k]   transB=0: B[k*ldb+n]
  *   A2/K1: optional second K segment (columns K1..K-1 come from A2[m*lda2 + k-K1]); K1 % 32 == 0,
  *          transA must be 0.  Pass A2=NULL for a single operand.
- *   tile: -1 = choose, 0 = 128x128, 1 = 64x64, 2 = 32x128.
+ *   tile: -1 = choose, 0 = 128x128, 1 = 64x64, 2 = 32x128, 3 = skinny (M <= 32, transA = 0: one 16-column
+ *         tile per workgroup, K split over its waves, operands straight to the 16x16x4 MFMA registers).
  * Replaces nn.Linear forward / its autograd transposes in RSSM.img_step, obs_step
  * (networks.py:195-233), GRUCell.forward (networks.py:762), MLP.forward (networks.py:657-681),
  * ConvDecoder._linear_layer (networks.py:569), and the torch.cat in front of them
@@ -69,7 +70,11 @@ int dv3_gru_bwd(const float* dh_new, long lddhn, const float* p, long ldp, const
  * (tools.py:446-450, 456-459): dlogit (+)= J^T dstoch.  Used by RSSM.get_dist/get_stoch
  * (networks.py:161-166, 235-239) and the discrete actor (networks.py:713-714). */
 int dv3_onehot_sample_fwd(const float* logit, const float* noise, const unsigned long long* rng_state,
-                          float* onehot, int* idx, long R, int D, float unimix, int mode, void* stream);
+                          unsigned long long rng_offset, float* onehot, int* idx, long R, int D, float unimix,
+                          int mode, void* stream);
+/* rng_offset is added to rng_state's offset for this call (R*D/4+1 counters are consumed): the caller lays
+ * the calls of one update out on disjoint counter ranges and advances rng_state once, so the launch
+ * sequence stays static under hipGraph replay. */
 int dv3_onehot_st_bwd(const float* logit, const float* dstoch, float* dlogit, long R, int D, float unimix,
                       int mode, int accumulate, void* stream);
 /* entropy [R] and log-prob [R] of one-hot x (either output may be NULL), and their backward */
@@ -187,6 +192,15 @@ int dv3_reset_blend(const float* x, long ldx, const float* init, const float* is
 int dv3_reset_blend_bwd(const float* dout, long ldo, const float* is_first, float* dx, long ldx, float* dinit,
                         int B, int n, void* stream);
 
+/* One-launch forms for an observe step: the three blends (stoch/deter against the learned initial state,
+ * action against zero; prev_* NULL = zeros for the first step), and their backward with the carry folded
+ * in: gs_prev += dsin*(1-m), gd_prev += ddin*(1-m) (NULL on the first step), dstoch0/ddeter0 += sum_b (.)*m. */
+int dv3_obs_blend(const float* prev_stoch, const float* init_stoch, const float* prev_deter, const float* init_deter,
+                  const float* action, const float* is_first, float* out_stoch, float* out_deter, float* out_action,
+                  int B, int SD, int De, int A, void* stream);
+int dv3_obs_blend_bwd(const float* dsin, const float* ddin, const float* is_first, float* gs_prev, float* gd_prev,
+                      float* dstoch0, float* ddeter0, int B, int SD, int De, void* stream);
+
 /* ---- optimizer -- tools.Optimizer.__call__ (tools.py:760-776) on a flat fp32 bucket ----------------
  * state[0] = step count, state[1] = sum of squares accumulator, state[2] = last grad norm.
  * dv3_sumsq_accumulate adds sum(x^2) into *out (x 16-byte aligned).  dv3_adam_step clips by
@@ -201,7 +215,8 @@ int dv3_axpby(const float* x, float* y, long n, float a, float b, void* stream);
 int dv3_rng_advance(unsigned long long* rng_state, unsigned long long increment, void* stream);
 /* out[n] ~ N(0,1) from Philox(rng_state) -- the actor's rsample noise when none is injected
  * (torch.distributions.utils._standard_normal behind networks.py:697-699); consumes ceil(n/4) counters. */
-int dv3_fill_normal(float* out, long n, const unsigned long long* rng_state, void* stream);
+int dv3_fill_normal(float* out, long n, const unsigned long long* rng_state, unsigned long long rng_offset,
+                    void* stream);
 
 #ifdef __cplusplus
 }

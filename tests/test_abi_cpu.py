@@ -46,7 +46,7 @@ def test_argument_rejection_happens_before_any_launch():
     lib = _lib.load()
     assert lib.dv3_gemm_f32(0, 1, 4, 4, 4, None, 4, None, 0, 0, None, 4, None, 4, None, 0, -1, None) == 10001
     assert lib.dv3_ln_act_fwd(None, 0, None, None, None, 0, None, None, 4, 4096, 1, 0, None) == 10001
-    assert lib.dv3_onehot_sample_fwd(None, None, None, None, None, 4, 128, 0.01, 0, None) == 10001
+    assert lib.dv3_onehot_sample_fwd(None, None, None, 0, None, None, 4, 128, 0.01, 0, None) == 10001
     assert lib.dv3_gemm_f32(0, 1, 0, 4, 4, None, 4, None, 0, 0, None, 4, None, 4, None, 0, -1, None) == 0  # empty
 
 

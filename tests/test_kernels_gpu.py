@@ -54,10 +54,12 @@ GEMM_SHAPES = [
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
 def test_gemm_nt_bias(ops, M, N, K, tile):
     if M * N * K > 5e9 and tile in (1, 2):
         pytest.skip("large shape: default tile only")
+    if tile == 3 and M > 32:
+        pytest.skip("skinny path is for M <= 32")
     g = torch.Generator().manual_seed(M * 31 + N * 7 + K)
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -67,7 +69,8 @@ def test_gemm_nt_bias(ops, M, N, K, tile):
     assert_close(C, A @ W.t() + b, what=f"gemm_nt {M}x{N}x{K} tile {tile}")
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 1030, 512), (16, 1024, 1536), (77, 45, 130), (1024, 512, 255)])
+@pytest.mark.parametrize("M,N,K", [(1024, 1030, 512), (16, 1024, 1536), (77, 45, 130), (1024, 512, 255),
+                                   (16, 512, 1536), (3, 19, 37), (32, 1030, 512), (1, 512, 1024), (24, 6, 512)])
 def test_gemm_nn_dgrad(ops, M, N, K):
     g = torch.Generator().manual_seed(1)
     dY = torch.randn(M, K, generator=g)
@@ -89,7 +92,8 @@ def test_gemm_tn_wgrad_accumulate(ops, rows, Nout, Kin):
 
 
 @pytest.mark.parametrize("M,K1,K2,N", [(1024, 1024, 6, 512), (1024, 512, 512, 1536), (16, 512, 4096, 512),
-                                       (48, 16, 3, 16), (9, 64, 5, 33)])
+                                       (48, 16, 3, 16), (9, 64, 5, 33), (16, 1024, 6, 512), (16, 512, 512, 1536),
+                                       (3, 16, 3, 16), (32, 48, 7, 20)])
 def test_gemm_two_segment_concat(ops, M, K1, K2, N):
     """[A | A2] @ W^T == torch.cat([A, A2], -1) @ W^T, including row-strided views."""
     g = torch.Generator().manual_seed(3)
@@ -240,16 +244,20 @@ def test_onehot_sample_philox_is_a_categorical_sampler(ops):
     """In-kernel RNG path: empirical frequencies follow p_hat (chi-square style bound)."""
     D, R = 8, 1 << 18
     logit = torch.tensor([0.0, 1.0, -1.0, 2.0, 0.5, -2.0, 0.0, 1.5]).repeat(R, 1).cuda()
-    st = torch.tensor([1234, 0], dtype=torch.int64).cuda()
+    st = ops.RngStream(torch.device("cuda"), 1234)
     out = torch.empty(R, D).cuda()
-    ops.onehot_sample(logit, out, rng_state=st, unimix=0.01)
+    ops.onehot_sample(logit, out, rng=st, unimix=0.01)
     freq = out.mean(0).cpu()
     p = F.softmax(logit[0].cpu(), -1) * 0.99 + 0.01 / D
     assert (freq - p).abs().max().item() < 5e-3
     out2 = torch.empty(R, D).cuda()
-    ops.rng_advance(st, R * D // 4 + 1)
-    ops.onehot_sample(logit, out2, rng_state=st, unimix=0.01)
+    ops.onehot_sample(logit, out2, rng=st, unimix=0.01)  # next counter range of the same stream
     assert (out != out2).any()
+    st.commit()
+    assert st.state[1].item() == 2 * (R * D // 4 + 1) and st.cursor == 0
+    z = torch.empty(1 << 20).cuda()
+    ops.fill_normal(z, st)
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1.0) < 5e-3
 
 
 @pytest.mark.parametrize("rows,S,D", [(1024, 32, 32), (18, 4, 4), (7, 3, 5)])
@@ -440,6 +448,26 @@ def test_reset_blend_fwd_bwd(ops):
     ops.reset_blend_bwd(dev(go), dev(first), dx, di)
     assert_close(dx, x.grad, what="dx")
     assert_close(di, init.grad, what="dinit")
+    # fused observe-step form
+    SD, De, A = 64, 40, 6
+    ps, pd, ac = torch.randn(B, SD, generator=g), torch.randn(B, De, generator=g), torch.randn(B, A, generator=g)
+    s0, d0 = torch.randn(SD, generator=g), torch.randn(De, generator=g)
+    os_, od_, oa_ = torch.empty(B, SD).cuda(), torch.empty(B, De).cuda(), torch.empty(B, A).cuda()
+    ops.obs_blend(dev(ps), dev(s0), dev(pd), dev(d0), dev(ac), dev(first), os_, od_, oa_)
+    m = first[:, None]
+    assert_close(os_, ps * (1 - m) + s0 * m, what="blend s")
+    assert_close(od_, pd * (1 - m) + d0 * m, what="blend d")
+    assert_close(oa_, ac * (1 - m), what="blend a")
+    ops.obs_blend(None, dev(s0), None, dev(d0), dev(ac), torch.ones(B).cuda(), os_, od_, oa_)
+    assert_close(os_, s0.expand(B, SD), what="blend init")
+    gsp, gdp = torch.randn(B, SD, generator=g), torch.randn(B, De, generator=g)
+    dsn, ddn = torch.randn(B, SD, generator=g), torch.randn(B, De, generator=g)
+    gsd, gdd, a0, b0 = dev(gsp.clone()), dev(gdp.clone()), torch.zeros(SD).cuda(), torch.zeros(De).cuda()
+    ops.obs_blend_bwd(dev(dsn), dev(ddn), dev(first), gsd, gdd, a0, b0)
+    assert_close(gsd, gsp + dsn * (1 - m), what="carry s")
+    assert_close(gdd, gdp + ddn * (1 - m), what="carry d")
+    assert_close(a0, (dsn * m).sum(0), what="ds0")
+    assert_close(b0, (ddn * m).sum(0), what="dd0")
 
 
 def test_adam_clip_matches_oracle(ops):
@@ -559,6 +587,14 @@ def test_layout_helpers(ops):
     assert_close(out, m.sum(0), what="colsum")
     ops.colsum(dev(m), out, accumulate=True)
     assert_close(out, 2 * m.sum(0), what="colsum acc")
+    narrow = torch.randn(70000, 3, generator=g)
+    o3 = torch.empty(3).cuda()
+    ops.colsum(dev(narrow), o3)
+    assert_close(o3, narrow.sum(0), tol=3e-4, what="colsum narrow")
+    one = torch.randn(15360, 1, generator=g)
+    o1 = torch.zeros(1).cuda()
+    ops.colsum(dev(one), o1, accumulate=True)
+    assert_close(o1, one.sum(0), tol=3e-4, what="colsum 1 col")
     small = torch.randn(16, 6, generator=g)
     o2 = torch.empty(6).cuda()
     ops.colsum(dev(small), o2)
