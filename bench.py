@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
+    ap.add_argument("--by-shape", action="store_true", help="roofline leg: key GEMM launches by (M,N,K) too")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,6 +173,7 @@ def main():
     # ---- roofline leg: per-launch HIP-event timing of one more (eager) update on the launch stream
     roofline = None
     if rank == 0:
+        ops.PROFILE.by_shape = args.by_shape
         ops.PROFILE.start()
         runner.step(data, eager=True)
         prof = ops.PROFILE.stop()
@@ -188,7 +190,7 @@ def main():
                                          "gflop_per_update": tot_fl / 1e9, "ms_per_update": tot_ms},
                     "by_kernel": {k: {"ms": round(v["ms"], 3), "n": v["launches"],
                                       "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
-                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:16]}}
+                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:(40 if args.by_shape else 16)]}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

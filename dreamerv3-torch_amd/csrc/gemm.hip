@@ -27,6 +27,7 @@ struct GemmParams {
   int accumulate;
   int vecA, vecB;
   int tiles_m, tiles_n;
+  int splits, kchunk;  // split-K over workgroups (accumulating GEMMs only: partial sums land with atomics)
 };
 
 template <class TS, bool TA, bool TB>
@@ -39,14 +40,18 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
   DenseOperand<!TA> aop{p.A, p.A2, p.lda, p.lda2, p.M, p.K, p.K1, p.vecA != 0};
   DenseOperand<TB> bop{p.B, nullptr, p.ldb, 0, p.N, p.K, p.K, p.vecB != 0};
 
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, tiles * p.splits);
+  const int wg = id % tiles, split = id / tiles;
   // consecutive workgroups walk N fastest: neighbours share the A row panel in L2
   const int m0 = (wg / p.tiles_n) * TS::BM;
   const int n0 = (wg % p.tiles_n) * TS::BN;
+  const int kb = split * p.kchunk;
+  const int ke = (p.splits > 1) ? min(p.K, kb + p.kchunk) : p.K;
 
   f32x16 acc[TS::TM][TS::TN];
-  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, 0, p.K, lds, acc);
+  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, kb, ke, lds, acc);
+  if (kb >= ke) return;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -58,15 +63,15 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
     for (int b = 0; b < TS::TN; ++b) {
       const int n = n0 + (wn * TS::TN + b) * 32 + col_l;
       if (n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+      const float bv = (p.bias && split == 0) ? p.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wm * TS::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < p.M) {
           float* c = p.C + (long)m * p.ldc + n;
-          float v = acc[a][b][r] + bv;
-          if (p.accumulate) v += *c;
-          *c = v;
+          const float v = acc[a][b][r] + bv;
+          if (p.splits > 1) atomicAdd(c, v);
+          else *c = p.accumulate ? (*c + v) : v;
         }
       }
     }
@@ -198,7 +203,23 @@ static hipError_t launch_ts(const GemmParams& p0, int transA, int transB, hipStr
   GemmParams p = p0;
   p.tiles_m = (p.M + TS::BM - 1) / TS::BM;
   p.tiles_n = (p.N + TS::BN - 1) / TS::BN;
-  dim3 grid(p.tiles_m * p.tiles_n), block(kThreads);
+  // accumulating GEMMs with a long reduction and few output tiles (weight gradients: K = rows of the
+  // batch) are split over K so that the grid covers the chip; partial sums are added atomically
+  const int tiles = p.tiles_m * p.tiles_n;
+  p.splits = 1;
+  p.kchunk = p.K;
+  if (p.accumulate && !p.A2 && tiles < 192 && p.K >= 8 * TS::BK) {
+    int want = (384 + tiles - 1) / tiles;
+    const int maxs = p.K / (4 * TS::BK);
+    if (want > maxs) want = maxs;
+    if (want > 1) {
+      int chunk = (p.K + want - 1) / want;
+      chunk = ((chunk + TS::BK - 1) / TS::BK) * TS::BK;
+      p.kchunk = chunk;
+      p.splits = (p.K + chunk - 1) / chunk;
+    }
+  }
+  dim3 grid(tiles * p.splits), block(kThreads);
   if (!transA && transB) hipLaunchKernelGGL((gemm_kernel<TS, false, true>), grid, block, 0, s, p);
   else if (!transA && !transB) hipLaunchKernelGGL((gemm_kernel<TS, false, false>), grid, block, 0, s, p);
   else if (transA && !transB) hipLaunchKernelGGL((gemm_kernel<TS, true, false>), grid, block, 0, s, p);
@@ -212,7 +233,7 @@ using T32x128 = TileShape<1, 4, 1, 1, 32>;  // 32 x 128, BK 32 (few rows: the ob
 
 // Pick the tile that minimises (waves of workgroups over 256 CUs) x (MFMAs per wave per k-step).
 static int pick_tile(int M, int N) {
-  if (M <= 32) return 2;
+  if (M <= 32) return 2;  // (the Python wrapper routes M <= 32, transA = 0 to the skinny kernel instead)
   auto cost = [&](int bm, int bn, int per_wave) {
     long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     return ((tiles + 255) / 256) * per_wave;

@@ -269,6 +269,318 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
   }
 }
 
+
+// ================================================================================================
+// Vectorised forms (16 bytes per lane per access).  Used whenever N % 4 == 0 and the tensor is plain
+// row-major; the scalar kernels above remain for ragged widths and the (C,H,W)-flatten addressing.
+// A row is owned by LPR lanes; lane l holds float4 chunks l + LPR*v, v < NV (columns 4*(l+LPR*v)..+3).
+// ================================================================================================
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ float hsum(f4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void ln_act_fwd_vec_kernel(const float* __restrict__ x, long ldx,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ y,
+                                                             long ldy, float* __restrict__ mean_out,
+                                                             float* __restrict__ rstd_out, long R, int N, int act) {
+  constexpr int RPB = 256 / LPR;
+  const int sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  f4 g[NV], b[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = 4 * (l + LPR * v);
+    const bool ok = c < N;
+    g[v] = ok ? *reinterpret_cast<const f4u*>(gamma + c) : (f4){0.f, 0.f, 0.f, 0.f};
+    b[v] = ok ? *reinterpret_cast<const f4u*>(beta + c) : (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float inv_n = 1.f / (float)N;
+  for (long r = (long)blockIdx.x * RPB + sub; r < R; r += (long)gridDim.x * RPB) {
+    f4 xv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = 4 * (l + LPR * v);
+      xv[v] = (c < N) ? *reinterpret_cast<const f4u*>(x + r * ldx + c) : (f4){0.f, 0.f, 0.f, 0.f};
+      s += hsum(xv[v]);
+    }
+    const float mean = group_sum<LPR>(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (4 * (l + LPR * v) < N) {
+        const f4 d = xv[v] - mean;
+        q += hsum(d * d);
+      }
+    }
+    const float rstd = rsqrtf(group_sum<LPR>(q) * inv_n + kLnEps);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = 4 * (l + LPR * v);
+      if (c < N) {
+        f4 z = (xv[v] - mean) * rstd * g[v] + b[v];
+        if (act) {
+          z.x = siluf_(z.x); z.y = siluf_(z.y); z.z = siluf_(z.z); z.w = siluf_(z.w);
+        }
+        *reinterpret_cast<f4u*>(y + r * ldy + c) = z;
+      }
+    }
+    if (l == 0) {
+      if (mean_out) mean_out[r] = mean;
+      if (rstd_out) rstd_out[r] = rstd;
+    }
+  }
+}
+
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void ln_act_bwd_vec_kernel(const float* __restrict__ dy, long lddy,
+                                                             const float* __restrict__ x, long ldx,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mean_in,
+                                                             const float* __restrict__ rstd_in,
+                                                             float* __restrict__ dx, long lddx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             long R, int N, int act, int accumulate_dx) {
+  constexpr int RPB = 256 / LPR;
+  const int sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  __shared__ float red[2][64 * kMaxV];
+  for (int c = threadIdx.x; c < N; c += 256) {
+    red[0][c] = 0.f;
+    red[1][c] = 0.f;
+  }
+  __syncthreads();
+  f4 g[NV], b[NV], pg[NV], pb[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = 4 * (l + LPR * v);
+    const bool ok = c < N;
+    g[v] = ok ? *reinterpret_cast<const f4u*>(gamma + c) : (f4){0.f, 0.f, 0.f, 0.f};
+    b[v] = ok ? *reinterpret_cast<const f4u*>(beta + c) : (f4){0.f, 0.f, 0.f, 0.f};
+    pg[v] = (f4){0.f, 0.f, 0.f, 0.f};
+    pb[v] = (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float inv_n = 1.f / (float)N;
+  for (long r = (long)blockIdx.x * RPB + sub; r < R; r += (long)gridDim.x * RPB) {
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    f4 xh[NV], dxh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = 4 * (l + LPR * v);
+      xh[v] = (f4){0.f, 0.f, 0.f, 0.f};
+      dxh[v] = (f4){0.f, 0.f, 0.f, 0.f};
+      if (c < N) {
+        const f4 xhat = (*reinterpret_cast<const f4u*>(x + r * ldx + c) - mean) * rstd;
+        f4 dz = *reinterpret_cast<const f4u*>(dy + r * lddy + c);
+        if (act) {
+          const f4 z = xhat * g[v] + b[v];
+          dz.x *= dsiluf_(z.x); dz.y *= dsiluf_(z.y); dz.z *= dsiluf_(z.z); dz.w *= dsiluf_(z.w);
+        }
+        pg[v] += dz * xhat;
+        pb[v] += dz;
+        xh[v] = xhat;
+        dxh[v] = dz * g[v];
+        s1 += hsum(dxh[v]);
+        s2 += hsum(dxh[v] * xhat);
+      }
+    }
+    s1 = group_sum<LPR>(s1) * inv_n;
+    s2 = group_sum<LPR>(s2) * inv_n;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = 4 * (l + LPR * v);
+      if (c < N) {
+        f4 d = (dxh[v] - s1 - xh[v] * s2) * rstd;
+        f4u* o = reinterpret_cast<f4u*>(dx + r * lddx + c);
+        if (accumulate_dx) d += *o;
+        *o = d;
+      }
+    }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = 4 * (l + LPR * v);
+      if (c < N) {
+        atomicAdd(&red[0][c], pg[v].x); atomicAdd(&red[0][c + 1], pg[v].y);
+        atomicAdd(&red[0][c + 2], pg[v].z); atomicAdd(&red[0][c + 3], pg[v].w);
+        atomicAdd(&red[1][c], pb[v].x); atomicAdd(&red[1][c + 1], pb[v].y);
+        atomicAdd(&red[1][c + 2], pb[v].z); atomicAdd(&red[1][c + 3], pb[v].w);
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += 256) {
+      atomicAdd(dgamma + c, red[0][c]);
+      atomicAdd(dbeta + c, red[1][c]);
+    }
+  }
+}
+
+// GRU gates, vectorised: De % 256 == 0, NVG = De/256 float4 chunks per gate per lane.  Lane l owns chunks
+// l + 64*v of each gate, so r, c, u of one hidden unit sit in the same lane.  One wave per row, whole row
+// of p (3*De floats) in registers, single pass.
+template <int NVG>
+__global__ __launch_bounds__(256) void gru_fwd_vec_kernel(const float* __restrict__ p, long ldp,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ h,
+                                                          long ldh, float* __restrict__ hn, long ldhn,
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                          int M, int De) {
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const float inv_n = 1.f / (float)(3 * De);
+  for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
+    const float* pr = p + (long)r * ldp;
+    f4 pv[3][NVG];
+    float s = 0.f;
+#pragma unroll
+    for (int gte = 0; gte < 3; ++gte)
+#pragma unroll
+      for (int v = 0; v < NVG; ++v) {
+        pv[gte][v] = *reinterpret_cast<const f4u*>(pr + gte * De + 4 * (l + 64 * v));
+        s += hsum(pv[gte][v]);
+      }
+    const float mean = group_sum<64>(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int gte = 0; gte < 3; ++gte)
+#pragma unroll
+      for (int v = 0; v < NVG; ++v) {
+        const f4 d = pv[gte][v] - mean;
+        q += hsum(d * d);
+      }
+    const float rstd = rsqrtf(group_sum<64>(q) * inv_n + kLnEps);
+#pragma unroll
+    for (int v = 0; v < NVG; ++v) {
+      const int j = 4 * (l + 64 * v);
+      const f4 yr = (pv[0][v] - mean) * rstd * *reinterpret_cast<const f4u*>(gamma + j) + *reinterpret_cast<const f4u*>(beta + j);
+      const f4 yc = (pv[1][v] - mean) * rstd * *reinterpret_cast<const f4u*>(gamma + De + j) + *reinterpret_cast<const f4u*>(beta + De + j);
+      const f4 yu = (pv[2][v] - mean) * rstd * *reinterpret_cast<const f4u*>(gamma + 2 * De + j) + *reinterpret_cast<const f4u*>(beta + 2 * De + j);
+      const f4 hp = *reinterpret_cast<const f4u*>(h + (long)r * ldh + j);
+      f4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float rg = sigmoidf_(yr[e]);
+        const float cg = tanhf(rg * yc[e]);
+        const float ug = sigmoidf_(yu[e] - 1.f);
+        o[e] = ug * cg + (1.f - ug) * hp[e];
+      }
+      *reinterpret_cast<f4u*>(hn + (long)r * ldhn + j) = o;
+    }
+    if (l == 0) {
+      mean_out[r] = mean;
+      rstd_out[r] = rstd;
+    }
+  }
+}
+
+template <int NVG>
+__global__ __launch_bounds__(256) void gru_bwd_vec_kernel(const float* __restrict__ dhn, long lddhn,
+                                                          const float* __restrict__ p, long ldp,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ h,
+                                                          long ldh, const float* __restrict__ mean_in,
+                                                          const float* __restrict__ rstd_in, float* __restrict__ dp,
+                                                          long lddp, float* __restrict__ dh, long lddh,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                          int De, int accumulate_dh) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 3*De block accumulators (dgamma, dbeta)
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int N = 3 * De;
+  float* accg = smem;
+  float* accb = smem + N;
+  if (dgamma) {
+    for (int c = threadIdx.x; c < 2 * N; c += 256) smem[c] = 0.f;
+    __syncthreads();
+  }
+  const float inv_n = 1.f / (float)N;
+  f4 pg[3][NVG], pb[3][NVG];
+#pragma unroll
+  for (int gte = 0; gte < 3; ++gte)
+#pragma unroll
+    for (int v = 0; v < NVG; ++v) {
+      pg[gte][v] = (f4){0.f, 0.f, 0.f, 0.f};
+      pb[gte][v] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+  for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
+    const float* pr = p + (long)r * ldp;
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    f4 xh[3][NVG], dy[3][NVG];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NVG; ++v) {
+      const int j = 4 * (l + 64 * v);
+      f4 gm[3], bt[3];
+#pragma unroll
+      for (int gte = 0; gte < 3; ++gte) {
+        xh[gte][v] = (*reinterpret_cast<const f4u*>(pr + gte * De + j) - mean) * rstd;
+        gm[gte] = *reinterpret_cast<const f4u*>(gamma + gte * De + j);
+        bt[gte] = *reinterpret_cast<const f4u*>(beta + gte * De + j);
+      }
+      const f4 hp = *reinterpret_cast<const f4u*>(h + (long)r * ldh + j);
+      const f4 go = *reinterpret_cast<const f4u*>(dhn + (long)r * lddhn + j);
+      f4 dhd;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float yr = xh[0][v][e] * gm[0][e] + bt[0][e];
+        const float yc = xh[1][v][e] * gm[1][e] + bt[1][e];
+        const float yu = xh[2][v][e] * gm[2][e] + bt[2][e];
+        const float rg = sigmoidf_(yr);
+        const float cg = tanhf(rg * yc);
+        const float ug = sigmoidf_(yu - 1.f);
+        const float g = go[e];
+        const float du = g * (cg - hp[e]) * ug * (1.f - ug);
+        const float drc = g * ug * (1.f - cg * cg);
+        dy[0][v][e] = drc * yc * rg * (1.f - rg);
+        dy[1][v][e] = drc * rg;
+        dy[2][v][e] = du;
+        dhd[e] = g * (1.f - ug);
+      }
+      f4u* o = reinterpret_cast<f4u*>(dh + (long)r * lddh + j);
+      if (accumulate_dh) dhd += *o;
+      *o = dhd;
+#pragma unroll
+      for (int gte = 0; gte < 3; ++gte) {
+        const f4 dxh = dy[gte][v] * gm[gte];
+        s1 += hsum(dxh);
+        s2 += hsum(dxh * xh[gte][v]);
+        pg[gte][v] += dy[gte][v] * xh[gte][v];
+        pb[gte][v] += dy[gte][v];
+        dy[gte][v] = dxh;  // keep dy*gamma for the second pass
+      }
+    }
+    s1 = group_sum<64>(s1) * inv_n;
+    s2 = group_sum<64>(s2) * inv_n;
+#pragma unroll
+    for (int gte = 0; gte < 3; ++gte)
+#pragma unroll
+      for (int v = 0; v < NVG; ++v) {
+        const int j = 4 * (l + 64 * v);
+        *reinterpret_cast<f4u*>(dp + (long)r * lddp + gte * De + j) = (dy[gte][v] - s1 - xh[gte][v] * s2) * rstd;
+      }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int gte = 0; gte < 3; ++gte)
+#pragma unroll
+      for (int v = 0; v < NVG; ++v) {
+        const int c = gte * De + 4 * (l + 64 * v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(accg + c + e, pg[gte][v][e]);
+          atomicAdd(accb + c + e, pb[gte][v][e]);
+        }
+      }
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += 256) {
+      atomicAdd(dgamma + c, accg[c]);
+      atomicAdd(dbeta + c, accb[c]);
+    }
+  }
+}
+
 template <int LPR, int NV>
 static void launch_ln_fwd(const float* x, long ldx, const float* g, const float* b, float* y, long ldy, float* mean,
                           float* rstd, long R, int N, int act, int G, hipStream_t s) {
@@ -317,11 +629,45 @@ static int pick_lpr(int N) {
 
 using namespace dv3;
 
+// (lanes per row, float4 chunks per lane) for the vectorised kernels
+static bool vec_shape(int N, int& lpr, int& nv) {
+  if (N % 4 != 0 || N < 16) return false;
+  const int chunks = N / 4;
+  lpr = 4;
+  while (lpr < 64 && lpr < chunks) lpr <<= 1;
+  nv = (chunks + lpr - 1) / lpr;
+  return nv <= 8;
+}
+#define DV3_LNV_DISPATCH(KERNEL, GRIDCAP, ...)                                                       \
+  do {                                                                                               \
+    int lpr_, nv_;                                                                                   \
+    vec_shape(N, lpr_, nv_);                                                                         \
+    const long rpb_ = 256 / lpr_;                                                                    \
+    long blocks_ = (R + rpb_ - 1) / rpb_;                                                            \
+    if (blocks_ > (GRIDCAP)) blocks_ = (GRIDCAP);                                                    \
+    const dim3 g_((unsigned)blocks_), b_(256);                                                       \
+    if (lpr_ == 4) hipLaunchKernelGGL((KERNEL<4, 1>), g_, b_, 0, s, __VA_ARGS__);                    \
+    else if (lpr_ == 8) hipLaunchKernelGGL((KERNEL<8, 1>), g_, b_, 0, s, __VA_ARGS__);               \
+    else if (lpr_ == 16) hipLaunchKernelGGL((KERNEL<16, 1>), g_, b_, 0, s, __VA_ARGS__);             \
+    else if (lpr_ == 32) hipLaunchKernelGGL((KERNEL<32, 1>), g_, b_, 0, s, __VA_ARGS__);             \
+    else if (nv_ <= 1) hipLaunchKernelGGL((KERNEL<64, 1>), g_, b_, 0, s, __VA_ARGS__);               \
+    else if (nv_ <= 2) hipLaunchKernelGGL((KERNEL<64, 2>), g_, b_, 0, s, __VA_ARGS__);               \
+    else if (nv_ <= 4) hipLaunchKernelGGL((KERNEL<64, 4>), g_, b_, 0, s, __VA_ARGS__);               \
+    else hipLaunchKernelGGL((KERNEL<64, 8>), g_, b_, 0, s, __VA_ARGS__);                             \
+  } while (0)
+
 extern "C" int dv3_ln_act_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy,
                               float* mean, float* rstd, long R, int N, int act, int chw_group, void* stream) {
   if (R <= 0) return 0;
   if (N <= 0 || N > 64 * kMaxV || !x || !y || !gamma || !beta) return DV3_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  {
+    int lpr0, nv0;
+    if (chw_group <= 0 && vec_shape(N, lpr0, nv0)) {
+      DV3_LNV_DISPATCH(ln_act_fwd_vec_kernel, 8192, x, ldx, gamma, beta, y, ldy, mean, rstd, R, N, act);
+      return (int)hipGetLastError();
+    }
+  }
   DV3_LN_DISPATCH(launch_ln_fwd, x, ldx, gamma, beta, y, ldy, mean, rstd, R, N, act, chw_group, s);
   return (int)hipGetLastError();
 }
@@ -334,6 +680,14 @@ extern "C" int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long l
   if (N <= 0 || N > 64 * kMaxV || !x || !dy || !dx || !gamma || !beta || !mean || !rstd) return DV3_ERR_ARG;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return DV3_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  {
+    int lpr0, nv0;
+    if (chw_group <= 0 && vec_shape(N, lpr0, nv0)) {
+      DV3_LNV_DISPATCH(ln_act_bwd_vec_kernel, 2048, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, R,
+                       N, act, accumulate_dx);
+      return (int)hipGetLastError();
+    }
+  }
   DV3_LN_DISPATCH(launch_ln_bwd, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, R, N, act, chw_group,
                   accumulate_dx, s);
   return (int)hipGetLastError();
@@ -345,6 +699,14 @@ extern "C" int dv3_gru_fwd(const float* p, long ldp, const float* gamma, const f
   if (De <= 0 || !p || !gamma || !beta || !h || !h_new || !mean || !rstd) return DV3_ERR_ARG;
   int blocks = (M + 3) / 4;
   if (blocks > 4096) blocks = 4096;
+  if (De % 256 == 0 && De <= 1024) {
+    hipStream_t s = (hipStream_t)stream;
+    if (De == 256) hipLaunchKernelGGL((gru_fwd_vec_kernel<1>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De);
+    else if (De == 512) hipLaunchKernelGGL((gru_fwd_vec_kernel<2>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De);
+    else if (De == 768) hipLaunchKernelGGL((gru_fwd_vec_kernel<3>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De);
+    else hipLaunchKernelGGL((gru_fwd_vec_kernel<4>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(gru_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, ldp, gamma, beta, h, ldh,
                      h_new, ldhn, mean, rstd, M, De);
   return (int)hipGetLastError();
@@ -361,6 +723,18 @@ extern "C" int dv3_gru_bwd(const float* dh_new, long lddhn, const float* p, long
   if (shmem > 150 * 1024) return DV3_ERR_ARG;  // De <= 2048; larger cells need the block-per-row variant
   int blocks = (M + 3) / 4;
   if (blocks > 256) blocks = 256;
+  if (De % 256 == 0 && De <= 1024) {
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sh = (size_t)2 * 3 * De * sizeof(float);
+#define DV3_GRUB(NVG_) hipLaunchKernelGGL((gru_bwd_vec_kernel<NVG_>), dim3(blocks), dim3(256), sh, s, dh_new, lddhn, p, ldp, \
+                                          gamma, beta, h, ldh, mean, rstd, dp, lddp, dh, lddh, dgamma, dbeta, M, De, accumulate_dh)
+    if (De == 256) DV3_GRUB(1);
+    else if (De == 512) DV3_GRUB(2);
+    else if (De == 768) DV3_GRUB(3);
+    else DV3_GRUB(4);
+#undef DV3_GRUB
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(gru_bwd_kernel, dim3(blocks), dim3(256), shmem, (hipStream_t)stream, dh_new, lddhn, p, ldp, gamma,
                      beta, h, ldh, mean, rstd, dp, lddp, dh, lddh, dgamma, dbeta, M, De, accumulate_dh);
   return (int)hipGetLastError();

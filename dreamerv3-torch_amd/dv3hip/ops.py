@@ -51,6 +51,7 @@ class _Profile:
 
     def __init__(self):
         self.enabled = False
+        self.by_shape = False
         self.records = {}  # key -> [launches, flops, bytes, [event pairs]]
 
     def start(self):
@@ -137,7 +138,8 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
             tile = 3
     _call("dv3_gemm_f32", int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(A2), lda2, K1, _ptr(B), ldb,
           _ptr(C), ldc, _ptr(bias), int(accumulate), tile, s,
-          key=f"gemm_kernel<{_TILE_NAMES[tile]},tA={int(transA)},tB={int(transB)}>", flops=2.0 * M * N * K,
+          key=(f"gemm_kernel<{_TILE_NAMES[tile]},tA={int(transA)},tB={int(transB)}>"
+               + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else "")), flops=2.0 * M * N * K,
           nbytes=4.0 * (M * K + N * K + M * N))
     return C
 
