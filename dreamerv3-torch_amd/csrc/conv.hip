@@ -300,7 +300,8 @@ __global__ __launch_bounds__(kThreads) void conv_s2_kernel(ConvParams p) {
   const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
   const int m0 = (wg / p.tiles_n) * TS::BM, n0 = (wg % p.tiles_n) * TS::BN;
   f32x16 acc[TS::TM][TS::TN];
-  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, 0, aop.K, lds, acc);
+  bool owner;
+  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, 0, aop.K, lds, acc, owner);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave / TS::WN, wn = wave % TS::WN, col_l = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -332,7 +333,8 @@ __global__ __launch_bounds__(kThreads) void convT_s2_kernel(ConvParams p) {
   const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
   const int m0 = (wg / p.tiles_n) * TS::BM, n0 = (wg % p.tiles_n) * TS::BN;
   f32x16 acc[TS::TM][TS::TN];
-  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, 0, aop.K, lds, acc);
+  bool owner;
+  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, 0, aop.K, lds, acc, owner);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave / TS::WN, wn = wave % TS::WN, col_l = lane & 31, h = lane >> 5;
   const int OH = 2 * p.H, OW = 2 * p.W;
@@ -384,7 +386,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
   long ke = kb + p.chunk;
   if (ke > rows) ke = rows;
   f32x16 acc[TS::TM][TS::TN];
-  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, (int)kb, (int)ke, lds, acc);
+  bool owner;
+  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, (int)kb, (int)ke, lds, acc, owner);
   if (kb >= ke) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave / TS::WN, wn = wave % TS::WN, col_l = lane & 31, h = lane >> 5;

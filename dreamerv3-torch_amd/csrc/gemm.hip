@@ -50,11 +50,12 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
   const int ke = (p.splits > 1) ? min(p.K, kb + p.kchunk) : p.K;
 
   f32x16 acc[TS::TM][TS::TN];
-  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, kb, ke, lds, acc);
-  if (kb >= ke) return;
+  bool owner;
+  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, kb, ke, lds, acc, owner);
+  if (kb >= ke || !owner) return;
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = (tid >> 6) % (TS::WM * TS::WN), lane = tid & 63;
   const int wm = wave / TS::WN, wn = wave % TS::WN;
   const int col_l = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -229,17 +230,19 @@ static hipError_t launch_ts(const GemmParams& p0, int transA, int transB, hipStr
 
 using T128 = TileShape<2, 2, 2, 2, 16>;    // 128 x 128, BK 16
 using T64 = TileShape<2, 2, 1, 1, 32>;     // 64 x 64,  BK 32
+using T128K32 = TileShape<2, 2, 2, 2, 32>;  // 128 x 128, BK 32 (64 MFMAs per wave per barrier)
+using T64K64 = TileShape<2, 2, 1, 1, 64>;   // 64 x 64,  BK 64 (32 MFMAs per wave per barrier)
+using T32x64S = TileShape<1, 2, 1, 1, 64, 2>;  // 32 x 64, BK 64, K split over 2 wave-groups (small M*N)
 using T32x128 = TileShape<1, 4, 1, 1, 32>;  // 32 x 128, BK 32 (few rows: the observe scan, M = batch)
 
-// Pick the tile that minimises (waves of workgroups over 256 CUs) x (MFMAs per wave per k-step).
-static int pick_tile(int M, int N) {
-  if (M <= 32) return 2;  // (the Python wrapper routes M <= 32, transA = 0 to the skinny kernel instead)
-  auto cost = [&](int bm, int bn, int per_wave) {
-    long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-    return ((tiles + 255) / 256) * per_wave;
-  };
-  const long c128 = cost(128, 128, 4), c64 = cost(64, 64, 1);
-  return (c64 < c128) ? 1 : 0;
+// Tile choice when the caller passes tile = -1 (the Python wrapper normally decides, same rule).
+static int pick_tile(int M, int N, int accumulate) {
+  if (M <= 32) return 2;
+  const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+  if (t64 <= 512 && !accumulate) return 6;
+  const long c128 = (((long)((M + 127) / 128) * ((N + 127) / 128)) + 255) / 256 * 4;
+  const long c64 = (t64 + 255) / 256;
+  return (c64 < c128) ? 1 : 4;
 }
 
 }  // namespace dv3
@@ -262,7 +265,8 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   }
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
-  const int t = (tile >= 0 && tile <= 3) ? tile : pick_tile(M, N);
+  int t = (tile >= 0 && tile <= 6) ? tile : pick_tile(M, N, accumulate);
+  if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6)) t = 1;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
   if (t == 3) {
@@ -279,6 +283,9 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
     return (int)hipGetLastError();
   }
   if (t == 0) e = launch_ts<T128>(p, transA, transB, s);
+  else if (t == 4) e = launch_ts<T128K32>(p, transA, transB, s);
+  else if (t == 5) e = launch_ts<T64K64>(p, transA, transB, s);
+  else if (t == 6) e = launch_ts<T32x64S>(p, transA, transB, s);
   else if (t == 1) e = launch_ts<T64>(p, transA, transB, s);
   else e = launch_ts<T32x128>(p, transA, transB, s);
   return (int)e;

@@ -60,7 +60,7 @@ struct DenseTile {
   // LDS row stride.  k-contiguous sources are transposed on the way in with ds_write_b32; the pad
   // spreads the BK/4 column chunks of a 32-lane group over the 32 banks (pad = 8/CH).  Row-contiguous
   // sources are written with ds_write_b128 and need a 16-byte multiple.
-  static constexpr int LD = ROWS + (KCONTIG ? (BK == 16 ? 2 : 1) : 4);
+  static constexpr int LD = ROWS + (KCONTIG ? (BK == 16 ? 2 : 1) : 4);  // BK 16 -> +2, BK 32/64 -> +1 (<= 2-way)
   f32x4 v[kVecs];
   float mask[kVecs];  // 1 for rows inside the matrix, 0 past its edge (KCONTIG tiles; loop-invariant)
 
@@ -194,11 +194,15 @@ struct DenseTile {
 // ---------------------------------------------------------------------------------------------
 // Tile shape: 4 waves as WM x WN, each wave TM x TN MFMA tiles of 32x32.
 // ---------------------------------------------------------------------------------------------
-template <int WM_, int WN_, int TM_, int TN_, int BK_>
+// WK > 1: the waves also split K -- wave-group wk takes k-steps [wk*BK/2/WK, (wk+1)*BK/2/WK) of every staged
+// tile and the partial accumulators are reduced through LDS at the end.  Twice the workgroups for the same
+// output: fills the chip when M*N is small (M = 1024 rows of imagination against N = 512 columns).
+template <int WM_, int WN_, int TM_, int TN_, int BK_, int WK_ = 1>
 struct TileShape {
-  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, BK = BK_;
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, BK = BK_, WK = WK_;
   static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(WM * WN * WK == 4, "4 waves per workgroup");
+  static_assert((BK / 2) % WK == 0, "k-steps must split evenly over the wave-groups");
   static constexpr int lds_floats = 2 * BK * (BM + 4) + 2 * BK * (BN + 4);  // upper bound on any pad
 };
 
@@ -209,11 +213,19 @@ struct TileShape {
 // Shape of the loop: all K-tiles that need no k guard run in a branch-free steady state (global loads of
 // tile t+1 issued, every LDS fragment of tile t read up front, MFMAs, LDS store, one barrier); the at most
 // one guarded tail tile is peeled off behind it.
+// A wave with a single 32x32 output tile would issue every MFMA into ONE accumulator: a dependent chain
+// that exposes the MFMA result latency.  Such shapes alternate k-steps between two accumulators (summed
+// once at the end), so consecutive MFMAs are independent.
+template <class TS>
+struct AccSplit {
+  static constexpr int N = (TS::TM * TS::TN == 1) ? 2 : 1;
+};
+
 template <class TS, class ATile, class BTile>
 __device__ __forceinline__ void mfma_tile_compute(const float* as, const float* bs, int h,
-                                                  f32x16 (&acc)[TS::TM][TS::TN]) {
+                                                  f32x16 (&acc)[AccSplit<TS>::N][TS::TM][TS::TN]) {
   constexpr int BK = TS::BK, LDA = ATile::LD, LDB = BTile::LD;
-  constexpr int NS = BK / 2;
+  constexpr int NS = BK / 2 / TS::WK;  // k-steps of this wave-group (as/bs already point at its first one)
   float av[NS][TS::TM], bv[NS][TS::TN];
   // every LDS fragment of the tile is requested before the first MFMA (pinned with sched_barrier: left
   // alone, hipcc sinks each pair of ds_reads next to its MFMAs and waits lgkmcnt(0) 8x per tile)
@@ -231,20 +243,26 @@ __device__ __forceinline__ void mfma_tile_compute(const float* as, const float* 
     for (int a = 0; a < TS::TM; ++a)
 #pragma unroll
       for (int b = 0; b < TS::TN; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], bv[s][b], acc[a][b], 0, 0, 0);
+        acc[s % AccSplit<TS>::N][a][b] =
+            __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], bv[s][b], acc[s % AccSplit<TS>::N][a][b], 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
 }
 
 template <class TS, class ATile, class BTile, class AOp, class BOp>
 __device__ __forceinline__ void mfma_mainloop(const AOp& aop, const BOp& bop, int m0, int n0, int kbeg,
-                                              int kend, float* lds, f32x16 (&acc)[TS::TM][TS::TN]) {
+                                              int kend, float* lds, f32x16 (&out)[TS::TM][TS::TN],
+                                              bool& owner) {
+  f32x16 acc[AccSplit<TS>::N][TS::TM][TS::TN];
+  owner = true;
   constexpr int BM = TS::BM, BK = TS::BK;
   constexpr int LDA = ATile::LD, LDB = BTile::LD;
   float* As = lds;
   float* Bs = lds + 2 * BK * (BM + 4);
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int wm = wave / TS::WN, wn = wave % TS::WN;
+  const int wk = wave / (TS::WM * TS::WN);
+  const int wmn = wave % (TS::WM * TS::WN);
+  const int wm = wmn / TS::WN, wn = wmn % TS::WN;
   const int i = lane & 31, h = lane >> 5;
 
 #pragma unroll
@@ -252,7 +270,11 @@ __device__ __forceinline__ void mfma_mainloop(const AOp& aop, const BOp& bop, in
 #pragma unroll
     for (int b = 0; b < TS::TN; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        out[a][b][r] = 0.f;
+#pragma unroll
+        for (int z = 0; z < AccSplit<TS>::N; ++z) acc[z][a][b][r] = 0.f;
+      }
 
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk <= 0) return;
@@ -276,7 +298,9 @@ __device__ __forceinline__ void mfma_mainloop(const AOp& aop, const BOp& bop, in
   bt.store(Bs, tid);
   __syncthreads();
   int cur = 0;
-  const int aoff = wm * TS::TM * 32 + i, boff = wn * TS::TN * 32 + i;
+  // + the first k-step of this wave-group inside a staged tile
+  const int aoff = wm * TS::TM * 32 + i + wk * (BK / TS::WK) * LDA;
+  const int boff = wn * TS::TN * 32 + i + wk * (BK / TS::WK) * LDB;
   for (int t = 0; t + 1 < n_full; ++t) {
     at.load_full(aop, m0, kbeg + (t + 1) * BK, tid);
     bt.load_full(bop, n0, kbeg + (t + 1) * BK, tid);
@@ -298,6 +322,38 @@ __device__ __forceinline__ void mfma_mainloop(const AOp& aop, const BOp& bop, in
     cur ^= 1;
   }
   mfma_tile_compute<TS, ATile, BTile>(As + cur * BK * LDA + aoff, Bs + cur * BK * LDB + boff, h, acc);
+#pragma unroll
+  for (int a = 0; a < TS::TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TS::TN; ++b) {
+      out[a][b] = acc[0][a][b];
+#pragma unroll
+      for (int z = 1; z < AccSplit<TS>::N; ++z) out[a][b] += acc[z][a][b];
+    }
+  if constexpr (TS::WK > 1) {
+    // reduce the wave-groups' partial tiles through LDS (the staging buffers are free now)
+    static_assert(TS::WK == 2, "reduction written for two wave-groups");
+    __syncthreads();
+    float* red = lds + (long)wmn * (TS::TM * TS::TN * 16 * 64);
+    if (wk == 1) {
+#pragma unroll
+      for (int a = 0; a < TS::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TS::TN; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((a * TS::TN + b) * 16 + r) * 64 + lane] = out[a][b][r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int a = 0; a < TS::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TS::TN; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[a][b][r] += red[((a * TS::TN + b) * 16 + r) * 64 + lane];
+    }
+    owner = (wk == 0);
+  }
 }
 
 }  // namespace dv3

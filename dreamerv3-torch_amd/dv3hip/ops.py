@@ -86,17 +86,21 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
     _lib.check(getattr(lib, fn_name)(*args), fn_name)
 
 
-_TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16"}
+_TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2"}
 
 
-def pick_gemm_tile(M: int, N: int) -> int:
-    """Same rule as csrc/gemm.hip pick_tile: minimise (waves of workgroups over 256 CUs) x (MFMAs per
-    wave per k-step)."""
+def pick_gemm_tile(M: int, N: int, wgrad: bool = False) -> int:
+    """Tile choice (mirrors csrc/gemm.hip): small outputs take the 32x64 tile with the K split inside the
+    workgroup (fills the 256 CUs when M*N is small); otherwise minimise (waves of workgroups over 256 CUs)
+    x (MFMAs per wave per k-step) between 64x64 and 128x128."""
     if M <= 32:
         return 2
+    t64 = -(-M // 64) * -(-N // 64)
+    if t64 <= 512 and not wgrad:  # weight gradients split K across workgroups instead (long reduction)
+        return 6
     c128 = ((-(-M // 128) * -(-N // 128)) + 255) // 256 * 4
-    c64 = ((-(-M // 64) * -(-N // 64)) + 255) // 256 * 1
-    return 1 if c64 < c128 else 0
+    c64 = (t64 + 255) // 256 * 1
+    return 1 if c64 < c128 else 4
 
 
 # ---------------------------------------------------------------------------------------------
@@ -125,7 +129,7 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         if bias.numel() != N:
             raise ValueError("bias size mismatch")
     s = _stream()
-    if A2 is not None and (K1 % 32) != 0:
+    if A2 is not None and (K1 % (64 if tile in (5, 6) else 32)) != 0:
         # segment edge not on a K-tile boundary: two passes, the second accumulating
         Bv1 = B[:, :K1] if transB else B[:K1]
         Bv2 = B[:, K1:] if transB else B[K1:]
@@ -133,9 +137,11 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         gemm(A2, Bv2, C, transA=False, transB=transB, accumulate=True, tile=tile)
         return C
     if tile < 0:
-        tile = pick_gemm_tile(M, N)
+        tile = pick_gemm_tile(M, N, bool(transA))
         if M <= 32 and not transA:
             tile = 3
+        if tile == 6 and A2 is not None and (K1 % 64) != 0:
+            tile = 1
     _call("dv3_gemm_f32", int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(A2), lda2, K1, _ptr(B), ldb,
           _ptr(C), ldc, _ptr(bias), int(accumulate), tile, s,
           key=(f"gemm_kernel<{_TILE_NAMES[tile]},tA={int(transA)},tB={int(transB)}>"

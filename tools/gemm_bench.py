@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Microbenchmark of dv3_gemm_f32 on the shapes the hot path issues (MI355X only).
+
+    python tools/gemm_bench.py [--reps 50]
+
+Prints, per (shape, layout, tile): average launch time (HIP events around `reps` back-to-back launches)
+and TFLOP/s against the 157.3 TFLOP/s fp32-MFMA peak.  Development aid for csrc/mfma_gemm.h.
+"""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "dreamerv3-torch_amd"))
+import torch  # noqa: E402
+
+from dv3hip import ops  # noqa: E402
+
+SHAPES = [
+    # M, N, K, transA, transB, note
+    (1024, 512, 1536, 0, 1, "actor/head L0 fwd"),
+    (1024, 1536, 1024, 0, 1, "GRU fwd"),
+    (1024, 512, 512, 0, 1, "img_out / L1 fwd"),
+    (1024, 512, 1030, 0, 1, "img_in fwd"),
+    (1024, 1024, 512, 0, 1, "stat layer fwd"),
+    (1024, 512, 1536, 0, 0, "dgrad gru->x"),
+    (1024, 1024, 512, 0, 0, "dgrad"),
+    (15360, 512, 1536, 0, 1, "behaviour head L0"),
+    (14336, 512, 512, 0, 0, "behaviour dgrad"),
+    (512, 512, 14336, 1, 0, "wgrad"),
+    (4096, 4096, 4096, 0, 1, "square 4k"),
+]
+
+
+def bench(M, N, K, tA, tB, tile, reps):
+    dev = "cuda"
+    A = torch.randn((K, M) if tA else (M, K), device=dev)
+    B = torch.randn((N, K) if tB else (K, N), device=dev)
+    C = torch.zeros(M, N, device=dev)
+    acc = bool(tA)
+    for _ in range(3):
+        ops.gemm(A, B, C, transA=bool(tA), transB=bool(tB), tile=tile, accumulate=acc)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        ops.gemm(A, B, C, transA=bool(tA), transB=bool(tB), tile=tile, accumulate=acc)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 1e3 / reps
+    return us, 2.0 * M * N * K / us / 1e6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--tiles", default="0,1")
+    args = ap.parse_args()
+    tiles = [int(t) for t in args.tiles.split(",")]
+    print(f"{'shape':>22s} {'tA tB':>6s} {'tile':>5s} {'us':>9s} {'TFLOP/s':>8s} {'frac':>6s}  note")
+    for M, N, K, tA, tB, note in SHAPES:
+        for t in tiles:
+            if M * N * K > 1e11 and t == 1:
+                continue
+            us, tf = bench(M, N, K, tA, tB, t, args.reps)
+            print(f"{M:6d}x{N:5d}x{K:6d} {tA:3d}{tB:3d} {t:5d} {us:9.1f} {tf:8.1f} {tf / 157.3:6.2f}  {note}")
+
+
+if __name__ == "__main__":
+    main()
