@@ -49,12 +49,12 @@ class UpdateRunner:
             wm.train_fwd_bwd(self._static)
         wm._model_opt.bucket.allreduce()
         with torch.cuda.graph(g2, pool=pool):
-            post, _, m1 = wm.train_opt()
+            post, _, m1 = wm.train_opt(allreduce=False)
             beh.train_fwd_bwd(post)
         beh._actor_opt.bucket.allreduce()
         beh._value_opt.bucket.allreduce()
         with torch.cuda.graph(g3, pool=pool):
-            m2 = beh.train_opt()[-1]
+            m2 = beh.train_opt(allreduce=False)[-1]
         self._graphs = (g1, g2, g3)
         self.last_metrics = {**m1, **m2}
 

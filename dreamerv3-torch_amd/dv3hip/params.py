@@ -19,11 +19,14 @@ _ALIGN = 4  # floats: keep every tensor 16-byte aligned inside the bucket
 
 
 class ParamBucket:
-    def __init__(self, name: str, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, name: str, params: Iterable[torch.nn.Parameter], allow_cpu: bool = False):
+        """allow_cpu: layout + all-reduce logic on CPU tensors (multi-process gloo tests); step() still
+        needs the GPU kernels."""
         self.name = name
         self.params: List[torch.nn.Parameter] = [p for p in params]
         self.flat = None
         self._layout = None
+        self._allow_cpu = allow_cpu
 
     # ------------------------------------------------------------------------------------------
     def _needs_build(self) -> bool:
@@ -40,7 +43,7 @@ class ParamBucket:
         if not self._needs_build():
             return self
         dev = self.params[0].device
-        if dev.type != "cuda":
+        if dev.type != "cuda" and not self._allow_cpu:
             raise RuntimeError(f"ParamBucket {self.name}: parameters must live on the GPU (got {dev}); "
                                "the MI355X hot path has no CPU implementation")
         layout, total = [], 0

@@ -148,10 +148,10 @@ class WorldModel(nn.Module):
         self.train_fwd_bwd(data, noise)
         return self.train_opt()
 
-    def train_opt(self):
+    def train_opt(self, allreduce=True):
         post, context, metrics, loss = self._pending
         metrics = dict(metrics)
-        metrics.update(self._model_opt.finish(loss))
+        metrics.update(self._model_opt.finish(loss, allreduce))
         return post, context, _wrap(metrics)
 
     def train_fwd_bwd(self, data, noise=None):
@@ -473,11 +473,11 @@ class ImagBehavior(nn.Module):
         self.train_fwd_bwd(start, noise)
         return self.train_opt()
 
-    def train_opt(self):
+    def train_opt(self, allreduce=True):
         ret, metrics, losses = self._pending
         metrics = dict(metrics)
-        metrics.update(self._actor_opt.finish(losses[0]))
-        metrics.update(self._value_opt.finish(losses[1]))
+        metrics.update(self._actor_opt.finish(losses[0], allreduce))
+        metrics.update(self._value_opt.finish(losses[1], allreduce))
         return ret + (_wrap(metrics),)
 
     def train_fwd_bwd(self, start, noise=None):

@@ -319,9 +319,16 @@ class Optimizer:
     def begin(self):
         self.bucket.ensure().zero_grad()
 
-    def finish(self, loss):
-        """loss: 0-d device tensor (metric only).  Returns the reference's metric dict with device scalars."""
-        scale = self.bucket.allreduce()
+    def finish(self, loss, allreduce=True):
+        """loss: 0-d device tensor (metric only).  Returns the reference's metric dict with device scalars.
+        allreduce=False: the caller already all-reduced the gradient bucket (hipGraph replay keeps the
+        collective outside the captured segment); only the 1/world scale is applied."""
+        if allreduce:
+            scale = self.bucket.allreduce()
+        else:
+            import torch.distributed as dist
+
+            scale = 1.0 / dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1.0
         self.bucket.step(lr=self._lr, eps=self._eps, clip=self._clip, weight_decay=self._wd, grad_scale=scale)
         return {f"{self._name}_loss": loss, f"{self._name}_grad_norm": self.bucket.grad_norm}
 
