@@ -122,11 +122,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X hot path has no CPU implementation")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("DV3_DIST_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from dv3hip import ops
     from tests import helpers as Hh
@@ -172,6 +177,9 @@ def main():
 
     # ---- roofline leg: per-launch HIP-event timing of one more (eager) update on the launch stream
     roofline = None
+    if rank != 0:
+        runner.step(data, eager=True)  # every rank takes part in the profiled update's all-reduces
+        torch.cuda.synchronize()
     if rank == 0:
         ops.PROFILE.by_shape = args.by_shape
         ops.PROFILE.start()

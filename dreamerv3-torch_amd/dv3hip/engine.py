@@ -30,6 +30,45 @@ from . import ops
 F32 = torch.float32
 
 
+class SideStream:
+    """Second HIP stream for work that is off the critical path (weight gradients, the critic branch) so it
+    runs beside the latency-bound scans, whose small launches leave most CUs idle.  fork() makes the side
+    stream wait for everything enqueued so far; join() makes the main stream wait for the side work.  Under
+    hipGraph capture the two streams become parallel branches of the graph."""
+
+    # Measured on MI355X at cfg 2 (r01): OFF is faster (27.7 vs 29.8 ms/update).  The heavy side kernels
+    # (conv wgrads) take every CU and each of the ~640 latency-critical scan launches then queues behind
+    # them.  Kept as a switch: it needs a CU-masked side stream to pay (DESIGN.md §7).
+    enabled = False
+    _streams: Dict[str, "torch.cuda.Stream"] = {}
+
+    def __init__(self, device):
+        key = str(device)
+        if key not in SideStream._streams:
+            SideStream._streams[key] = torch.cuda.Stream(device=device)
+        self.stream = SideStream._streams[key]
+        self._forked = False
+
+    def run(self, fns):
+        """Run the deferred callables on the side stream (or inline when disabled)."""
+        if not fns:
+            return
+        if not SideStream.enabled:
+            for f in fns:
+                f()
+            return
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for f in fns:
+                f()
+        self._forked = True
+
+    def join(self):
+        if self._forked:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self._forked = False
+
+
 class Workspace:
     """Named device buffers, allocated on first use and reused (no allocation in steady state)."""
 
@@ -163,10 +202,11 @@ class MLPEngine:
         return h1, o, o2
 
     def backward(self, x1, x2, rows: slice, dout=None, dout2=None, *, wgrad: bool, dx1=None, dx2=None,
-                 acc_dx=False, dh=None):
+                 acc_dx=False, dh=None, defer=None):
         """Back-propagate rows `rows` of the stored activations.  x1/x2: the inputs those rows were computed
         from (same row count).  dout/dout2: gradients of the head Linears' outputs for those rows; dh: gradient
-        on the trunk output itself (head-less MLPs such as the proprio encoder)."""
+        on the trunk output itself (head-less MLPs such as the proprio encoder).  defer: a list that receives
+        the weight-gradient launches as callables instead of running them inline (see SideStream)."""
         P, ws, nm = self.P, self.ws, self.name
         acts, _, _ = self._bufs(self.total)
         R = x1.shape[0]
@@ -183,9 +223,11 @@ class MLPEngine:
             ops.gemm(d, lin.W, dh, transB=False, accumulate=not first)
             first = False
             if wgrad:
-                lin_wgrad(lin.W, d, h)
-                if lin.b is not None:
-                    ops.colsum(d, _g(lin.b), accumulate=True)
+                def _head_wgrad(lin=lin, d=d, h=h):
+                    lin_wgrad(lin.W, d, h)
+                    if lin.b is not None:
+                        ops.colsum(d, _g(lin.b), accumulate=True)
+                (defer.append if defer is not None else (lambda f: f()))(_head_wgrad)
         if first:
             raise ValueError("MLP backward without any upstream gradient")
         dy = dh
@@ -196,7 +238,9 @@ class MLPEngine:
             dpre = ws.get(f"{nm}.dpre{i}", (R, pre.shape[1]))
             dense_ln_bwd_pre(L, dy, pre[rows], mean[rows], rstd[rows], dpre, wgrad=wgrad)
             if wgrad:
-                lin_wgrad(L.W, dpre, xin1, xin2)
+                def _wg(L=L, dpre=dpre, xin1=xin1, xin2=xin2):
+                    lin_wgrad(L.W, dpre, xin1, xin2)
+                (defer.append if defer is not None else (lambda f: f()))(_wg)
             if i > 0:
                 dprev = ws.get(f"{nm}.dy{i - 1}", (R, xin1.shape[1]))
                 ops.gemm(dpre, L.W, dprev, transB=False)
@@ -304,13 +348,15 @@ class RSSMEngine:
         return dict(post_stoch=post_stoch, post_logit=post_logit, deter=deter, prior_stoch=prior_stoch,
                     prior_logit=prior_logit, action=ain)
 
-    def observe_bwd(self, dpost_logit, dprior_logit, gs, gd, dembed):
+    def observe_bwd(self, dpost_logit, dprior_logit, gs, gd, dembed, extra_side=None):
         """Backward of observe_fwd.
 
         dpost_logit/dprior_logit [T,B,S,D]: gradient on the logits (from the KL; dpost_logit is updated in
         place with the straight-through term).  gs [T,B,SD], gd [T,B,De]: gradient on post stoch / deter
         from the heads (both are used as scratch).  dembed [T,B,E] receives the encoder-output gradient.
-        All RSSM parameter gradients are accumulated into their .grad views."""
+        All RSSM parameter gradients are accumulated into their .grad views.  extra_side: callables (weight
+        gradients of the heads / decoder) to run on the side stream beside the reverse scan.  Returns the
+        SideStream so that the caller can put more work beside the encoder backward and join()."""
         P, ws = self.P, self.ws
         T, B, S, D, SD, De, Hd, A, E = self.T, self.B, self.S, self.D, self.SD, self.De, self.Hd, self.A, self.E
         TB = T * B
@@ -329,13 +375,18 @@ class RSSMEngine:
         # ---- prior head, batched: prior_logit -> ims -> LN/SiLU -> img_out -> deter
         dx2 = g("obs.dx2", (TB, Hd))
         dpl2 = v2(dprior_logit, SD)
+        side = SideStream(dprior_logit.device)
         ops.gemm(dpl2, P.ims.W, dx2, transB=False)
-        lin_wgrad(P.ims.W, dpl2, v2(x2, Hd))
-        ops.colsum(dpl2, _g(P.ims.b), accumulate=True)
         dx2pre = g("obs.dx2pre", (TB, Hd))
         dense_ln_bwd_pre(P.img_out, dx2, v2(x2pre, Hd), m2.view(TB), r2.view(TB), dx2pre, wgrad=True)
-        lin_wgrad(P.img_out.W, dx2pre, v2(deter, De))
         ops.gemm(dx2pre, P.img_out.W, v2(gd, De), transB=False, accumulate=True)
+
+        def _prior_wgrads():
+            lin_wgrad(P.ims.W, dpl2, v2(x2, Hd))
+            ops.colsum(dpl2, _g(P.ims.b), accumulate=True)
+            lin_wgrad(P.img_out.W, dx2pre, v2(deter, De))
+
+        side.run((extra_side or []) + [_prior_wgrads])  # beside the reverse scan below
         # ---- reverse scan
         dx3 = g("obs.dx3", (B, Hd))
         dx3pre = g("obs.dx3pre", (T, B, Hd))
@@ -358,15 +409,21 @@ class RSSMEngine:
             ops.gemm(dx1pre[t], P.img_in.W[:, :SD], dsin, transB=False)
             ops.obs_blend_bwd(dsin, ddin, first[t], gs[t - 1] if t > 0 else None, gd[t - 1] if t > 0 else None,
                               dstoch0, ddeter0)
-        # ---- batched weight gradients and the encoder-output gradient
-        dpl = v2(dpost_logit, SD)
-        lin_wgrad(P.obs.W, dpl, v2(x3, Hd))
-        ops.colsum(dpl, _g(P.obs.b), accumulate=True)
-        lin_wgrad(P.obs_out.W, v2(dx3pre, Hd), v2(deter, De), v2(self._embed, E))
-        lin_wgrad(P.gru.W, v2(dgpre, 3 * De), v2(x1, Hd), v2(din, De))
-        lin_wgrad(P.img_in.W, v2(dx1pre, Hd), v2(sin, SD), v2(ain, A))
+        # ---- the encoder-output gradient (critical path) and, beside it, the batched weight gradients
+        side.join()  # the init-state backward below adds into the same prior-head gradients
         ops.gemm(v2(dx3pre, Hd), P.obs_out.W[:, De:], v2(dembed, E), transB=False)
-        self.init_state_bwd(dstoch0, ddeter0)
+        dpl = v2(dpost_logit, SD)
+
+        def _scan_wgrads():
+            lin_wgrad(P.obs.W, dpl, v2(x3, Hd))
+            ops.colsum(dpl, _g(P.obs.b), accumulate=True)
+            lin_wgrad(P.obs_out.W, v2(dx3pre, Hd), v2(deter, De), v2(self._embed, E))
+            lin_wgrad(P.gru.W, v2(dgpre, 3 * De), v2(x1, Hd), v2(din, De))
+            lin_wgrad(P.img_in.W, v2(dx1pre, Hd), v2(sin, SD), v2(ain, A))
+            self.init_state_bwd(dstoch0, ddeter0)
+
+        side.run([_scan_wgrads])  # beside the encoder backward the caller launches next
+        return side
 
     # -- one img_step on a row block (networks.py:208-233), used by the policy path and imagine ---------
     def img_step_fwd(self, stoch, deter, action, bufs, *, noise=None, rng=None, sample=True):
@@ -510,8 +567,9 @@ class ConvDecoderEngine:
             x, H = y, OH
         return x
 
-    def backward(self, drecon, dx1, dx2, *, acc_dx=False):
+    def backward(self, drecon, dx1, dx2, *, acc_dx=False, defer=None):
         ws = self.ws
+        run = defer.append if defer is not None else (lambda f: f())
         dy = drecon
         for i in reversed(range(len(self.L))):
             L = self.L[i]
@@ -526,8 +584,10 @@ class ConvDecoderEngine:
             else:
                 dpre = dy
                 if L.bias is not None:
-                    ops.colsum(dpre.view(rows, Co), _g(L.bias), accumulate=True)
-            ops.conv_s2_wgrad(x, dpre, _g(L.W))  # coarse = layer input, fine = output gradient
+                    run(lambda dpre=dpre, L=L, rows=rows, Co=Co: ops.colsum(dpre.view(rows, Co), _g(L.bias),
+                                                                         accumulate=True))
+            # coarse = layer input, fine = output gradient
+            run(lambda x=x, dpre=dpre, L=L: ops.conv_s2_wgrad(x, dpre, _g(L.W)))
             wp = ws.get(f"dec.wp{i}", (Ci, 16 * Co))
             ops.pack_conv_weight(L.W, wp, transposed=False)  # ConvTranspose2d weight read as its adjoint
             dx = ws.get(f"dec.dx{i}", x.shape)
@@ -537,8 +597,12 @@ class ConvDecoderEngine:
         E = self.lin.W.shape[0]
         dh0 = dy.view(R, E)
         x1, x2 = self._x
-        lin_wgrad(self.lin.W, dh0, x1, x2)
-        ops.colsum(dh0, _g(self.lin.b), accumulate=True)
+
+        def _lin_wg():
+            lin_wgrad(self.lin.W, dh0, x1, x2)
+            ops.colsum(dh0, _g(self.lin.b), accumulate=True)
+
+        run(_lin_wg)
         k1 = x1.shape[1]
         ops.gemm(dh0, self.lin.W[:, :k1], dx1, transB=False, accumulate=acc_dx)
         ops.gemm(dh0, self.lin.W[:, k1:], dx2, transB=False, accumulate=acc_dx)

@@ -212,6 +212,7 @@ class WorldModel(nn.Module):
         acc = ws.zeros("wm.acc", (8,))  # [model_loss, image, reward, cont, kl, ent_prior, ent_post, vector]
         gs, gd = ws.get("wm.gs", (T, B, SD)), ws.get("wm.gd", (T, B, De))
         wrote = False
+        deferred = []  # weight-gradient launches that can run beside the reverse scan (E.SideStream)
         dec = self.heads["decoder"]
         grad_heads = cfg.grad_heads
         if dec.cnn_shapes:
@@ -221,7 +222,7 @@ class WorldModel(nn.Module):
             drecon = ws.get("wm.drecon", recon.shape)
             ops.mse_image(recon, st["image"], limg, drecon, upstream=up, perm=(B, T))
             ops.dot_accumulate(limg, acc[1:2], scale=up)
-            dec_eng.backward(drecon, gs.view(TB, SD), gd.view(TB, De), acc_dx=False)
+            dec_eng.backward(drecon, gs.view(TB, SD), gd.view(TB, De), acc_dx=False, defer=deferred)
             wrote = True
             if "decoder" not in grad_heads:
                 gs.zero_(), gd.zero_()
@@ -245,7 +246,7 @@ class WorldModel(nn.Module):
                 ops.colsum(dmode, lin.bias.grad, accumulate=True)
             gh = "decoder" in grad_heads
             deng.backward(ps, dt, slice(0, TB), wgrad=True, dh=dh, dx1=gs.view(TB, SD) if gh else None,
-                          dx2=gd.view(TB, De) if gh else None, acc_dx=wrote)
+                          dx2=gd.view(TB, De) if gh else None, acc_dx=wrote, defer=deferred)
             wrote = wrote or gh
         if not wrote:
             gs.zero_(), gd.zero_()
@@ -260,7 +261,7 @@ class WorldModel(nn.Module):
         ops.disc_logprob_bwd(r_logits, reward_tm.view(TB), up_r, dr)
         g_r = "reward" in grad_heads
         reng.backward(ps, dt, slice(0, TB), dout=dr, wgrad=True, dx1=gs.view(TB, SD) if g_r else None,
-                      dx2=gd.view(TB, De) if g_r else None, acc_dx=True)
+                      dx2=gd.view(TB, De) if g_r else None, acc_dx=True, defer=deferred)
         # continue head
         ceng = self.heads["cont"].engine_for(".wm")
         _, c_logit, _ = ceng.forward(ps, dt)
@@ -272,7 +273,7 @@ class WorldModel(nn.Module):
         ops.bernoulli_logprob_bwd(c_logit.view(TB), cont_tm.view(TB), up_c, dc.view(TB))
         g_c = "cont" in grad_heads
         ceng.backward(ps, dt, slice(0, TB), dout=dc, wgrad=True, dx1=gs.view(TB, SD) if g_c else None,
-                      dx2=gd.view(TB, De) if g_c else None, acc_dx=True)
+                      dx2=gd.view(TB, De) if g_c else None, acc_dx=True, defer=deferred)
         # KL
         dpl, dql = ws.get("wm.dpost_logit", (T, B, S, D)), ws.get("wm.dprior_logit", (T, B, S, D))
         ops.kl_bwd(out["post_logit"], out["prior_logit"], kl, dpl, dql, unimix=dyn._unimix_ratio, free=cfg.kl_free,
@@ -280,11 +281,12 @@ class WorldModel(nn.Module):
         ops.dot_accumulate(kl.view(TB), acc[4:5], clip_min=cfg.kl_free, scale=up)  # mean of the clipped KL
         # ---- backward through the scan and the encoder
         dembed = ws.get("wm.dembed", (T, B, E_))
-        rssm.observe_bwd(dpl, dql, gs, gd, dembed)
+        side = rssm.observe_bwd(dpl, dql, gs, gd, dembed, extra_side=deferred)
         if enc.cnn_shapes:
             enc_eng.backward(dembed.view(TB, E_))
         else:
             enc_eng.backward(self._enc_in, None, slice(0, TB), wgrad=True, dh=dembed.view(TB, E_))
+        side.join()
 
         # ---- scalar loss + optimizer
         loss = ws.get("wm.loss", (1,))
@@ -541,6 +543,26 @@ class ImagBehavior(nn.Module):
             dtarget = g("bh.dtarget", (H - 1, N))
             ops.actor_loss(target, value, weights, ent, ema, acc[0:1], dent, dtarget=dtarget,
                            entropy_coef=cfg.actor["entropy"], reinforce=False)
+        # ---- critic branch: -log_prob(target) - log_prob(slow.mode), weighted by the cumulative discount.
+        # Independent of the actor's backward, so it runs on the side stream beside the dynamics scan.
+        R = H1N
+
+        def _critic():
+            inv = 1.0 / H1N
+            up_v = ops.scale_neg(weights.view(HN)[:R], g("bh.up_v", (R,)), inv)
+            lp, lp2 = g("bh.lp_v", (R,)), g("bh.lp_v2", (R,))
+            dvl = g("bh.dv_logits", (R, 255))
+            ops.disc_logprob_fwd(v_logits[:R], target.view(R), lp)
+            ops.dot_accumulate(lp, acc[1:2], w=up_v)
+            ops.disc_logprob_bwd(v_logits[:R], target.view(R), up_v, dvl)
+            if cfg.critic["slow_target"]:
+                ops.disc_logprob_fwd(v_logits[:R], slow.view(R), lp2)
+                ops.dot_accumulate(lp2, acc[1:2], w=up_v)
+                ops.disc_logprob_bwd(v_logits[:R], slow.view(R), up_v, dvl, accumulate=True)
+            veng.backward(fs[:R], fd[:R], slice(0, R), dout=dvl, wgrad=True)
+
+        side = E.SideStream(fs.device)
+        side.run([_critic])
         # ---- dynamics backprop: target -> reward / cont heads -> imagined states -> actions
         daction = g("bh.daction", (H, N, A))
         if not reinforce:
@@ -567,7 +589,6 @@ class ImagBehavior(nn.Module):
                 rssm.img_step_bwd(gs[t], gd[t], deter[t - 1], b, scratch, gs[t - 1], gd[t - 1], daction[t - 1],
                                   accumulate_prev=t > 1)
         # ---- actor backward over steps 0..H-2 (the last step's action feeds nothing that is used)
-        R = H1N
         dmean, dstd = g("bh.dmean", (R, A)), g("bh.dstd", (R, A))
         if normal:
             ops.actor_normal_bwd(a_mean[:R], a_std[:R], dmean, dstd, eps=im["eps"].view(HN, A)[:R],
@@ -583,19 +604,7 @@ class ImagBehavior(nn.Module):
                                     unimix=cfg.actor["unimix_ratio"], accumulate=not reinforce)
             dstd = None
         im["actor"].backward(fs[:R], fd[:R], slice(0, R), dout=dmean, dout2=dstd, wgrad=True)
-        # ---- critic: -log_prob(target) - log_prob(slow.mode), weighted by the cumulative discount
-        inv = 1.0 / H1N
-        up_v = ops.scale_neg(weights.view(HN)[:R], g("bh.up_v", (R,)), inv)
-        lp = g("bh.lp_v", (R,))
-        dvl = g("bh.dv_logits", (R, 255))
-        ops.disc_logprob_fwd(v_logits[:R], target.view(R), lp)
-        ops.dot_accumulate(lp, acc[1:2], w=up_v)
-        ops.disc_logprob_bwd(v_logits[:R], target.view(R), up_v, dvl)
-        if cfg.critic["slow_target"]:
-            ops.disc_logprob_fwd(v_logits[:R], slow.view(R), lp)
-            ops.dot_accumulate(lp, acc[1:2], w=up_v)
-            ops.disc_logprob_bwd(v_logits[:R], slow.view(R), up_v, dvl, accumulate=True)
-        veng.backward(fs[:R], fd[:R], slice(0, R), dout=dvl, wgrad=True)
+        side.join()
         # ---- metrics + optimizers
         ops.dot_accumulate(ent.view(HN), acc[2:3], scale=1.0 / HN)
         metrics = {}
