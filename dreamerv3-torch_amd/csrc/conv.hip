@@ -439,6 +439,132 @@ __global__ void pack_convT_w_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The 3-channel image layers (encoder's first conv, decoder's last transposed conv) have K = 48 or
+// N = 3: on MFMA tiles they run at 3-14 TFLOP/s of padding.  They are HBM-bound (134 MB of fp32
+// activations on the 32-channel side) with 1536 FMAs per pixel, so: one thread per coarse-grid pixel, the
+// whole receptive field in registers, weights read with wave-uniform indices (scalar loads, they
+// never touch a VGPR), 16-byte global accesses.  CW = channels on the wide side (multiple of 4).
+// ------------------------------------------------------------------------------------------------
+typedef float f4a __attribute__((ext_vector_type(4), aligned(4)));
+
+// y[n,oy,ox,0..CW) = sum_{ky,kx,c<3} x[n,2oy+ky-1,2ox+kx-1,c] * w[co][c][ky][kx]      (Conv2d 3 -> CW)
+template <int CW>
+__global__ __launch_bounds__(256) void conv_s2_c3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ y, int Nimg, int H, int W,
+                                                         int accumulate) {
+  const int OH = H / 2, OW = W / 2;
+  const long total = (long)Nimg * OH * OW;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(p % OW);
+    const long t = p / OW;
+    const int oy = (int)(t % OH);
+    const long n = t / OH;
+    float in[4][12];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      const bool rowok = iy >= 0 && iy < H;
+      const float* row = x + ((n * H + (rowok ? iy : 0)) * W) * 3;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        const bool ok = rowok && ix >= 0 && ix < W;
+        const float* q = row + (ok ? ix : 0) * 3;
+        const float m = ok ? 1.f : 0.f;
+        in[ky][kx * 3 + 0] = q[0] * m;
+        in[ky][kx * 3 + 1] = q[1] * m;
+        in[ky][kx * 3 + 2] = q[2] * m;
+      }
+    }
+    float* out = y + p * CW;
+#pragma unroll 1
+    for (int c0 = 0; c0 < CW; c0 += 4) {
+      f4a acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wc = w + (long)(c0 + e) * 48;  // [co][c][ky][kx]
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) a += in[ky][kx * 3 + c] * wc[(c * 4 + ky) * 4 + kx];
+        acc[e] = a;
+      }
+      f4a* o = reinterpret_cast<f4a*>(out + c0);
+      if (accumulate) acc += *o;
+      *o = acc;
+    }
+  }
+}
+
+// y[n,2y2+py,2x2+px,co<3] = sum_{a,b,ci<CW} x[n,y2+py-a,x2+px-b,ci] * w[ci][co][1-py+2a][1-px+2b] + bias + add
+// (ConvTranspose2d CW -> 3).  One thread per input-grid pixel computes its 2x2 output block.
+template <int CW>
+__global__ __launch_bounds__(256) void convT_s2_c3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float out_add,
+                                                          float* __restrict__ y, int Nimg, int IH, int IW,
+                                                          int accumulate) {
+  const long total = (long)Nimg * IH * IW;
+  const int OW = 2 * IW, OH = 2 * IH;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int x2 = (int)(p % IW);
+    const long t = p / IW;
+    const int y2 = (int)(t % IH);
+    const long n = t / IH;
+    float acc[2][2][3];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int co = 0; co < 3; ++co) acc[py][px][co] = 0.f;
+#pragma unroll 1
+    for (int c0 = 0; c0 < CW; c0 += 4) {
+      f4a in[3][3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int iy = y2 + dy - 1, ix = x2 + dx - 1;
+          const bool ok = iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+          const float* q = x + (((n * IH + (ok ? iy : 0)) * IW + (ok ? ix : 0)) * CW) + c0;
+          in[dy][dx] = *reinterpret_cast<const f4a*>(q) * (ok ? 1.f : 0.f);
+        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wc = w + (long)(c0 + e) * 48;  // [ci][co][ky][kx]
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) {
+                const float v = in[py - a + 1][px - b + 1][e];
+                const int ky = 1 - py + 2 * a, kx = 1 - px + 2 * b;
+#pragma unroll
+                for (int co = 0; co < 3; ++co) acc[py][px][co] += v * wc[(co * 4 + ky) * 4 + kx];
+              }
+      }
+    }
+    const float b0 = (bias ? bias[0] : 0.f) + out_add, b1 = (bias ? bias[1] : 0.f) + out_add,
+                b2 = (bias ? bias[2] : 0.f) + out_add;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      float* o = y + (((n * OH + 2 * y2 + py) * OW) + 2 * x2) * 3;  // 6 contiguous floats: px = 0, 1
+      float v[6] = {acc[py][0][0] + b0, acc[py][0][1] + b1, acc[py][0][2] + b2,
+                    acc[py][1][0] + b0, acc[py][1][1] + b1, acc[py][1][2] + b2};
+#pragma unroll
+      for (int e = 0; e < 6; ++e) o[e] = accumulate ? (o[e] + v[e]) : v[e];
+    }
+  }
+}
+
 using C128 = TileShape<2, 2, 2, 2, 16>;    // 128 x 128
 using C64 = TileShape<2, 2, 1, 1, 32>;     // 64 x 64
 using C128x32 = TileShape<4, 1, 1, 1, 32>;  // 128 x 32 (narrow channel counts)
@@ -521,5 +647,34 @@ extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* 
   p.splits = (int)splits;
   p.chunk = (int)chunk;
   hipLaunchKernelGGL((conv_wgrad_kernel<TS>), dim3((unsigned)(tiles * splits)), dim3(kThreads), 0, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+
+// Specialised image-side layers (3 channels on one side).  Weights in the REFERENCE layout (no packing):
+// conv: Conv2d weight [CW][3][4][4];  convT: ConvTranspose2d weight [CW][3][4][4] (in = CW, out = 3).
+extern "C" int dv3_conv_s2_c3_fwd(const float* x, const float* w, float* y, int Nimg, int H, int W, int CW,
+                                  int accumulate, void* stream) {
+  if (Nimg <= 0) return 0;
+  if (!x || !w || !y || !pow2_spatial(H, W)) return DV3_ERR_ARG;
+  const long total = (long)Nimg * (H / 2) * (W / 2);
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (CW == 32) hipLaunchKernelGGL((conv_s2_c3_kernel<32>), dim3(blocks), dim3(256), 0, s, x, w, y, Nimg, H, W, accumulate);
+  else if (CW == 96) hipLaunchKernelGGL((conv_s2_c3_kernel<96>), dim3(blocks), dim3(256), 0, s, x, w, y, Nimg, H, W, accumulate);
+  else return DV3_ERR_ARG;
+  return (int)hipGetLastError();
+}
+extern "C" int dv3_convT_s2_c3_fwd(const float* x, const float* w, const float* bias, float out_add, float* y,
+                                   int Nimg, int IH, int IW, int CW, int accumulate, void* stream) {
+  if (Nimg <= 0) return 0;
+  if (!x || !w || !y || IH <= 0 || IW <= 0) return DV3_ERR_ARG;
+  const long total = (long)Nimg * IH * IW;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (CW == 32) hipLaunchKernelGGL((convT_s2_c3_kernel<32>), dim3(blocks), dim3(256), 0, s, x, w, bias, out_add, y, Nimg, IH, IW, accumulate);
+  else if (CW == 96) hipLaunchKernelGGL((convT_s2_c3_kernel<96>), dim3(blocks), dim3(256), 0, s, x, w, bias, out_add, y, Nimg, IH, IW, accumulate);
+  else return DV3_ERR_ARG;
   return (int)hipGetLastError();
 }

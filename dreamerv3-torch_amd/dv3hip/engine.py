@@ -493,11 +493,14 @@ class ConvEncoderEngine:
         n_layers = len(self.L)
         for i, L in enumerate(self.L):
             Co, Ci = L.W.shape[0], L.W.shape[1]
-            wp = ws.get(f"enc.wp{i}", (Co, 16 * Ci))
-            ops.pack_conv_weight(L.W, wp, transposed=False)
             OH = H // 2
             pre = ws.get(f"enc.pre{i}", (N, OH, OH, Co))
-            ops.conv_s2_fwd(x, wp, pre, Ci=Ci, Co=Co)
+            if Ci == 3 and Co in ops.C3_WIDTHS:
+                ops.conv_s2_c3_fwd(x, L.W, pre, CW=Co)
+            else:
+                wp = ws.get(f"enc.wp{i}", (Co, 16 * Ci))
+                ops.pack_conv_weight(L.W, wp, transposed=False)
+                ops.conv_s2_fwd(x, wp, pre, Ci=Ci, Co=Co)
             R = N * OH * OH
             mean, rstd = ws.get(f"enc.m{i}", (R,)), ws.get(f"enc.r{i}", (R,))
             last = i == n_layers - 1
@@ -549,9 +552,11 @@ class ConvDecoderEngine:
         x, H = h0, mr
         for i, L in enumerate(self.L):
             Ci, Co = L.W.shape[0], L.W.shape[1]
-            wpt = ws.get(f"dec.wpt{i}", (4, Co, 4 * Ci))
-            ops.pack_conv_weight(L.W, wpt, transposed=True)
             OH = 2 * H
+            c3 = L.g is None and Co == 3 and Ci in ops.C3_WIDTHS
+            if not c3:
+                wpt = ws.get(f"dec.wpt{i}", (4, Co, 4 * Ci))
+                ops.pack_conv_weight(L.W, wpt, transposed=True)
             if L.g is not None:
                 pre = ws.get(f"dec.pre{i}", (R, OH, OH, Co))
                 ops.convT_s2_fwd(x, wpt, pre, Ci=Ci, Co=Co)
@@ -562,7 +567,10 @@ class ConvDecoderEngine:
                 self._acts.append((x, pre, mean, rstd, y))
             else:
                 y = ws.get("dec.recon", (R, OH, OH, Co))
-                ops.convT_s2_fwd(x, wpt, y, Ci=Ci, Co=Co, bias=L.bias, out_add=0.5)
+                if c3:
+                    ops.convT_s2_c3_fwd(x, L.W, y, CW=Ci, bias=L.bias, out_add=0.5)
+                else:
+                    ops.convT_s2_fwd(x, wpt, y, Ci=Ci, Co=Co, bias=L.bias, out_add=0.5)
                 self._acts.append((x, None, None, None, y))
             x, H = y, OH
         return x
@@ -588,10 +596,13 @@ class ConvDecoderEngine:
                                                                          accumulate=True))
             # coarse = layer input, fine = output gradient
             run(lambda x=x, dpre=dpre, L=L: ops.conv_s2_wgrad(x, dpre, _g(L.W)))
-            wp = ws.get(f"dec.wp{i}", (Ci, 16 * Co))
-            ops.pack_conv_weight(L.W, wp, transposed=False)  # ConvTranspose2d weight read as its adjoint
             dx = ws.get(f"dec.dx{i}", x.shape)
-            ops.conv_s2_fwd(dpre, wp, dx, Ci=Co, Co=Ci)
+            if Co == 3 and Ci in ops.C3_WIDTHS:
+                ops.conv_s2_c3_fwd(dpre, L.W, dx, CW=Ci)  # ConvTranspose2d weight [Ci,3,4,4] read as its adjoint
+            else:
+                wp = ws.get(f"dec.wp{i}", (Ci, 16 * Co))
+                ops.pack_conv_weight(L.W, wp, transposed=False)  # ConvTranspose2d weight read as its adjoint
+                ops.conv_s2_fwd(dpre, wp, dx, Ci=Co, Co=Ci)
             dy = dx
         R = dy.shape[0]
         E = self.lin.W.shape[0]

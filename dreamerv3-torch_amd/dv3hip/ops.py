@@ -513,7 +513,7 @@ def conv_s2_fwd(x, wp, y, *, Ci, Co, accumulate=False):
     if wp.numel() != 16 * Ci * Co or y.numel() != N * (H // 2) * (W // 2) * Co:
         raise ValueError("conv shapes mismatch")
     _call("dv3_conv_s2_fwd", _ptr(x), _ptr(wp), _ptr(y), N, H, W, Ci, Co, int(accumulate), _stream(),
-          key=f"conv_s2_kernel<Co={Co}>", flops=2.0 * N * (H // 2) * (W // 2) * 16 * Ci * Co,
+          key=f"conv_s2_kernel<Co={Co}>" + (f"[N{N} {H}x{W} Ci{Ci}]" if PROFILE.by_shape else ""), flops=2.0 * N * (H // 2) * (W // 2) * 16 * Ci * Co,
           nbytes=4.0 * (x.numel() + y.numel() + wp.numel()))
     return y
 
@@ -531,7 +531,7 @@ def convT_s2_fwd(x, wp, y, *, Ci, Co, bias=None, out_add=0.0, accumulate=False):
         if bias.numel() != Co:
             raise ValueError("bias size mismatch")
     _call("dv3_convT_s2_fwd", _ptr(x), _ptr(wp), _ptr(bias), float(out_add), _ptr(y), N, IH, IW, Ci, Co,
-          int(accumulate), _stream(), key=f"convT_s2_kernel<Co={Co}>", flops=2.0 * N * IH * IW * 16 * Ci * Co,
+          int(accumulate), _stream(), key=f"convT_s2_kernel<Co={Co}>" + (f"[N{N} {IH}x{IW} Ci{Ci}]" if PROFILE.by_shape else ""), flops=2.0 * N * IH * IW * 16 * Ci * Co,
           nbytes=4.0 * (x.numel() + y.numel() + wp.numel()))
     return y
 
@@ -546,7 +546,7 @@ def conv_s2_wgrad(coarse, fine, dw):
     if coarse.shape[0] != N or coarse.shape[1] * 2 != H or coarse.shape[2] * 2 != W or dw.numel() != 16 * Cc * Cf:
         raise ValueError("wgrad shapes mismatch")
     _call("dv3_conv_s2_wgrad", _ptr(coarse), _ptr(fine), _ptr(dw), N, H, W, Cf, Cc, _stream(),
-          key="conv_wgrad_kernel", flops=2.0 * N * (H // 2) * (W // 2) * 16 * Cf * Cc,
+          key="conv_wgrad_kernel" + (f"[N{N} {H}x{W} Cf{Cf} Cc{Cc}]" if PROFILE.by_shape else ""), flops=2.0 * N * (H // 2) * (W // 2) * 16 * Cf * Cc,
           nbytes=4.0 * (coarse.numel() + fine.numel() + dw.numel()))
     return dw
 
@@ -785,3 +785,36 @@ def scale_neg(w, out, s):
         raise ValueError("size mismatch")
     _call("dv3_scale_neg", _ptr(w), _ptr(out), w.numel(), float(s), _stream())
     return out
+
+
+C3_WIDTHS = (32, 96)
+
+
+def conv_s2_c3_fwd(x, w, y, *, CW, accumulate=False):
+    """x [N,H,W,3] -> y [N,H/2,W/2,CW]; w = Conv2d weight [CW,3,4,4] (reference layout, unpacked)."""
+    _contig(x, "x"), _contig(w, "w"), _contig(y, "y")
+    if x.dim() != 4 or x.shape[3] != 3 or tuple(w.shape) != (CW, 3, 4, 4) or CW not in C3_WIDTHS:
+        raise ValueError("conv_s2_c3 shapes")
+    N, H, W = x.shape[0], x.shape[1], x.shape[2]
+    if H % 2 or W % 2 or y.numel() != N * (H // 2) * (W // 2) * CW:
+        raise ValueError("conv_s2_c3 output size")
+    _call("dv3_conv_s2_c3_fwd", _ptr(x), _ptr(w), _ptr(y), N, H, W, CW, int(accumulate), _stream(),
+          key="conv_s2_c3_kernel", nbytes=4.0 * (x.numel() + y.numel()))
+    return y
+
+
+def convT_s2_c3_fwd(x, w, y, *, CW, bias=None, out_add=0.0, accumulate=False):
+    """x [N,IH,IW,CW] -> y [N,2IH,2IW,3]; w = ConvTranspose2d weight [CW,3,4,4] (reference layout)."""
+    _contig(x, "x"), _contig(w, "w"), _contig(y, "y")
+    if x.dim() != 4 or x.shape[3] != CW or tuple(w.shape) != (CW, 3, 4, 4) or CW not in C3_WIDTHS:
+        raise ValueError("convT_s2_c3 shapes")
+    N, IH, IW = x.shape[0], x.shape[1], x.shape[2]
+    if y.numel() != N * 4 * IH * IW * 3:
+        raise ValueError("convT_s2_c3 output size")
+    if bias is not None:
+        _contig(bias, "bias")
+        if bias.numel() != 3:
+            raise ValueError("bias size")
+    _call("dv3_convT_s2_c3_fwd", _ptr(x), _ptr(w), _ptr(bias), float(out_add), _ptr(y), N, IH, IW, CW,
+          int(accumulate), _stream(), key="convT_s2_c3_kernel", nbytes=4.0 * (x.numel() + y.numel()))
+    return y

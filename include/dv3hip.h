@@ -144,6 +144,13 @@ int dv3_convT_s2_fwd(const float* x, const float* w_packed, const float* bias, f
                      int IH, int IW, int Ci, int Co, int accumulate, void* stream);
 int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* dw, int Nimg, int H, int W, int Cfine,
                       int Ccoarse, void* stream);
+/* The 3-channel image-side layers (first encoder conv 3->CW, last decoder transposed conv CW->3, and each
+ * other's input gradient), as HBM-bound VALU kernels with wave-uniform weights read in the REFERENCE layout
+ * ([CW][3][4][4] for both; CW in {32, 96} = cnn_depth of the shipped configs). */
+int dv3_conv_s2_c3_fwd(const float* x, const float* w, float* y, int Nimg, int H, int W, int CW, int accumulate,
+                       void* stream);
+int dv3_convT_s2_c3_fwd(const float* x, const float* w, const float* bias, float out_add, float* y, int Nimg,
+                        int IH, int IW, int CW, int accumulate, void* stream);
 
 /* ---- proprio inputs/outputs -- tools.symlog (tools.py:22-23), tools.SymlogDist (tools.py:543-572) --- */
 int dv3_symlog(const float* x, float* y, long n, void* stream);

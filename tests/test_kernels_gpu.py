@@ -609,3 +609,33 @@ def test_layout_helpers(ops):
     dxd = torch.empty(1, 512).cuda()
     ops.tanh_bwd(yd, dev(gy), dxd)
     assert_close(dxd, t.grad, what="tanh bwd")
+
+
+@pytest.mark.parametrize("CW", [32, 96])
+def test_three_channel_image_layers(ops, CW):
+    """Dedicated kernels for the 3-channel side: encoder conv 3->CW and decoder convT CW->3 (+bias+0.5),
+    weights in the reference layout, against torch CPU."""
+    g = torch.Generator().manual_seed(CW)
+    N, H = 3, 64
+    x = torch.randn(N, 3, H, H, generator=g)
+    w = torch.randn(CW, 3, 4, 4, generator=g) / math.sqrt(48)
+    ref = F.conv2d(F.pad(x, [1, 1, 1, 1]), w, None, 2)
+    y = torch.empty(N, H // 2, H // 2, CW).cuda()
+    ops.conv_s2_c3_fwd(dev(nhwc(x)), dev(w), y, CW=CW)
+    assert_close(y, nhwc(ref), what="conv c3")
+    ops.conv_s2_c3_fwd(dev(nhwc(x)), dev(w), y, CW=CW, accumulate=True)
+    assert_close(y, 2 * nhwc(ref), what="conv c3 accumulate")
+    xi = torch.randn(N, CW, 32, 32, generator=g)
+    wt = torch.randn(CW, 3, 4, 4, generator=g) / math.sqrt(4 * CW)
+    b = torch.randn(3, generator=g)
+    reft = F.conv_transpose2d(xi, wt, b, 2, padding=1) + 0.5
+    yt = torch.empty(N, 64, 64, 3).cuda()
+    ops.convT_s2_c3_fwd(dev(nhwc(xi)), dev(wt), yt, CW=CW, bias=dev(b), out_add=0.5)
+    assert_close(yt, nhwc(reft), what="convT c3")
+    # adjointness: conv_c3 with the ConvTranspose2d weight is the convT's input gradient
+    xi2 = xi.clone().requires_grad_(True)
+    dy = torch.randn(N, 3, 64, 64, generator=g)
+    F.conv_transpose2d(xi2, wt, None, 2, padding=1).backward(dy)
+    dx = torch.empty(N, 32, 32, CW).cuda()
+    ops.conv_s2_c3_fwd(dev(nhwc(dy)), dev(wt), dx, CW=CW)
+    assert_close(dx, nhwc(xi2.grad), what="convT c3 dgrad")
