@@ -67,8 +67,7 @@ class UpdateRunner:
         self._load(data)
         if self._graphs is None:
             torch.cuda.synchronize()
-            self._capture()
-            return
+            self._capture()  # records only: nothing has executed yet, so fall through and replay
         g1, g2, g3 = self._graphs
         g1.replay()
         self.wm._model_opt.bucket.allreduce()
