@@ -17,6 +17,26 @@
 
 namespace dv3 {
 
+// x / d and x % d without an integer division when d is a power of two (every spatial size and most
+// channel counts here are): runtime integer division is ~40 VALU instructions on CDNA and the im2col
+// address decode would otherwise out-cost the MFMAs it feeds.
+struct FastDiv {
+  int d, shift;  // shift >= 0: d == 1 << shift
+  __host__ __device__ static FastDiv make(int d) {
+    FastDiv f{d, -1};
+    if (d > 0 && (d & (d - 1)) == 0) {
+      int s = 0;
+      while ((1 << s) < d) ++s;
+      f.shift = s;
+    }
+    return f;
+  }
+  __device__ __forceinline__ long quot(long x) const { return shift >= 0 ? (x >> shift) : x / d; }
+  __device__ __forceinline__ int rem(long x) const { return shift >= 0 ? (int)(x & (d - 1)) : (int)(x % d); }
+  __device__ __forceinline__ int quot(int x) const { return shift >= 0 ? (x >> shift) : x / d; }
+  __device__ __forceinline__ int rem(int x) const { return shift >= 0 ? (x & (d - 1)) : x % d; }
+};
+
 // ------------------------------------------------------------------------------------------------
 // A loader for conv_s2: row m = (n, oy, ox) of the output grid, k = (ky, kx, ci).
 // ------------------------------------------------------------------------------------------------
@@ -25,6 +45,7 @@ struct ConvA {
   int H, W, C, OH, OW;
   long M;  // Nimg*OH*OW
   int K;   // 16*C
+  FastDiv dC, dC4;
 };
 
 template <int ROWS, int BK>
@@ -76,9 +97,8 @@ struct ConvATile {
     const int k = k0 + 4 * c;
     if ((op.C & 3) == 0) {
       // 4 consecutive k share (ky,kx): one 16-byte gather or zeros
-      const int c4 = 4 * op.C;
-      const int ky = k / c4, j = k - ky * c4;
-      const int kx = j / op.C, ci = j - kx * op.C;
+      const int ky = op.dC4.quot(k), j = op.dC4.rem(k);
+      const int kx = op.dC.quot(j), ci = op.dC.rem(j);
 #pragma unroll
       for (int p = 0; p < kVecs; ++p) {
         const int iy = iy0[p] + ky, ix = ix0[p] + kx;
@@ -118,6 +138,7 @@ struct ConvTA {
   int IH, IW, C, py, px;
   long M;  // Nimg*IH*IW
   int K;   // 4*C
+  FastDiv dC, dC2;
 };
 
 template <int ROWS, int BK>
@@ -166,9 +187,8 @@ struct ConvTATile {
     const int c = tid % CH;
     const int k = k0 + 4 * c;
     if ((op.C & 3) == 0) {
-      const int c2 = 2 * op.C;
-      const int a = k / c2, j = k - a * c2;
-      const int b = j / op.C, ci = j - b * op.C;
+      const int a = op.dC2.quot(k), j = op.dC2.rem(k);
+      const int b = op.dC.quot(j), ci = op.dC.rem(j);
 #pragma unroll
       for (int p = 0; p < kVecs; ++p) {
         const int iy = y0[p] - a, ix = x0[p] - b;
@@ -207,6 +227,7 @@ struct WgradB {
   int H, W, C, OH, OW;
   long Mrows;  // Nimg*OH*OW  (the reduction length)
   int Ncols;   // 16*C
+  FastDiv dOW, dOH, dC, dC4;
 };
 
 template <int ROWS, int BK>
@@ -240,18 +261,17 @@ struct WgradBTile {
   __device__ __forceinline__ void load(const WgradB& op, int, int k0, int tid) {
     const int kr = tid / CH;
     if ((op.C & 3) == 0) {
-      const int c4 = 4 * op.C;
-      const int ky = jcol / c4, jj = jcol - ky * c4;
-      const int kx = jj / op.C, ci = jj - kx * op.C;
+      const int ky = op.dC4.quot(jcol), jj = op.dC4.rem(jcol);
+      const int kx = op.dC.quot(jj), ci = op.dC.rem(jj);
       const bool colok = jcol < op.Ncols;
 #pragma unroll
       for (int p = 0; p < kVecs; ++p) {
         const long m = (long)k0 + p * KPP + kr;
         const long mc = (m < op.Mrows) ? m : 0;
-        const int ox = (int)(mc % op.OW);
-        const long q = mc / op.OW;
-        const int oy = (int)(q % op.OH);
-        const long n = q / op.OH;
+        const int ox = op.dOW.rem(mc);
+        const long q = op.dOW.quot(mc);
+        const int oy = op.dOH.rem(q);
+        const long n = op.dOH.quot(q);
         const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
         const bool ok = colok && m < op.Mrows && iy >= 0 && iy < op.H && ix >= 0 && ix < op.W;
         const float* src = ok ? op.x + ((n * op.H + iy) * op.W + ix) * op.C + ci : op.x;
@@ -295,7 +315,8 @@ __global__ __launch_bounds__(kThreads) void conv_s2_kernel(ConvParams p) {
   using ATile = ConvATile<TS::BM, TS::BK>;
   using BTile = DenseTile<TS::BN, TS::BK, true>;
   const int OH = p.H / 2, OW = p.W / 2;
-  ConvA aop{p.x, p.H, p.W, p.Ci, OH, OW, (long)p.Nimg * OH * OW, 16 * p.Ci};
+  ConvA aop{p.x, p.H, p.W, p.Ci, OH, OW, (long)p.Nimg * OH * OW, 16 * p.Ci, FastDiv::make(p.Ci),
+            FastDiv::make(4 * p.Ci)};
   DenseOperand<true> bop{p.wp, nullptr, 16L * p.Ci, 0, p.Co, 16 * p.Ci, 16 * p.Ci, true};
   const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
   const int m0 = (wg / p.tiles_n) * TS::BM, n0 = (wg % p.tiles_n) * TS::BN;
@@ -328,7 +349,8 @@ __global__ __launch_bounds__(kThreads) void convT_s2_kernel(ConvParams p) {
   using ATile = ConvTATile<TS::BM, TS::BK>;
   using BTile = DenseTile<TS::BN, TS::BK, true>;
   const int cls = blockIdx.y, py = cls >> 1, px = cls & 1;
-  ConvTA aop{p.x, p.H, p.W, p.Ci, py, px, (long)p.Nimg * p.H * p.W, 4 * p.Ci};
+  ConvTA aop{p.x, p.H, p.W, p.Ci, py, px, (long)p.Nimg * p.H * p.W, 4 * p.Ci, FastDiv::make(p.Ci),
+             FastDiv::make(2 * p.Ci)};
   DenseOperand<true> bop{p.wp + (long)cls * p.Co * 4 * p.Ci, nullptr, 4L * p.Ci, 0, p.Co, 4 * p.Ci, 4 * p.Ci, true};
   const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
   const int m0 = (wg / p.tiles_n) * TS::BM, n0 = (wg % p.tiles_n) * TS::BN;
@@ -364,12 +386,12 @@ __global__ __launch_bounds__(kThreads) void convT_s2_kernel(ConvParams p) {
 struct WgradParams {
   const float* dy;  // [rows][Co]   coarse-grid tensor (conv: dY; convT: the layer input)
   const float* x;   // [Nimg][H][W][Ci]  fine-grid tensor (conv: the layer input; convT: dOut)
-  float* dw;        // [Co][Ci][4][4] accumulated with atomics
+  float* dw;        // packed [Co][(ky,kx,ci)] scratch, accumulated with atomics
   int Nimg, H, W, Ci, Co;
   int tiles_m, tiles_n, splits, chunk;  // chunk: reduction rows per split (multiple of BK)
 };
 
-// dw[co][ci][ky][kx] += sum_m dy[m][co] * x[n,2oy+ky-1,2ox+kx-1,ci]
+// dw_packed[co][(ky,kx,ci)] += sum_m dy[m][co] * x[n,2oy+ky-1,2ox+kx-1,ci]
 template <class TS>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
   __shared__ __attribute__((aligned(16))) float lds[TS::lds_floats];
@@ -378,7 +400,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
   const int OH = p.H / 2, OW = p.W / 2;
   const long rows = (long)p.Nimg * OH * OW;
   DenseOperand<false> aop{p.dy, nullptr, (long)p.Co, 0, p.Co, (int)rows, (int)rows, true};
-  WgradB bop{p.x, p.H, p.W, p.Ci, OH, OW, rows, 16 * p.Ci};
+  WgradB bop{p.x, p.H, p.W, p.Ci, OH, OW, rows, 16 * p.Ci, FastDiv::make(OW), FastDiv::make(OH),
+             FastDiv::make(p.Ci), FastDiv::make(4 * p.Ci)};
   const int tiles = p.tiles_m * p.tiles_n;
   const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
   const int m0 = (tile / p.tiles_n) * TS::BM, n0 = (tile % p.tiles_n) * TS::BN;
@@ -397,15 +420,29 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
     for (int b = 0; b < TS::TN; ++b) {
       const int j = n0 + (wn * TS::TN + b) * 32 + col_l;
       if (j >= 16 * p.Ci) continue;
-      const int c4 = 4 * p.Ci;
-      const int ky = j / c4, jj = j - ky * c4;
-      const int kx = jj / p.Ci, ci = jj - kx * p.Ci;
+      // packed layout [co][(ky,kx,ci)]: a half-wave adds 32 consecutive floats (128 B) per instruction --
+      // the shape fp32 atomics run at full rate on; dv3_unpack_conv_wgrad moves it to [co][ci][ky][kx]
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = m0 + (wm * TS::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < p.Co) atomicAdd(p.dw + (((long)co * p.Ci + ci) * 4 + ky) * 4 + kx, acc[a][b][r]);
+        if (co < p.Co) atomicAdd(p.dw + (long)co * (16 * p.Ci) + j, acc[a][b][r]);
       }
     }
+}
+
+// dw[co][ci][ky][kx] += packed[co][(ky,kx,ci)]; packed is cleared for the next update
+__global__ void unpack_conv_wgrad_kernel(float* __restrict__ packed, float* __restrict__ dw, int Co, int Ci) {
+  const long total = (long)Co * Ci * 16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci);
+    long t = i / Ci;
+    const int kx = (int)(t % 4);
+    t /= 4;
+    const int ky = (int)(t % 4);
+    const long co = t / 4;
+    dw[((co * Ci + ci) * 4 + ky) * 4 + kx] += packed[i];
+    packed[i] = 0.f;
+  }
 }
 
 // Conv2d weight [Co][Ci][4][4] -> [Co][(ky,kx,ci)]
@@ -625,13 +662,13 @@ extern "C" int dv3_convT_s2_fwd(const float* x, const float* w_packed, const flo
   return (int)hipGetLastError();
 }
 
-extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* dw, int Nimg, int H, int W, int Cfine,
-                                 int Ccoarse, void* stream) {
+extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* dw_packed, float* dw, int Nimg, int H,
+                                 int W, int Cfine, int Ccoarse, void* stream) {
   if (Nimg <= 0) return 0;
-  if (!coarse || !fine || !dw || Cfine <= 0 || Ccoarse <= 0 || !pow2_spatial(H, W)) return DV3_ERR_ARG;
+  if (!coarse || !fine || !dw || !dw_packed || Cfine <= 0 || Ccoarse <= 0 || !pow2_spatial(H, W)) return DV3_ERR_ARG;
   const long rows = (long)Nimg * (H / 2) * (W / 2);
   if (rows > 0x7fffffffL - 4096) return DV3_ERR_ARG;
-  WgradParams p{coarse, fine, dw, Nimg, H, W, Cfine, Ccoarse, 0, 0, 0, 0};
+  WgradParams p{coarse, fine, dw_packed, Nimg, H, W, Cfine, Ccoarse, 0, 0, 0, 0};
   using TS = C64;
   p.tiles_m = (Ccoarse + TS::BM - 1) / TS::BM;
   p.tiles_n = (16 * Cfine + TS::BN - 1) / TS::BN;
@@ -647,6 +684,10 @@ extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* 
   p.splits = (int)splits;
   p.chunk = (int)chunk;
   hipLaunchKernelGGL((conv_wgrad_kernel<TS>), dim3((unsigned)(tiles * splits)), dim3(kThreads), 0, (hipStream_t)stream, p);
+  const long total = 16L * Ccoarse * Cfine;
+  unsigned ub = (unsigned)((total + 255) / 256);
+  if (ub > 1024) ub = 1024;
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(ub), dim3(256), 0, (hipStream_t)stream, dw_packed, dw, Ccoarse, Cfine);
   return (int)hipGetLastError();
 }
 

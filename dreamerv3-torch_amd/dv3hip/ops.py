@@ -536,6 +536,9 @@ def convT_s2_fwd(x, wp, y, *, Ci, Co, bias=None, out_add=0.0, accumulate=False):
     return y
 
 
+_WGRAD_SCRATCH = {}
+
+
 def conv_s2_wgrad(coarse, fine, dw):
     """dw[Cc,Cf,4,4] += grad.  coarse [N,H/2,W/2,Cc], fine [N,H,W,Cf] (NHWC)."""
     _contig(coarse, "coarse"), _contig(fine, "fine"), _contig(dw, "dw")
@@ -545,10 +548,47 @@ def conv_s2_wgrad(coarse, fine, dw):
     Cc = coarse.shape[3]
     if coarse.shape[0] != N or coarse.shape[1] * 2 != H or coarse.shape[2] * 2 != W or dw.numel() != 16 * Cc * Cf:
         raise ValueError("wgrad shapes mismatch")
-    _call("dv3_conv_s2_wgrad", _ptr(coarse), _ptr(fine), _ptr(dw), N, H, W, Cf, Cc, _stream(),
-          key="conv_wgrad_kernel" + (f"[N{N} {H}x{W} Cf{Cf} Cc{Cc}]" if PROFILE.by_shape else ""), flops=2.0 * N * (H // 2) * (W // 2) * 16 * Cf * Cc,
+    key = (str(dw.device), dw.data_ptr())  # one zero-initialised packed scratch per weight tensor
+    scratch = _WGRAD_SCRATCH.get(key)
+    if scratch is None or scratch.numel() != dw.numel():
+        scratch = torch.zeros(dw.numel(), dtype=F32, device=dw.device)
+        _WGRAD_SCRATCH[key] = scratch
+    _call("dv3_conv_s2_wgrad", _ptr(coarse), _ptr(fine), _ptr(scratch), _ptr(dw), N, H, W, Cf, Cc, _stream(),
+          key="conv_wgrad_kernel" + (f"[N{N} {H}x{W} Cf{Cf} Cc{Cc}]" if PROFILE.by_shape else ""),
+          flops=2.0 * N * (H // 2) * (W // 2) * 16 * Cf * Cc,
           nbytes=4.0 * (coarse.numel() + fine.numel() + dw.numel()))
     return dw
+
+
+def sumsq_accumulate(x, out):
+    _contig(x, "x"), _contig(out, "out")
+    _call("dv3_sumsq_accumulate", _ptr(x), x.numel(), _ptr(out), _stream())
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, state, *, lr, beta1=0.9, beta2=0.999, eps, clip, weight_decay=0.0,
+              grad_scale=1.0):
+    for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"),
+                  (state, "state")):
+        _contig(t, nm)
+    n = param.numel()
+    if grad.numel() != n or exp_avg.numel() != n or exp_avg_sq.numel() != n or state.numel() < 3:
+        raise ValueError("size mismatch")
+    _call("dv3_adam_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, _ptr(state), float(lr),
+          float(beta1), float(beta2), float(eps), float(clip or 0.0), float(weight_decay or 0.0), float(grad_scale),
+          _stream())
+
+
+def axpby(x, y, a, b):
+    _contig(x, "x"), _contig(y, "y")
+    if x.numel() != y.numel():
+        raise ValueError("size mismatch")
+    _call("dv3_axpby", _ptr(x), _ptr(y), x.numel(), float(a), float(b), _stream())
+    return y
+
+
+def rng_advance(rng_state, increment):
+    _contig(rng_state, "rng_state", torch.int64)
+    _call("dv3_rng_advance", _ptr(rng_state), int(increment), _stream())
 
 
 def symlog(x, y):
@@ -682,37 +722,6 @@ def reset_blend_bwd(dout, is_first, dx=None, dinit=None):
     if is_first.numel() != B:
         raise ValueError("is_first size mismatch")
     _call("dv3_reset_blend_bwd", _ptr(dout), ldo, _ptr(is_first), _ptr(dx), ldx, _ptr(dinit), B, n, _stream())
-
-
-def sumsq_accumulate(x, out):
-    _contig(x, "x"), _contig(out, "out")
-    _call("dv3_sumsq_accumulate", _ptr(x), x.numel(), _ptr(out), _stream())
-
-
-def adam_step(param, grad, exp_avg, exp_avg_sq, state, *, lr, beta1=0.9, beta2=0.999, eps, clip, weight_decay=0.0,
-              grad_scale=1.0):
-    for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"),
-                  (state, "state")):
-        _contig(t, nm)
-    n = param.numel()
-    if grad.numel() != n or exp_avg.numel() != n or exp_avg_sq.numel() != n or state.numel() < 3:
-        raise ValueError("size mismatch")
-    _call("dv3_adam_step", _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, _ptr(state), float(lr),
-          float(beta1), float(beta2), float(eps), float(clip or 0.0), float(weight_decay or 0.0), float(grad_scale),
-          _stream())
-
-
-def axpby(x, y, a, b):
-    _contig(x, "x"), _contig(y, "y")
-    if x.numel() != y.numel():
-        raise ValueError("size mismatch")
-    _call("dv3_axpby", _ptr(x), _ptr(y), x.numel(), float(a), float(b), _stream())
-    return y
-
-
-def rng_advance(rng_state, increment):
-    _contig(rng_state, "rng_state", torch.int64)
-    _call("dv3_rng_advance", _ptr(rng_state), int(increment), _stream())
 
 
 def fill_normal(out, rng: RngStream):

@@ -142,8 +142,10 @@ int dv3_conv_s2_fwd(const float* x, const float* w_packed, float* y, int Nimg, i
                     int accumulate, void* stream);
 int dv3_convT_s2_fwd(const float* x, const float* w_packed, const float* bias, float out_add, float* y, int Nimg,
                      int IH, int IW, int Ci, int Co, int accumulate, void* stream);
-int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* dw, int Nimg, int H, int W, int Cfine,
-                      int Ccoarse, void* stream);
+int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* dw_packed, float* dw, int Nimg, int H, int W,
+                      int Cfine, int Ccoarse, void* stream);
+/* dw_packed: caller-owned scratch of Ccoarse*16*Cfine floats that must be ZERO on entry; partial sums land there
+ * with coalesced fp32 atomics, then are added into dw (reference layout) and the scratch is cleared again. */
 /* The 3-channel image-side layers (first encoder conv 3->CW, last decoder transposed conv CW->3, and each
  * other's input gradient), as HBM-bound VALU kernels with wave-uniform weights read in the REFERENCE layout
  * ([CW][3][4][4] for both; CW in {32, 96} = cnn_depth of the shipped configs). */
