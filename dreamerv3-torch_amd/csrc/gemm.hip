@@ -28,6 +28,7 @@ struct GemmParams {
   int vecA, vecB;
   int tiles_m, tiles_n;
   int splits, kchunk;  // split-K over workgroups (accumulating GEMMs only: partial sums land with atomics)
+  int transC;          // skinny kernel only: store C[col*ldc + row] and index bias by row
 };
 
 template <class TS, bool TA, bool TB>
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < kSkinnyWaves; ++w) v += red[w][t][x];
-      if (p.bias) v += p.bias[col];
-      float* o = p.C + (long)row * p.ldc + col;
+      if (p.bias) v += p.bias[p.transC ? row : col];
+      float* o = p.transC ? p.C + (long)col * p.ldc + row : p.C + (long)row * p.ldc + col;
       if (p.accumulate) v += *o;
       *o = v;
     }
@@ -254,6 +255,21 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
                             const float* bias, int accumulate, int tile, void* stream) {
   if (M <= 0 || N <= 0) return 0;
   if (K < 0 || !A || !B || !C) return DV3_ERR_ARG;
+  if (tile == 7) {
+    // narrow output (N <= 32, e.g. the actor's mean/std heads): C^T[N,M] = W[N,K] * A[M,K]^T on the skinny
+    // kernel, weights as the few-row operand, transposed store.  Needs the plain y = x W^T + b form.
+    if (transA || !transB || A2 || N > 32) return DV3_ERR_ARG;
+    GemmParams q{};
+    q.A = B; q.A2 = nullptr; q.B = A; q.C = C; q.bias = bias;
+    q.M = N; q.N = M; q.K = K; q.K1 = K;
+    q.lda = ldb; q.lda2 = 0; q.ldb = lda; q.ldc = ldc;
+    q.accumulate = accumulate; q.transC = 1;
+    dim3 grid((M + 15) / 16), block(64 * kSkinnyWaves);
+    hipStream_t s7 = (hipStream_t)stream;
+    if (N <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<true, 1>), grid, block, 0, s7, q);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<true, 2>), grid, block, 0, s7, q);
+    return (int)hipGetLastError();
+  }
   GemmParams p{};
   p.A = A; p.A2 = A2; p.B = B; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K; p.K1 = (A2 ? K1 : K);

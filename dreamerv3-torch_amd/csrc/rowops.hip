@@ -683,7 +683,10 @@ extern "C" int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long l
   {
     int lpr0, nv0;
     if (chw_group <= 0 && vec_shape(N, lpr0, nv0)) {
-      DV3_LNV_DISPATCH(ln_act_bwd_vec_kernel, 2048, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, R,
+      // with parameter gradients every block ends with N atomics per array onto the same N addresses: few,
+      // fat blocks (256) keep that contention off the critical path; without them use the whole chip
+      const long cap = dgamma ? 256 : 2048;
+      DV3_LNV_DISPATCH(ln_act_bwd_vec_kernel, cap, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, R,
                        N, act, accumulate_dx);
       return (int)hipGetLastError();
     }

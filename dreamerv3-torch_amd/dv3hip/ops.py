@@ -86,7 +86,7 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
     _lib.check(getattr(lib, fn_name)(*args), fn_name)
 
 
-_TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2"}
+_TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2", 7: "narrowN"}
 
 
 def pick_gemm_tile(M: int, N: int, wgrad: bool = False) -> int:
@@ -142,6 +142,8 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
             tile = 3
         if tile == 6 and A2 is not None and (K1 % 64) != 0:
             tile = 1
+        if N <= 32 and M > 32 and not transA and transB and A2 is None:
+            tile = 7
     _call("dv3_gemm_f32", int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(A2), lda2, K1, _ptr(B), ldb,
           _ptr(C), ldc, _ptr(bias), int(accumulate), tile, s,
           key=(f"gemm_kernel<{_TILE_NAMES[tile]},tA={int(transA)},tB={int(transB)}>"
@@ -170,7 +172,8 @@ def ln_act_fwd(x, gamma, beta, y, mean=None, rstd=None, *, act=True, chw_group=0
             if t.numel() != R:
                 raise ValueError(nm + " size mismatch")
     _call("dv3_ln_act_fwd", _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(y), ldy, _ptr(mean), _ptr(rstd), R, N,
-          int(act), int(chw_group), _stream())
+          int(act), int(chw_group), _stream(),
+          key="dv3_ln_act_fwd" + (f"[{R}x{N}]" if PROFILE.by_shape else ""), nbytes=8.0 * R * N)
     return y
 
 
@@ -199,7 +202,9 @@ def ln_act_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma=None, dbeta=None, *, a
         if dgamma.numel() != N or dbeta.numel() != N:
             raise ValueError("dgamma size mismatch")
     _call("dv3_ln_act_bwd", _ptr(dy), lddy, _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx),
-          lddx, _ptr(dgamma), _ptr(dbeta), R, N, int(act), int(chw_group), int(accumulate_dx), _stream())
+          lddx, _ptr(dgamma), _ptr(dbeta), R, N, int(act), int(chw_group), int(accumulate_dx), _stream(),
+          key="dv3_ln_act_bwd" + (f"[{R}x{N}{' +dgamma' if dgamma is not None else ''}]" if PROFILE.by_shape else ""),
+          nbytes=12.0 * R * N)
     return dx
 
 

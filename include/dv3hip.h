@@ -33,7 +33,9 @@ int dv3_version(void);
  *   A2/K1: optional second K segment (columns K1..K-1 come from A2[m*lda2 + k-K1]); K1 % 32 == 0,
  *          transA must be 0.  Pass A2=NULL for a single operand.
  *   tile: -1 = choose, 0 = 128x128, 1 = 64x64, 2 = 32x128, 3 = skinny (M <= 32, transA = 0: one 16-column
- *         tile per workgroup, K split over its waves, operands straight to the 16x16x4 MFMA registers).
+ *         tile per workgroup, K split over its waves, operands straight to the 16x16x4 MFMA registers),
+ *         4 = 128x128x32, 5 = 64x64x64, 6 = 32x64x64 with K split inside the workgroup, 7 = narrow output
+ *         (N <= 32, transA=0, transB=1, no A2: the skinny kernel on the transposed problem).
  * Replaces nn.Linear forward / its autograd transposes in RSSM.img_step, obs_step
  * (networks.py:195-233), GRUCell.forward (networks.py:762), MLP.forward (networks.py:657-681),
  * ConvDecoder._linear_layer (networks.py:569), and the torch.cat in front of them
