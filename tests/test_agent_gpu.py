@@ -1,0 +1,111 @@
+"""Agent-level drop-in check: the reference's Dreamer class surface (dreamer.py:35-208) driven the way
+tools.simulate drives it -- agent(obs, reset, state) -> (policy_output, state), training updates drawn from a
+dataset iterator, metrics accumulated for the logger, checkpoint round trip through state_dict()."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as Hh
+from tests.golden import common
+
+pytestmark = pytest.mark.gpu
+
+
+class _Logger:
+    def __init__(self):
+        self.step, self.scalars = 0, {}
+
+    def scalar(self, k, v):
+        self.scalars[k] = v
+
+    def video(self, *a, **k):
+        pass
+
+    def write(self, fps=False):
+        pass
+
+
+def _dataset(name):
+    i = 0
+    while True:
+        yield common.make_batch(name, seed=i)
+        i += 1
+
+
+def _obs(n_envs, first):
+    rs = np.random.RandomState(0)
+    return {"image": rs.randint(0, 256, (n_envs, 64, 64, 3)).astype(np.uint8),
+            "is_first": np.full((n_envs,), first), "is_terminal": np.zeros((n_envs,), bool)}
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_onehot"])
+def test_dreamer_agent_trains_and_acts(name):
+    import dreamer
+
+    cfg = Hh.make_config(name)
+    cfg.pretrain, cfg.log_every, cfg.video_pred_log, cfg.train_ratio = 3, 1, False, 512
+    logger = _Logger()
+    agent = dreamer.Dreamer(Hh.obs_space(name), None, cfg, logger, _dataset(name)).to(cfg.device)
+    agent.requires_grad_(False)
+    n_envs, A = 2, common.SHAPES[name]["A"]
+    reset = np.ones(n_envs, bool)
+    out, state = agent(_obs(n_envs, True), reset, None, training=True)  # runs `pretrain` updates, then acts
+    assert agent._update_count == 3
+    assert out["action"].shape == (n_envs, A) and out["logprob"].shape == (n_envs,)
+    assert torch.isfinite(out["action"]).all() and torch.isfinite(out["logprob"]).all()
+    latent, action = state
+    assert set(latent) == {"stoch", "deter", "logit"} and latent["stoch"].sum(-1).eq(1).all()
+    # the logger received the reference's metric keys
+    for k in ("model_loss", "model_grad_norm", "image_loss", "reward_loss", "cont_loss", "kl", "prior_ent",
+              "post_ent", "actor_loss", "value_loss", "actor_grad_norm", "value_grad_norm", "actor_entropy",
+              "EMA_005", "EMA_095", "update_count"):
+        assert k in logger.scalars and np.isfinite(logger.scalars[k]), k
+    # carry the state through further env steps (no reset), eval mode uses the mode of the actor
+    for _ in range(3):
+        out, state = agent(_obs(n_envs, False), np.zeros(n_envs, bool), state, training=False)
+    assert torch.isfinite(out["action"]).all()
+    if name == "tiny_onehot":
+        assert out["action"].sum(-1).eq(1).all()
+    else:
+        assert out["action"].abs().max() <= 1.0 + 1e-6
+    # checkpoint round trip: same keys as the reference's agent_state_dict, loads into a fresh agent
+    sd = agent.state_dict()
+    assert "_wm.dynamics._cell.layers.GRU_linear.weight" in sd and "_task_behavior.ema_vals" in sd
+    assert "_task_behavior._world_model.dynamics.W" in sd  # the reference's aliasing of the world model
+    agent2 = dreamer.Dreamer(Hh.obs_space(name), None, cfg, _Logger(), _dataset(name)).to(cfg.device)
+    agent2.load_state_dict(sd)
+    for k, v in agent2.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
+def test_policy_step_matches_oracle():
+    """One acting step (Dreamer._policy -> encoder -> obs_step -> actor mode) against the oracle."""
+    import dreamer
+
+    from oracle import dv3_oracle as O
+
+    name = "tiny"
+    cfg = Hh.make_config(name)
+    cfg.pretrain = 0
+    agent = dreamer.Dreamer(Hh.obs_space(name), None, cfg, _Logger(), _dataset(name)).to(cfg.device)
+    w = common.make_weights(name)
+    sd = agent.state_dict()
+    for k in sd:
+        key = k.replace("_wm.", "", 1) if k.startswith("_wm.") else k.replace("_task_behavior.", "", 1)
+        if key.startswith("_world_model."):
+            key = key[len("_world_model."):]
+        if key in w:
+            sd[k] = torch.from_numpy(w[key])
+    agent.load_state_dict(sd)
+    agent.requires_grad_(False)
+    obs = _obs(3, True)
+    out, (latent, action) = agent._policy(obs, None, training=False)
+    pc = common.path_config(name)
+    p = {k: torch.from_numpy(v) for k, v in w.items()}
+    img = torch.from_numpy(obs["image"]).float() / 255.0
+    embed = O.conv_encoder(pc, p, img[:, None])[:, 0]
+    post, _ = O.obs_step(pc, p, None, None, embed, torch.ones(3), None, None, sample=False)
+    feat = O.get_feat(pc, post)
+    mean, std = O.actor_stats(pc, p, feat)
+    assert torch.allclose(latent["deter"].cpu(), post["deter"], atol=1e-4)
+    assert torch.allclose(latent["logit"].cpu(), post["logit"], atol=1e-4)
