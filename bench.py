@@ -186,16 +186,38 @@ def main():
         runner.step(data, eager=True)
         prof = ops.PROFILE.stop()
         mf = {k: v for k, v in prof.items() if v["flops"] > 0}
-        dom = max(mf, key=lambda k: mf[k]["ms"])
-        d = mf[dom]
+        # MFMA-bound candidates: the tile-engine kernels.  The M = batch scan GEMM ("skinny16"/"narrowN") is a
+        # weight-streaming, latency-bound kernel and is reported on its own below.
+        tile_engine = {k: v for k, v in mf.items() if "skinny16" not in k and "narrowN" not in k}
+        dom = max(tile_engine, key=lambda k: tile_engine[k]["ms"])
+        d = tile_engine[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         tot_fl, tot_ms = sum(v["flops"] for v in mf.values()), sum(v["ms"] for v in mf.values())
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+        sym = ops.kernel_symbol(dom)
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            if sym in pmc:
+                traffic = pmc[sym]["bytes_per_launch"]
+                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
+        scan = {k: v for k, v in mf.items() if "skinny16" in k}
+        scan_ms = sum(v["ms"] for v in scan.values())
+        scan_n = sum(v["launches"] for v in scan.values())
+        scan_bytes = sum(v["bytes"] for v in scan.values())
+        roofline = {"bound": "mfma", "kernel": dom, "kernel_symbol": sym, "achieved": ach,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_update": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                     "flops_per_launch": d["flops"] / d["launches"],
+                    "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                     "all_mfma_kernels": {"achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
                                          "gflop_per_update": tot_fl / 1e9, "ms_per_update": tot_ms},
+                    "scan_gemm": {"bound": "hbm", "kernel": "gemm_skinny_kernel (M = batch rows of the observe scan)",
+                                  "launches_per_update": scan_n, "avg_launch_us": scan_ms * 1e3 / max(scan_n, 1),
+                                  "achieved": scan_bytes / max(scan_ms * 1e-3, 1e-12) / 1e9, "unit": "GB/s",
+                                  "peak": 8000.0, "note": "weight stream served by L2 / Infinity Cache; latency-bound"},
                     "by_kernel": {k: {"ms": round(v["ms"], 3), "n": v["launches"],
                                       "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
                                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:(40 if args.by_shape else 16)]}}

@@ -89,6 +89,26 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
 _TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2", 7: "narrowN"}
 
 
+_TILE_TEMPLATES = {0: "2, 2, 2, 2, 16, 1", 1: "2, 2, 1, 1, 32, 1", 2: "1, 4, 1, 1, 32, 1", 4: "2, 2, 2, 2, 32, 1",
+                   5: "2, 2, 1, 1, 64, 1", 6: "1, 2, 1, 1, 64, 2"}
+
+
+def kernel_symbol(key: str) -> str:
+    """Profile key -> the C++ kernel name rocprofv3 prints (to match bench.py's roofline with profiles/)."""
+    import re
+
+    m = re.match(r"gemm_kernel<([^,]+),tA=(\d),tB=(\d)>", key)
+    if m:
+        tile = {v: k for k, v in _TILE_NAMES.items()}[m.group(1)]
+        ta, tb = ("true" if m.group(2) == "1" else "false"), ("true" if m.group(3) == "1" else "false")
+        if tile in (3, 7):
+            return f"void dv3::gemm_skinny_kernel<{tb if tile == 3 else 'true'}, 1>(dv3::GemmParams)"
+        return f"void dv3::gemm_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, {ta}, {tb}>(dv3::GemmParams)"
+    if key.startswith("conv_wgrad_kernel"):
+        return "void dv3::conv_wgrad_kernel<dv3::TileShape<2, 2, 1, 1, 32, 1> >(dv3::WgradParams)"
+    return key
+
+
 def pick_gemm_tile(M: int, N: int, wgrad: bool = False) -> int:
     """Tile choice (mirrors csrc/gemm.hip): small outputs take the 32x64 tile with the K split inside the
     workgroup (fills the 256 CUs when M*N is small); otherwise minimise (waves of workgroups over 256 CUs)
