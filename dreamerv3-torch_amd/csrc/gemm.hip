@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
 // identically for A and B (still an exact fp32 fma chain, in a different order).
 // ------------------------------------------------------------------------------------------------
 constexpr int kSkinnyWaves = 8;   // K is split over the waves of a workgroup
-constexpr int kSkinnyBatch = 4;   // 16-k chunks whose loads are issued together before their MFMAs
+constexpr int kSkinnyBatch = 6;   // 16-k chunks whose loads are issued together before their MFMAs
 
 template <bool TB, int MT>
 __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmParams p) {

@@ -328,21 +328,20 @@ __global__ void obs_blend_bwd_kernel(const float* __restrict__ dsin, const float
                                      const float* __restrict__ first, float* __restrict__ gs_prev,
                                      float* __restrict__ gd_prev, float* __restrict__ ds0,
                                      float* __restrict__ dd0, int B, int SD, int De) {
+  // one thread per (row, column): the carry is a plain read-modify-write; the initial-state gradient only
+  // receives anything on reset rows (rare), so its atomics almost never execute
   const int W = SD + De;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < W; j += gridDim.x * blockDim.x) {
+  const long total = (long)B * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / W), j = (int)(i % W);
     const bool is_s = j < SD;
     const int k = is_s ? j : j - SD;
     const int w = is_s ? SD : De;
-    const float* src = is_s ? dsin : ddin;
+    const float m = first[b];
+    const float g = (is_s ? dsin : ddin)[(long)b * w + k];
     float* prev = is_s ? gs_prev : gd_prev;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float m = first[b];
-      const float g = src[(long)b * w + k];
-      if (prev) prev[(long)b * w + k] += g * (1.f - m);
-      acc += g * m;
-    }
-    (is_s ? ds0 : dd0)[k] += acc;
+    if (prev) prev[(long)b * w + k] += g * (1.f - m);
+    if (m != 0.f) atomicAdd((is_s ? ds0 : dd0) + k, g * m);
   }
 }
 
@@ -808,7 +807,7 @@ extern "C" int dv3_obs_blend_bwd(const float* dsin, const float* ddin, const flo
   if (B <= 0) return 0;
   if (!dsin || !ddin || !is_first || !dstoch0 || !ddeter0) return DV3_ERR_ARG;
   if ((gs_prev == nullptr) != (gd_prev == nullptr)) return DV3_ERR_ARG;
-  hipLaunchKernelGGL(obs_blend_bwd_kernel, dim3(nblk(SD + De, 256, 1024)), dim3(256), 0, S_, dsin, ddin, is_first, gs_prev,
-                     gd_prev, dstoch0, ddeter0, B, SD, De);
+  hipLaunchKernelGGL(obs_blend_bwd_kernel, dim3(nblk((long)B * (SD + De), 256, 1024)), dim3(256), 0, S_, dsin, ddin,
+                     is_first, gs_prev, gd_prev, dstoch0, ddeter0, B, SD, De);
   return (int)hipGetLastError();
 }

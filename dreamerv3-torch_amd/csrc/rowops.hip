@@ -334,6 +334,133 @@ __global__ __launch_bounds__(256) void ln_act_fwd_vec_kernel(const float* __rest
   }
 }
 
+constexpr int kColRoleRows = 128;  // rows per column-role workgroup (32 per wave)
+constexpr int kColBatch = 8;       // rows a wave loads together (branch-free, clamped) before using them
+
+// ------------------------------------------------------------------------------------------------
+// Column role for d-gamma / d-beta (the observe scan issues these kernels with 16 rows once per step, on the
+// critical path; the heads with 1k-15k rows).
+// A CU can retire roughly one 256-byte atomic instruction per 50 ns, so flushing d-gamma / d-beta from the
+// 1..4 row-role workgroups that few rows give costs 10-17 us -- several times the kernel itself.  Instead the
+// same launch carries extra workgroups that OWN 64 columns each: lane = column, the 4 waves split the rows,
+// the partial column sums meet in LDS and one plain read-modify-write per column finishes the job.  No
+// atomics, no second launch, and the two roles run concurrently on different CUs (both only read inputs).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ln_bwd_cols(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta, long R, int N, int act,
+                                            int cblk, float* lds) {
+  // cblk = slice * ncb + cb: with more than kColRoleRows rows the rows are cut into slices of that many, one
+  // set of column workgroups per slice, and the slices meet through one atomic per column
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ncb = (N + 63) / 64, cb = cblk % ncb, slice = cblk / ncb;
+  const bool single = R <= kColRoleRows;
+  x += (long)slice * kColRoleRows * ldx;
+  dy += (long)slice * kColRoleRows * lddy;
+  mean_in += (long)slice * kColRoleRows;
+  rstd_in += (long)slice * kColRoleRows;
+  R -= (long)slice * kColRoleRows;
+  if (R > kColRoleRows) R = kColRoleRows;
+  const int c = cb * 64 + lane;
+  const bool ok = c < N;
+  const int cc = ok ? c : 0;
+  const float g = gamma[cc], b = beta[cc];
+  float pg = 0.f, pb = 0.f;
+  for (int r0 = wave; r0 < (int)R; r0 += 4 * kColBatch) {
+    float xv[kColBatch], dv[kColBatch], mu[kColBatch], rs[kColBatch];
+#pragma unroll
+    for (int i = 0; i < kColBatch; ++i) {  // clamped rows: branch-free loads, all in flight together
+      const int r = r0 + 4 * i, rr = r < (int)R ? r : (int)R - 1;
+      xv[i] = x[(long)rr * ldx + cc];
+      dv[i] = dy[(long)rr * lddy + cc];
+      mu[i] = mean_in[rr];
+      rs[i] = rstd_in[rr];
+    }
+#pragma unroll
+    for (int i = 0; i < kColBatch; ++i) {
+      const float xh = (xv[i] - mu[i]) * rs[i];
+      float dz = (r0 + 4 * i < (int)R) ? dv[i] : 0.f;
+      if (act) dz *= dsiluf_(xh * g + b);
+      pg += dz * xh;
+      pb += dz;
+    }
+  }
+  lds[wave * 128 + lane] = pg;
+  lds[wave * 128 + 64 + lane] = pb;
+  __syncthreads();
+  if (wave == 0 && ok) {
+    const float sg = lds[lane] + lds[128 + lane] + lds[256 + lane] + lds[384 + lane];
+    const float sb = lds[64 + lane] + lds[192 + lane] + lds[320 + lane] + lds[448 + lane];
+    if (single) {
+      dgamma[c] += sg;
+      dbeta[c] += sb;
+    } else {
+      atomicAdd(dgamma + c, sg);
+      atomicAdd(dbeta + c, sb);
+    }
+  }
+}
+
+__device__ __forceinline__ void gru_bwd_cols(const float* __restrict__ dhn, long lddhn, const float* __restrict__ p,
+                                             long ldp, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             const float* __restrict__ h, long ldh, const float* __restrict__ mean_in,
+                                             const float* __restrict__ rstd_in, float* __restrict__ dgamma,
+                                             float* __restrict__ dbeta, int M, int De, int cblk, float* lds) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ncb = De / 64, cb = cblk % ncb, slice = cblk / ncb;  // row slices as in ln_bwd_cols
+  const bool single = M <= kColRoleRows;
+  p += (long)slice * kColRoleRows * ldp;
+  h += (long)slice * kColRoleRows * ldh;
+  dhn += (long)slice * kColRoleRows * lddhn;
+  mean_in += slice * kColRoleRows;
+  rstd_in += slice * kColRoleRows;
+  M -= slice * kColRoleRows;
+  if (M > kColRoleRows) M = kColRoleRows;
+  const int j = cb * 64 + lane;  // hidden unit; De % 64 == 0
+  const float gr = gamma[j], gc = gamma[De + j], gu = gamma[2 * De + j];
+  const float br = beta[j], bc = beta[De + j], bu = beta[2 * De + j];
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r0 = wave; r0 < M; r0 += 4 * kColBatch) {
+    float pr[kColBatch], pc[kColBatch], pu[kColBatch], hp[kColBatch], go[kColBatch], mu[kColBatch], rs[kColBatch];
+#pragma unroll
+    for (int i = 0; i < kColBatch; ++i) {
+      const int r = r0 + 4 * i, rr = r < M ? r : M - 1;
+      const float* row = p + (long)rr * ldp;
+      pr[i] = row[j];
+      pc[i] = row[De + j];
+      pu[i] = row[2 * De + j];
+      hp[i] = h[(long)rr * ldh + j];
+      go[i] = dhn[(long)rr * lddhn + j];
+      mu[i] = mean_in[rr];
+      rs[i] = rstd_in[rr];
+    }
+#pragma unroll
+    for (int i = 0; i < kColBatch; ++i) {
+      const float xr = (pr[i] - mu[i]) * rs[i], xc = (pc[i] - mu[i]) * rs[i], xu = (pu[i] - mu[i]) * rs[i];
+      const float yr = xr * gr + br, yc = xc * gc + bc, yu = xu * gu + bu;
+      const float rg = sigmoidf_(yr), cg = tanhf(rg * yc), ug = sigmoidf_(yu - 1.f);
+      const float g = (r0 + 4 * i < M) ? go[i] : 0.f;
+      const float drc = g * ug * (1.f - cg * cg);
+      const float dyr = drc * yc * rg * (1.f - rg), dyc = drc * rg, dyu = g * (cg - hp[i]) * ug * (1.f - ug);
+      acc[0] += dyr * xr; acc[1] += dyc * xc; acc[2] += dyu * xu;
+      acc[3] += dyr; acc[4] += dyc; acc[5] += dyu;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) lds[(wave * 6 + k) * 64 + lane] = acc[k];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float v = lds[k * 64 + lane] + lds[(6 + k) * 64 + lane] + lds[(12 + k) * 64 + lane] + lds[(18 + k) * 64 + lane];
+      float* dst = (k < 3 ? dgamma : dbeta) + (k % 3) * De + j;
+      if (single) *dst += v;
+      else atomicAdd(dst, v);
+    }
+  }
+}
+
 template <int LPR, int NV>
 __global__ __launch_bounds__(256) void ln_act_bwd_vec_kernel(const float* __restrict__ dy, long lddy,
                                                              const float* __restrict__ x, long ldx,
@@ -343,11 +470,17 @@ __global__ __launch_bounds__(256) void ln_act_bwd_vec_kernel(const float* __rest
                                                              const float* __restrict__ rstd_in,
                                                              float* __restrict__ dx, long lddx,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             long R, int N, int act, int accumulate_dx) {
+                                                             long R, int N, int act, int accumulate_dx, int row_blocks) {
   constexpr int RPB = 256 / LPR;
   const int sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
   __shared__ float red[2][64 * kMaxV];
-  for (int c = threadIdx.x; c < N; c += 256) {
+  if ((int)blockIdx.x >= row_blocks) {  // column role: owns 64 columns of d-gamma / d-beta
+    ln_bwd_cols(dy, lddy, x, ldx, gamma, beta, mean_in, rstd_in, dgamma, dbeta, R, N, act, (int)blockIdx.x - row_blocks,
+                &red[0][0]);
+    return;
+  }
+  const bool flush = dgamma && (int)gridDim.x == row_blocks;
+  if (flush) for (int c = threadIdx.x; c < N; c += 256) {
     red[0][c] = 0.f;
     red[1][c] = 0.f;
   }
@@ -363,7 +496,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_vec_kernel(const float* __rest
     pb[v] = (f4){0.f, 0.f, 0.f, 0.f};
   }
   const float inv_n = 1.f / (float)N;
-  for (long r = (long)blockIdx.x * RPB + sub; r < R; r += (long)gridDim.x * RPB) {
+  for (long r = (long)blockIdx.x * RPB + sub; r < R; r += (long)row_blocks * RPB) {
     const float mean = mean_in[r], rstd = rstd_in[r];
     f4 xh[NV], dxh[NV];
     float s1 = 0.f, s2 = 0.f;
@@ -400,7 +533,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_vec_kernel(const float* __rest
       }
     }
   }
-  if (dgamma) {
+  if (flush) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int c = 4 * (l + LPR * v);
@@ -485,13 +618,19 @@ __global__ __launch_bounds__(256) void gru_bwd_vec_kernel(const float* __restric
                                                           const float* __restrict__ rstd_in, float* __restrict__ dp,
                                                           long lddp, float* __restrict__ dh, long lddh,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
-                                                          int De, int accumulate_dh) {
+                                                          int De, int accumulate_dh, int row_blocks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 x 3*De block accumulators (dgamma, dbeta)
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int N = 3 * De;
   float* accg = smem;
   float* accb = smem + N;
-  if (dgamma) {
+  if ((int)blockIdx.x >= row_blocks) {  // column role: owns 64 hidden units of d-gamma / d-beta
+    gru_bwd_cols(dhn, lddhn, p, ldp, gamma, beta, h, ldh, mean_in, rstd_in, dgamma, dbeta, M, De,
+                 (int)blockIdx.x - row_blocks, smem);
+    return;
+  }
+  const bool flush = dgamma && (int)gridDim.x == row_blocks;
+  if (flush) {
     for (int c = threadIdx.x; c < 2 * N; c += 256) smem[c] = 0.f;
     __syncthreads();
   }
@@ -504,7 +643,7 @@ __global__ __launch_bounds__(256) void gru_bwd_vec_kernel(const float* __restric
       pg[gte][v] = (f4){0.f, 0.f, 0.f, 0.f};
       pb[gte][v] = (f4){0.f, 0.f, 0.f, 0.f};
     }
-  for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
+  for (int r = blockIdx.x * 4 + wave; r < M; r += row_blocks * 4) {
     const float* pr = p + (long)r * ldp;
     const float mean = mean_in[r], rstd = rstd_in[r];
     f4 xh[3][NVG], dy[3][NVG];
@@ -561,7 +700,7 @@ __global__ __launch_bounds__(256) void gru_bwd_vec_kernel(const float* __restric
         *reinterpret_cast<f4u*>(dp + (long)r * lddp + gte * De + j) = (dy[gte][v] - s1 - xh[gte][v] * s2) * rstd;
       }
   }
-  if (dgamma) {
+  if (flush) {
 #pragma unroll
     for (int gte = 0; gte < 3; ++gte)
 #pragma unroll
@@ -580,6 +719,7 @@ __global__ __launch_bounds__(256) void gru_bwd_vec_kernel(const float* __restric
     }
   }
 }
+
 
 template <int LPR, int NV>
 static void launch_ln_fwd(const float* x, long ldx, const float* g, const float* b, float* y, long ldy, float* mean,
@@ -638,14 +778,14 @@ static bool vec_shape(int N, int& lpr, int& nv) {
   nv = (chunks + lpr - 1) / lpr;
   return nv <= 8;
 }
-#define DV3_LNV_DISPATCH(KERNEL, GRIDCAP, ...)                                                       \
+#define DV3_LNV_DISPATCH(KERNEL, GRIDCAP, EXTRA, ...)                                                     \
   do {                                                                                               \
     int lpr_, nv_;                                                                                   \
     vec_shape(N, lpr_, nv_);                                                                         \
     const long rpb_ = 256 / lpr_;                                                                    \
     long blocks_ = (R + rpb_ - 1) / rpb_;                                                            \
     if (blocks_ > (GRIDCAP)) blocks_ = (GRIDCAP);                                                    \
-    const dim3 g_((unsigned)blocks_), b_(256);                                                       \
+    const dim3 g_((unsigned)(blocks_ + (EXTRA))), b_(256);                                           \
     if (lpr_ == 4) hipLaunchKernelGGL((KERNEL<4, 1>), g_, b_, 0, s, __VA_ARGS__);                    \
     else if (lpr_ == 8) hipLaunchKernelGGL((KERNEL<8, 1>), g_, b_, 0, s, __VA_ARGS__);               \
     else if (lpr_ == 16) hipLaunchKernelGGL((KERNEL<16, 1>), g_, b_, 0, s, __VA_ARGS__);             \
@@ -664,7 +804,7 @@ extern "C" int dv3_ln_act_fwd(const float* x, long ldx, const float* gamma, cons
   {
     int lpr0, nv0;
     if (chw_group <= 0 && vec_shape(N, lpr0, nv0)) {
-      DV3_LNV_DISPATCH(ln_act_fwd_vec_kernel, 8192, x, ldx, gamma, beta, y, ldy, mean, rstd, R, N, act);
+      DV3_LNV_DISPATCH(ln_act_fwd_vec_kernel, 8192, 0, x, ldx, gamma, beta, y, ldy, mean, rstd, R, N, act);
       return (int)hipGetLastError();
     }
   }
@@ -685,9 +825,15 @@ extern "C" int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long l
     if (chw_group <= 0 && vec_shape(N, lpr0, nv0)) {
       // with parameter gradients every block ends with N atomics per array onto the same N addresses: few,
       // fat blocks (256) keep that contention off the critical path; without them use the whole chip
-      const long cap = dgamma ? 256 : 2048;
-      DV3_LNV_DISPATCH(ln_act_bwd_vec_kernel, cap, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, R,
-                       N, act, accumulate_dx);
+      // d-gamma / d-beta: wide rows (N >= 256) get column-role workgroups -- flushing N atomics per row-role
+      // workgroup is what dominates there; narrow rows (conv channels, R up to 1M) keep the atomic flush from
+      // few fat workgroups, which is cheap for small N and does not re-read the (HBM-bound) inputs.
+      // (Never when dx overwrites dy in place: the column role re-reads dy while the row role writes dx.)
+      const bool col_role = dgamma && dx != dy && N >= 256;
+      const long cap = (dgamma && !col_role) ? 256 : 2048;
+      const int col_blocks = col_role ? ((N + 63) / 64) * (int)((R + kColRoleRows - 1) / kColRoleRows) : 0;
+      DV3_LNV_DISPATCH(ln_act_bwd_vec_kernel, cap, col_blocks, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma,
+                       dbeta, R, N, act, accumulate_dx, (int)blocks_);
       return (int)hipGetLastError();
     }
   }
@@ -729,8 +875,10 @@ extern "C" int dv3_gru_bwd(const float* dh_new, long lddhn, const float* p, long
   if (De % 256 == 0 && De <= 1024) {
     hipStream_t s = (hipStream_t)stream;
     const size_t sh = (size_t)2 * 3 * De * sizeof(float);
-#define DV3_GRUB(NVG_) hipLaunchKernelGGL((gru_bwd_vec_kernel<NVG_>), dim3(blocks), dim3(256), sh, s, dh_new, lddhn, p, ldp, \
-                                          gamma, beta, h, ldh, mean, rstd, dp, lddp, dh, lddh, dgamma, dbeta, M, De, accumulate_dh)
+    const int col_blocks =
+        (dgamma && dh != dh_new && dh != h && dp != p) ? (De / 64) * ((M + kColRoleRows - 1) / kColRoleRows) : 0;
+#define DV3_GRUB(NVG_) hipLaunchKernelGGL((gru_bwd_vec_kernel<NVG_>), dim3(blocks + col_blocks), dim3(256), sh, s, dh_new, lddhn, p, ldp, \
+                                          gamma, beta, h, ldh, mean, rstd, dp, lddp, dh, lddh, dgamma, dbeta, M, De, accumulate_dh, blocks)
     if (De == 256) DV3_GRUB(1);
     else if (De == 512) DV3_GRUB(2);
     else if (De == 768) DV3_GRUB(3);
