@@ -91,19 +91,22 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
 // and issues 4 MFMAs; element g of both fragments is k = k+4q+g, so the k-order is permuted
 // identically for A and B (still an exact fp32 fma chain, in a different order).
 // ------------------------------------------------------------------------------------------------
-constexpr int kSkinnyWaves = 8;   // K is split over the waves of a workgroup
+constexpr int kSkinnyWaves = 8;   // K is split over the waves of a workgroup (4 when K is also split over workgroups)
 constexpr int kSkinnyBatch = 6;   // 16-k chunks whose loads are issued together before their MFMAs
 
 template <bool TB, int MT>
 __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmParams p) {
   __shared__ float red[kSkinnyWaves][MT][256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nwaves = blockDim.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * 16;
-  // K range of this wave, in 16-k chunks
+  // K range of this workgroup (gridDim.y splits, accumulating calls only), then of this wave, in 16-k chunks
   const int chunks = (p.K + 15) >> 4;
-  const int per = (chunks + kSkinnyWaves - 1) / kSkinnyWaves;
-  const int cb = wave * per, ce = min(chunks, cb + per);
+  const int per_wg = (chunks + gridDim.y - 1) / gridDim.y;
+  const int wcb = blockIdx.y * per_wg, wce = min(chunks, wcb + per_wg);
+  const int per = (max(wce - wcb, 0) + nwaves - 1) / nwaves;
+  const int cb = wcb + wave * per, ce = min(wce, cb + per);
   f32x4 acc[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -122,16 +125,18 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
     arow[t] = p.A + (long)(ok ? row : 0) * p.lda;
     arow2[t] = p.A2 ? p.A2 + (long)(ok ? row : 0) * p.lda2 : nullptr;
   }
-  // chunks whose 4-element groups are entirely inside K (and inside their A segment) take the fast path
   for (int c0 = cb; c0 < ce; c0 += kSkinnyBatch) {
     f32x4 a[kSkinnyBatch][MT], b[kSkinnyBatch];
-    const bool fast = (c0 + kSkinnyBatch <= ce) && ((c0 + kSkinnyBatch) * 16 <= p.K) &&
-                      ((c0 * 16 >= p.K1) || ((c0 + kSkinnyBatch) * 16 <= p.K1));
+    // chunks of the batch beyond this wave's range are clamped onto its last chunk (loaded, never multiplied);
+    // the fast path needs every loaded 4-element group inside K and inside one A segment
+    const int clast = ce - 1;
+    const int cend = min(c0 + kSkinnyBatch, ce);
+    const bool fast = (cend * 16 <= p.K) && ((c0 * 16 >= p.K1) || (cend * 16 <= p.K1));
     if (fast) {
       const bool seg2 = c0 * 16 >= p.K1;
 #pragma unroll
       for (int u = 0; u < kSkinnyBatch; ++u) {
-        const int k = ((c0 + u) << 4) + 4 * q;
+        const int k = (min(c0 + u, clast) << 4) + 4 * q;
 #pragma unroll
         for (int t = 0; t < MT; ++t)
           a[u][t] = *reinterpret_cast<const f32x4u*>(seg2 ? arow2[t] + (k - p.K1) : arow[t] + k);
@@ -172,11 +177,13 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
     }
 #pragma unroll
     for (int u = 0; u < kSkinnyBatch; ++u)
+      if (c0 + u < ce) {  // wave-uniform
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t][g] * amask[t], b[u][g] * bmask, acc[t], 0, 0, 0);
+          for (int t = 0; t < MT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t][g] * amask[t], b[u][g] * bmask, acc[t], 0, 0, 0);
+      }
   }
 #pragma unroll
   for (int t = 0; t < MT; ++t)
@@ -184,20 +191,40 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
     for (int r = 0; r < 4; ++r) red[wave][t][r * 64 + lane] = acc[t][r];
   __syncthreads();
   // finish the MT*256 outputs: element x = r*64 + lane -> row 4*(lane>>4)+r (+16 t), col lane&15
-  for (int e = tid; e < MT * 256; e += 64 * kSkinnyWaves) {
+  const bool split = gridDim.y > 1;
+  for (int e = tid; e < MT * 256; e += blockDim.x) {
     const int t = e >> 8, x = e & 255;
     const int r = x >> 6, l = x & 63;
     const int row = 16 * t + 4 * (l >> 4) + r, col = n0 + (l & 15);
     if (row < p.M && col < p.N) {
       float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < kSkinnyWaves; ++w) v += red[w][t][x];
-      if (p.bias) v += p.bias[p.transC ? row : col];
+      for (int w = 0; w < nwaves; ++w) v += red[w][t][x];
+      if (p.bias && blockIdx.y == 0) v += p.bias[p.transC ? row : col];
       float* o = p.transC ? p.C + (long)col * p.ldc + row : p.C + (long)row * p.ldc + col;
-      if (p.accumulate) v += *o;
-      *o = v;
+      if (split) {
+        atomicAdd(o, v);  // accumulate semantics: C already holds the value being added to
+      } else {
+        if (p.accumulate) v += *o;
+        *o = v;
+      }
     }
   }
+}
+
+// K splits for an accumulating skinny call: enough workgroups of 4 waves to put ~1k waves on the chip while
+// leaving every wave at least two 16-k chunks
+static void skinny_launch_shape(int N, int K, int accumulate, dim3& grid, dim3& block) {
+  const int tiles = (N + 15) / 16, chunks = (K + 15) / 16;
+  int splits = 1, waves = kSkinnyWaves;
+  if (accumulate) {
+    waves = 4;
+    splits = (1024 + tiles * waves - 1) / (tiles * waves);
+    const int maxs = chunks / (2 * waves);
+    if (splits > maxs) splits = maxs;
+    if (splits <= 1) { splits = 1; waves = kSkinnyWaves; }
+  }
+  grid = dim3(tiles, splits);
+  block = dim3(64 * waves);
 }
 
 template <class TS>
@@ -264,7 +291,8 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
     q.M = N; q.N = M; q.K = K; q.K1 = K;
     q.lda = ldb; q.lda2 = 0; q.ldb = lda; q.ldc = ldc;
     q.accumulate = accumulate; q.transC = 1;
-    dim3 grid((M + 15) / 16), block(64 * kSkinnyWaves);
+    dim3 grid, block;
+    skinny_launch_shape(q.N, q.K, accumulate, grid, block);
     hipStream_t s7 = (hipStream_t)stream;
     if (N <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<true, 1>), grid, block, 0, s7, q);
     else hipLaunchKernelGGL((gemm_skinny_kernel<true, 2>), grid, block, 0, s7, q);
@@ -288,7 +316,8 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   if (t == 3) {
     // skinny path: M <= 32, A k-contiguous; segment edge on a 16-k chunk boundary
     if (M > 32 || transA || (A2 && (K1 % 16) != 0)) return DV3_ERR_ARG;
-    dim3 grid((N + 15) / 16), block(64 * kSkinnyWaves);
+    dim3 grid, block;
+    skinny_launch_shape(N, K, accumulate, grid, block);
     if (M <= 16) {
       if (transB) hipLaunchKernelGGL((gemm_skinny_kernel<true, 1>), grid, block, 0, s, p);
       else hipLaunchKernelGGL((gemm_skinny_kernel<false, 1>), grid, block, 0, s, p);

@@ -324,8 +324,8 @@ __global__ void obs_blend_kernel(const float* __restrict__ ps, const float* __re
 }
 // backward of the stoch / deter blends: gs_prev += dsin*(1-m), gd_prev += ddin*(1-m) (skipped when NULL),
 // dstoch0 += sum_b dsin*m, ddeter0 += sum_b ddin*m
-__global__ void obs_blend_bwd_kernel(const float* __restrict__ dsin, const float* __restrict__ ddin,
-                                     const float* __restrict__ first, float* __restrict__ gs_prev,
+__global__ void obs_blend_bwd_kernel(const float* __restrict__ dsin, long ld_dsin, const float* __restrict__ ddin,
+                                     long ld_ddin, const float* __restrict__ first, float* __restrict__ gs_prev,
                                      float* __restrict__ gd_prev, float* __restrict__ ds0,
                                      float* __restrict__ dd0, int B, int SD, int De) {
   // one thread per (row, column): the carry is a plain read-modify-write; the initial-state gradient only
@@ -338,7 +338,7 @@ __global__ void obs_blend_bwd_kernel(const float* __restrict__ dsin, const float
     const int k = is_s ? j : j - SD;
     const int w = is_s ? SD : De;
     const float m = first[b];
-    const float g = (is_s ? dsin : ddin)[(long)b * w + k];
+    const float g = is_s ? dsin[(long)b * ld_dsin + k] : ddin[(long)b * ld_ddin + k];
     float* prev = is_s ? gs_prev : gd_prev;
     if (prev) prev[(long)b * w + k] += g * (1.f - m);
     if (m != 0.f) atomicAdd((is_s ? ds0 : dd0) + k, g * m);
@@ -802,12 +802,13 @@ extern "C" int dv3_obs_blend(const float* prev_stoch, const float* init_stoch, c
                      init_stoch, prev_deter, init_deter, action, is_first, out_stoch, out_deter, out_action, B, SD, De, A);
   return (int)hipGetLastError();
 }
-extern "C" int dv3_obs_blend_bwd(const float* dsin, const float* ddin, const float* is_first, float* gs_prev,
-                                 float* gd_prev, float* dstoch0, float* ddeter0, int B, int SD, int De, void* stream) {
+extern "C" int dv3_obs_blend_bwd(const float* dsin, long ld_dsin, const float* ddin, long ld_ddin, const float* is_first,
+                                 float* gs_prev, float* gd_prev, float* dstoch0, float* ddeter0, int B, int SD, int De,
+                                 void* stream) {
   if (B <= 0) return 0;
-  if (!dsin || !ddin || !is_first || !dstoch0 || !ddeter0) return DV3_ERR_ARG;
+  if (!dsin || !ddin || !is_first || !dstoch0 || !ddeter0 || ld_dsin < SD || ld_ddin < De) return DV3_ERR_ARG;
   if ((gs_prev == nullptr) != (gd_prev == nullptr)) return DV3_ERR_ARG;
-  hipLaunchKernelGGL(obs_blend_bwd_kernel, dim3(nblk((long)B * (SD + De), 256, 1024)), dim3(256), 0, S_, dsin, ddin,
-                     is_first, gs_prev, gd_prev, dstoch0, ddeter0, B, SD, De);
+  hipLaunchKernelGGL(obs_blend_bwd_kernel, dim3(nblk((long)B * (SD + De), 256, 1024)), dim3(256), 0, S_, dsin, ld_dsin,
+                     ddin, ld_ddin, is_first, gs_prev, gd_prev, dstoch0, ddeter0, B, SD, De);
   return (int)hipGetLastError();
 }

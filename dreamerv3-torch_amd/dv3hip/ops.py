@@ -771,18 +771,19 @@ def obs_blend(prev_stoch, init_stoch, prev_deter, init_deter, action, is_first, 
 
 
 def obs_blend_bwd(dsin, ddin, is_first, gs_prev, gd_prev, dstoch0, ddeter0):
-    B, SD = dsin.shape
-    De = ddin.shape[1]
-    for t, nm, n in ((dsin, "dsin", B * SD), (ddin, "ddin", B * De), (is_first, "is_first", B),
-                     (gs_prev, "gs_prev", B * SD), (gd_prev, "gd_prev", B * De), (dstoch0, "dstoch0", SD),
-                     (ddeter0, "ddeter0", De)):
+    B, SD, ld_s = _rows2d(dsin, "dsin")
+    Bd, De, ld_d = _rows2d(ddin, "ddin")
+    if Bd != B:
+        raise ValueError("dsin/ddin row mismatch")
+    for t, nm, n in ((is_first, "is_first", B), (gs_prev, "gs_prev", B * SD), (gd_prev, "gd_prev", B * De),
+                     (dstoch0, "dstoch0", SD), (ddeter0, "ddeter0", De)):
         if t is None:
             continue
         _contig(t, nm)
         if t.numel() != n:
             raise ValueError(nm + " size mismatch")
-    _call("dv3_obs_blend_bwd", _ptr(dsin), _ptr(ddin), _ptr(is_first), _ptr(gs_prev), _ptr(gd_prev), _ptr(dstoch0),
-          _ptr(ddeter0), B, SD, De, _stream())
+    _call("dv3_obs_blend_bwd", _ptr(dsin), ld_s, _ptr(ddin), ld_d, _ptr(is_first), _ptr(gs_prev), _ptr(gd_prev),
+          _ptr(dstoch0), _ptr(ddeter0), B, SD, De, _stream())
 
 
 def dot_accumulate(x, out, *, w=None, clip_min=None, scale=1.0):

@@ -205,12 +205,14 @@ int dv3_reset_blend_bwd(const float* dout, long ldo, const float* is_first, floa
 
 /* One-launch forms for an observe step: the three blends (stoch/deter against the learned initial state,
  * action against zero; prev_* NULL = zeros for the first step), and their backward with the carry folded
- * in: gs_prev += dsin*(1-m), gd_prev += ddin*(1-m) (NULL on the first step), dstoch0/ddeter0 += sum_b (.)*m. */
+ * in: gs_prev += dsin*(1-m), gd_prev += ddin*(1-m) (NULL on the first step), dstoch0/ddeter0 += sum_b (.)*m.
+ * dsin / ddin are row-strided (ld_*), everything else dense. */
 int dv3_obs_blend(const float* prev_stoch, const float* init_stoch, const float* prev_deter, const float* init_deter,
                   const float* action, const float* is_first, float* out_stoch, float* out_deter, float* out_action,
                   int B, int SD, int De, int A, void* stream);
-int dv3_obs_blend_bwd(const float* dsin, const float* ddin, const float* is_first, float* gs_prev, float* gd_prev,
-                      float* dstoch0, float* ddeter0, int B, int SD, int De, void* stream);
+int dv3_obs_blend_bwd(const float* dsin, long ld_dsin, const float* ddin, long ld_ddin, const float* is_first,
+                      float* gs_prev, float* gd_prev, float* dstoch0, float* ddeter0, int B, int SD, int De,
+                      void* stream);
 
 /* ---- optimizer -- tools.Optimizer.__call__ (tools.py:760-776) on a flat fp32 bucket ----------------
  * state[0] = step count, state[1] = sum of squares accumulator, state[2] = last grad norm.
