@@ -92,9 +92,10 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
 // identically for A and B (still an exact fp32 fma chain, in a different order).
 // ------------------------------------------------------------------------------------------------
 constexpr int kSkinnyWaves = 8;   // K is split over the waves of a workgroup (4 when K is also split over workgroups)
-constexpr int kSkinnyBatch = 6;   // 16-k chunks whose loads are issued together before their MFMAs
+// kSkinnyBatch (template): 16-k chunks whose loads a wave issues together before their MFMAs -- sized by the host
+// so that a wave's whole K share is ONE batch where registers allow (one memory round trip per launch)
 
-template <bool TB, int MT>
+template <bool TB, int MT, int kSkinnyBatch>
 __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmParams p) {
   __shared__ float red[kSkinnyWaves][MT][256];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -211,20 +212,139 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
   }
 }
 
-// K splits for an accumulating skinny call: enough workgroups of 4 waves to put ~1k waves on the chip while
-// leaving every wave at least two 16-k chunks
-static void skinny_launch_shape(int N, int K, int accumulate, dim3& grid, dim3& block) {
-  const int tiles = (N + 15) / 16, chunks = (K + 15) / 16;
+// Few-row product against an n-contiguous B (data gradients: dX = dY * W, W [K,N] row-major), K split over
+// workgroups, partial tiles added atomically (accumulate == 2 only).  The 16-column kernel above needs four
+// 4-byte loads per lane per chunk here (a lane's B operand is one column); this one gives a wave 64 columns
+// as four INTERLEAVED 16-column tiles -- tile j holds columns n0 + 4*i + j -- so that lane (i, q) reads
+// B[k][n0+4i .. 4i+3] as one float4 and feeds its j-th element to tile j: per 16-k chunk 1 + 4 vector loads
+// and 16 MFMAs, and the finished 16 x 64 block leaves as 256-byte coalesced atomic rows.
+// Requires N % 64 == 0, no A2.  4 waves; K range = gridDim.y splits, then the waves.
+template <int MT, int BATCH>
+__global__ __launch_bounds__(256) void gemm_skinny_nn64_kernel(GemmParams p) {
+  __shared__ float red[4][MT][4][257];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 64;
+  const int chunks = (p.K + 15) >> 4;
+  const int per_wg = (chunks + gridDim.y - 1) / gridDim.y;
+  const int wcb = blockIdx.y * per_wg, wce = min(chunks, wcb + per_wg);
+  const int per = (max(wce - wcb, 0) + 3) / 4;
+  const int cb = wcb + wave * per, ce = min(wce, cb + per);
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float amask[MT];
+  const float* arow[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int row = i + 16 * t;
+    const bool ok = row < p.M;
+    amask[t] = ok ? 1.f : 0.f;
+    arow[t] = p.A + (long)(ok ? row : 0) * p.lda;
+  }
+  const float* bptr = p.B + n0 + 4 * i;
+  for (int c0 = cb; c0 < ce; c0 += BATCH) {
+    f32x4 a[BATCH][MT], b[BATCH][4];
+    const int clast = ce - 1;
+    const bool fast = min(c0 + BATCH, ce) * 16 <= p.K;
+    if (fast) {
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int k = (min(c0 + u, clast) << 4) + 4 * q;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[u][t] = *reinterpret_cast<const f32x4u*>(arow[t] + k);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[u][g] = *reinterpret_cast<const f32x4u*>(bptr + (long)(k + g) * p.ldb);
+      }
+    } else {  // ragged end of K
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int k = (min(c0 + u, clast) << 4) + 4 * q;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < p.K) v[e] = arow[t][k + e];
+          a[u][t] = v;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 w = {0.f, 0.f, 0.f, 0.f};
+          if (k + g < p.K) w = *reinterpret_cast<const f32x4u*>(bptr + (long)(k + g) * p.ldb);
+          b[u][g] = w;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u)
+      if (c0 + u < ce) {  // wave-uniform
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            const float av = a[u][t][g] * amask[t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u][g][j], acc[t][j], 0, 0, 0);
+          }
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][t][j][r * 64 + lane] = acc[t][j][r];
+  __syncthreads();
+  // 16*MT rows x 64 columns; consecutive threads take consecutive columns of one row
+  for (int e = tid; e < MT * 1024; e += 256) {
+    const int t = e >> 10, row16 = (e >> 6) & 15, cidx = e & 63;
+    const int row = 16 * t + row16;
+    if (row < p.M) {
+      const int x = (row16 & 3) * 64 + (row16 >> 2) * 16 + (cidx >> 2), j = cidx & 3;
+      float v = red[0][t][j][x] + red[1][t][j][x] + red[2][t][j][x] + red[3][t][j][x];
+      if (p.bias && blockIdx.y == 0) v += p.bias[n0 + cidx];
+      atomicAdd(p.C + (long)row * p.ldc + n0 + cidx, v);
+    }
+  }
+}
+
+template <int MT>
+static void launch_skinny_nn64(const GemmParams& p, hipStream_t s) {
+  const int tiles = p.N / 64, chunks = (p.K + 15) / 16;
+  int splits = (256 + tiles - 1) / tiles;
+  const int maxs = chunks / 4 > 0 ? chunks / 4 : 1;
+  if (splits > maxs) splits = maxs;
+  const int per = ((chunks + splits - 1) / splits + 3) / 4;
+  const dim3 grid(tiles, splits), block(256);
+  if (per <= 2) hipLaunchKernelGGL((gemm_skinny_nn64_kernel<MT, 2>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_skinny_nn64_kernel<MT, 4>), grid, block, 0, s, p);
+}
+
+// Launch of the few-row kernel.  accumulate == 2 ("C += ..., summation order free") lets K be split over
+// workgroups: enough workgroups of 4 waves to put ~1k waves on the chip while leaving every wave at least two
+// 16-k chunks; the partial tiles are added with atomics.  accumulate == 1 keeps one workgroup per column tile
+// (deterministic order).
+template <bool TB, int MT>
+static void launch_skinny(const GemmParams& p, int accumulate, hipStream_t s) {
+  const int tiles = (p.N + 15) / 16, chunks = (p.K + 15) / 16;
   int splits = 1, waves = kSkinnyWaves;
-  if (accumulate) {
+  if (accumulate == 2) {
     waves = 4;
     splits = (1024 + tiles * waves - 1) / (tiles * waves);
     const int maxs = chunks / (2 * waves);
     if (splits > maxs) splits = maxs;
     if (splits <= 1) { splits = 1; waves = kSkinnyWaves; }
   }
-  grid = dim3(tiles, splits);
-  block = dim3(64 * waves);
+  const int per_wg = (chunks + splits - 1) / splits;
+  const int per = (per_wg + waves - 1) / waves;
+  const dim3 grid(tiles, splits), block(64 * waves);
+  if (per <= 3) hipLaunchKernelGGL((gemm_skinny_kernel<TB, MT, 3>), grid, block, 0, s, p);
+  else if (per <= 6 || MT > 1) hipLaunchKernelGGL((gemm_skinny_kernel<TB, MT, 6>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<TB, MT, (MT > 1 ? 6 : 12)>), grid, block, 0, s, p);
 }
 
 template <class TS>
@@ -291,11 +411,9 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
     q.M = N; q.N = M; q.K = K; q.K1 = K;
     q.lda = ldb; q.lda2 = 0; q.ldb = lda; q.ldc = ldc;
     q.accumulate = accumulate; q.transC = 1;
-    dim3 grid, block;
-    skinny_launch_shape(q.N, q.K, accumulate, grid, block);
     hipStream_t s7 = (hipStream_t)stream;
-    if (N <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<true, 1>), grid, block, 0, s7, q);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<true, 2>), grid, block, 0, s7, q);
+    if (N <= 16) launch_skinny<true, 1>(q, accumulate, s7);
+    else launch_skinny<true, 2>(q, accumulate, s7);
     return (int)hipGetLastError();
   }
   GemmParams p{};
@@ -316,14 +434,15 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   if (t == 3) {
     // skinny path: M <= 32, A k-contiguous; segment edge on a 16-k chunk boundary
     if (M > 32 || transA || (A2 && (K1 % 16) != 0)) return DV3_ERR_ARG;
-    dim3 grid, block;
-    skinny_launch_shape(N, K, accumulate, grid, block);
-    if (M <= 16) {
-      if (transB) hipLaunchKernelGGL((gemm_skinny_kernel<true, 1>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((gemm_skinny_kernel<false, 1>), grid, block, 0, s, p);
+    if (accumulate == 2 && !transB && !A2 && (N % 64) == 0) {
+      if (M <= 16) launch_skinny_nn64<1>(p, s);
+      else launch_skinny_nn64<2>(p, s);
+    } else if (M <= 16) {
+      if (transB) launch_skinny<true, 1>(p, accumulate, s);
+      else launch_skinny<false, 1>(p, accumulate, s);
     } else {
-      if (transB) hipLaunchKernelGGL((gemm_skinny_kernel<true, 2>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((gemm_skinny_kernel<false, 2>), grid, block, 0, s, p);
+      if (transB) launch_skinny<true, 2>(p, accumulate, s);
+      else launch_skinny<false, 2>(p, accumulate, s);
     }
     return (int)hipGetLastError();
   }

@@ -388,8 +388,8 @@ class RSSMEngine:
 
         side.run((extra_side or []) + [_prior_wgrads])  # beside the reverse scan below
         # ---- reverse scan
-        # Every GEMM of the reverse scan ACCUMULATES into buffers zeroed here in bulk: an accumulating few-row
-        # GEMM may split K over workgroups (atomics onto C), which is what fills the chip at B rows.  The two
+        # Every GEMM of the reverse scan ACCUMULATES into buffers zeroed here in bulk: a few-row GEMM with
+        # accumulate="atomic" may split K over workgroups (atomics onto C), which is what fills the chip at B rows.  The two
         # data gradients of the GRU matmul share one GEMM: dxd[t] = [dx1 | ddin], whose right half gru_bwd
         # pre-loads with the direct dh path.
         dx3 = ws.zeros("obs.dx3", (T, B, Hd))
@@ -403,14 +403,14 @@ class RSSMEngine:
             gs_t, gd_t = gs[t], gd[t]  # already hold the carry from step t+1 (folded in by obs_blend_bwd)
             dx1, ddin = dxd[t][:, :Hd], dxd[t][:, Hd:]
             ops.onehot_st_bwd(post_logit[t], gs_t.view(B, S, D), dpost_logit[t], unimix=self.unimix, accumulate=True)
-            ops.gemm(dpost_logit[t].view(B, SD), P.obs.W, dx3[t], transB=False, accumulate=True)
+            ops.gemm(dpost_logit[t].view(B, SD), P.obs.W, dx3[t], transB=False, accumulate="atomic")
             dense_ln_bwd_pre(P.obs_out, dx3[t], x3pre[t], m3[t], r3[t], dx3pre[t], wgrad=True)
-            ops.gemm(dx3pre[t], P.obs_out.W[:, :De], gd_t, transB=False, accumulate=True)
+            ops.gemm(dx3pre[t], P.obs_out.W[:, :De], gd_t, transB=False, accumulate="atomic")
             ops.gru_bwd(gd_t, gpre[t], P.gru.g, P.gru.b, din[t], mg[t], rg[t], dgpre[t], ddin, _g(P.gru.g),
                         _g(P.gru.b))
-            ops.gemm(dgpre[t], P.gru.W, dxd[t], transB=False, accumulate=True)
+            ops.gemm(dgpre[t], P.gru.W, dxd[t], transB=False, accumulate="atomic")
             dense_ln_bwd_pre(P.img_in, dx1, x1pre[t], m1[t], r1[t], dx1pre[t], wgrad=True)
-            ops.gemm(dx1pre[t], P.img_in.W[:, :SD], dsin[t], transB=False, accumulate=True)
+            ops.gemm(dx1pre[t], P.img_in.W[:, :SD], dsin[t], transB=False, accumulate="atomic")
             ops.obs_blend_bwd(dsin[t], ddin, first[t], gs[t - 1] if t > 0 else None, gd[t - 1] if t > 0 else None,
                               dstoch0, ddeter0)
         # ---- the encoder-output gradient (critical path) and, beside it, the batched weight gradients

@@ -125,7 +125,12 @@ def pick_gemm_tile(M: int, N: int, wgrad: bool = False) -> int:
 
 # ---------------------------------------------------------------------------------------------
 def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=False, tile=-1):
-    """C (+)= [A|A2] @ op(B) + bias.   op(B)[K,N]: transB -> B is [N,K]; else B is [K,N]."""
+    """C (+)= [A|A2] @ op(B) + bias.   op(B)[K,N]: transB -> B is [N,K]; else B is [K,N].
+
+    accumulate: False (overwrite), True (C += ..., fixed summation order on the few-row path) or "atomic"
+    (C += ..., the few-row kernel may split K over workgroups and add the partial tiles atomically: order not
+    fixed -- used for the gradients of the reverse scan, never for the forward values that feed sampling)."""
+    acc_flag = 2 if accumulate == "atomic" else int(bool(accumulate))
     ra, ca, lda = _rows2d(A, "A")
     rb, cb, ldb = _rows2d(B, "B")
     M, N, ldc = _rows2d(C, "C")
@@ -154,7 +159,7 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         Bv1 = B[:, :K1] if transB else B[:K1]
         Bv2 = B[:, K1:] if transB else B[K1:]
         gemm(A, Bv1, C, transA=False, transB=transB, bias=bias, accumulate=accumulate, tile=tile)
-        gemm(A2, Bv2, C, transA=False, transB=transB, accumulate=True, tile=tile)
+        gemm(A2, Bv2, C, transA=False, transB=transB, accumulate=accumulate or True, tile=tile)
         return C
     if tile < 0:
         tile = pick_gemm_tile(M, N, bool(transA))
@@ -165,7 +170,7 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         if N <= 32 and M > 32 and not transA and transB and A2 is None:
             tile = 7
     _call("dv3_gemm_f32", int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(A2), lda2, K1, _ptr(B), ldb,
-          _ptr(C), ldc, _ptr(bias), int(accumulate), tile, s,
+          _ptr(C), ldc, _ptr(bias), acc_flag, tile, s,
           key=(f"gemm_kernel<{_TILE_NAMES[tile]},tA={int(transA)},tB={int(transB)}>"
                + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else "")), flops=2.0 * M * N * K,
           nbytes=4.0 * (M * K + N * K + M * N))

@@ -36,6 +36,10 @@ int dv3_version(void);
  *         tile per workgroup, K split over its waves, operands straight to the 16x16x4 MFMA registers),
  *         4 = 128x128x32, 5 = 64x64x64, 6 = 32x64x64 with K split inside the workgroup, 7 = narrow output
  *         (N <= 32, transA=0, transB=1, no A2: the skinny kernel on the transposed problem).
+ *   accumulate: 0 = overwrite C, 1 = C += product, 2 = C += product with the summation order left free: the
+ *         skinny kernel then also splits K over workgroups and adds the partial tiles with atomics (fills the
+ *         chip at M <= 32).  The tile kernels treat 1 and 2 alike (they split long-K accumulating products,
+ *         i.e. weight gradients, atomically in either case).
  * Replaces nn.Linear forward / its autograd transposes in RSSM.img_step, obs_step
  * (networks.py:195-233), GRUCell.forward (networks.py:762), MLP.forward (networks.py:657-681),
  * ConvDecoder._linear_layer (networks.py:569), and the torch.cat in front of them

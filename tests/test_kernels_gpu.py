@@ -82,6 +82,24 @@ def test_gemm_nn_dgrad(ops, M, N, K):
     assert_close(C, dY @ W, what="gemm_nn")
 
 
+@pytest.mark.parametrize("M,N,K", [(16, 512, 1536), (16, 1024, 1536), (16, 512, 1024), (3, 19, 37), (32, 1030, 512),
+                                   (1, 512, 1024), (16, 512, 1030), (7, 33, 4608)])
+@pytest.mark.parametrize("transB", [False, True])
+@pytest.mark.parametrize("mode", [True, "atomic"])
+def test_gemm_few_rows_accumulate(ops, M, N, K, transB, mode):
+    """Few-row GEMM adding into C (strided C and bias included); "atomic" = K split over workgroups."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn((N, K) if transB else (K, N), generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N + 5, generator=g)
+    C = dev(C0.clone())
+    ops.gemm(dev(A), dev(W), C[:, :N], transB=transB, bias=dev(b), accumulate=mode)
+    want = C0.clone()
+    want[:, :N] += A @ (W.t() if transB else W) + b
+    assert_close(C, want, what=f"gemm few rows accumulate={mode}")
+
+
 @pytest.mark.parametrize("rows,Nout,Kin", [(1024, 512, 1030), (1024, 1536, 1024), (333, 70, 45), (14336, 255, 512)])
 def test_gemm_tn_wgrad_accumulate(ops, rows, Nout, Kin):
     g = torch.Generator().manual_seed(2)

@@ -44,7 +44,7 @@ def main():
     args = ap.parse_args()
     dev = "cuda"
     r = lambda *s: torch.randn(*s, device=dev)
-    for M in (16, 64, 1024):
+    for M in (16, 32, 1024):
         De = 512
         p, h, dhn = r(M, 3 * De), r(M, De), r(M, De)
         g, b = r(3 * De), r(3 * De)
@@ -71,8 +71,10 @@ def main():
             A = r(M, K)
             B = r(N, K) if tB else r(K, N)
             C = r(M, N)
-            us = graph_us(lambda: ops.gemm(A, B, C, transB=tB), args.reps)
-            print(f"gemm {note:14s} M={M:5d} N={N} K={K}: {us:7.2f} us  {2.0 * M * N * K / us / 1e6:6.2f} TF/s")
+            for mode in (False, True, "atomic"):
+                us = graph_us(lambda: ops.gemm(A, B, C, transB=tB, accumulate=mode), args.reps)
+                print(f"gemm {note:14s} M={M:5d} N={N} K={K} acc={str(mode):6s}: {us:7.2f} us  "
+                      f"{2.0 * M * N * K / us / 1e6:6.2f} TF/s")
 
 
 if __name__ == "__main__":
