@@ -669,21 +669,26 @@ extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* 
   const long rows = (long)Nimg * (H / 2) * (W / 2);
   if (rows > 0x7fffffffL - 4096) return DV3_ERR_ARG;
   WgradParams p{coarse, fine, dw_packed, Nimg, H, W, Cfine, Ccoarse, 0, 0, 0, 0};
-  using TS = C64;
-  p.tiles_m = (Ccoarse + TS::BM - 1) / TS::BM;
-  p.tiles_n = (16 * Cfine + TS::BN - 1) / TS::BN;
-  const int tiles = p.tiles_m * p.tiles_n;
-  // aim at ~1024 workgroups, at least 512 reduction rows each
-  long splits = (1024 + tiles - 1) / tiles;
-  const long max_splits = (rows + 511) / 512;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  long chunk = (rows + splits - 1) / splits;
-  chunk = ((chunk + TS::BK - 1) / TS::BK) * TS::BK;
-  splits = (rows + chunk - 1) / chunk;
-  p.splits = (int)splits;
-  p.chunk = (int)chunk;
-  hipLaunchKernelGGL((conv_wgrad_kernel<TS>), dim3((unsigned)(tiles * splits)), dim3(kThreads), 0, (hipStream_t)stream, p);
+  auto go = [&](auto ts, long target_wgs) {
+    using TS = decltype(ts);
+    p.tiles_m = (Ccoarse + TS::BM - 1) / TS::BM;
+    p.tiles_n = (16 * Cfine + TS::BN - 1) / TS::BN;
+    const int tiles = p.tiles_m * p.tiles_n;
+    // aim at target_wgs workgroups, at least 512 reduction rows each
+    long splits = (target_wgs + tiles - 1) / tiles;
+    const long max_splits = (rows + 511) / 512;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long chunk = (rows + splits - 1) / splits;
+    chunk = ((chunk + TS::BK - 1) / TS::BK) * TS::BK;
+    splits = (rows + chunk - 1) / chunk;
+    p.splits = (int)splits;
+    p.chunk = (int)chunk;
+    hipLaunchKernelGGL((conv_wgrad_kernel<TS>), dim3((unsigned)(tiles * splits)), dim3(kThreads), 0, (hipStream_t)stream, p);
+  };
+  // 128x128 tiles halve the L2->LDS traffic per flop; they need >= 128 output channels to fill their rows
+  if (Ccoarse >= 128) go(C128{}, 512);
+  else go(C64{}, 1024);
   const long total = 16L * Ccoarse * Cfine;
   unsigned ub = (unsigned)((total + 255) / 256);
   if (ub > 1024) ub = 1024;

@@ -384,8 +384,9 @@ using T32x64S = TileShape<1, 2, 1, 1, 64, 2>;  // 32 x 64, BK 64, K split over 2
 using T32x128 = TileShape<1, 4, 1, 1, 32>;  // 32 x 128, BK 32 (few rows: the observe scan, M = batch)
 
 // Tile choice when the caller passes tile = -1 (the Python wrapper normally decides, same rule).
-static int pick_tile(int M, int N, int accumulate) {
+static int pick_tile(int M, int N, int K, int accumulate) {
   if (M <= 32) return 2;
+  if (accumulate && K >= 4096 && (long)M * N >= 512L * 512) return 4;
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
   if (t64 <= 512 && !accumulate) return 6;
   const long c128 = (((long)((M + 127) / 128) * ((N + 127) / 128)) + 255) / 256 * 4;
@@ -427,7 +428,7 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   }
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
-  int t = (tile >= 0 && tile <= 6) ? tile : pick_tile(M, N, accumulate);
+  int t = (tile >= 0 && tile <= 6) ? tile : pick_tile(M, N, K, accumulate);
   if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6)) t = 1;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;

@@ -109,12 +109,14 @@ def kernel_symbol(key: str) -> str:
     return key
 
 
-def pick_gemm_tile(M: int, N: int, wgrad: bool = False) -> int:
+def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
     """Tile choice (mirrors csrc/gemm.hip): small outputs take the 32x64 tile with the K split inside the
     workgroup (fills the 256 CUs when M*N is small); otherwise minimise (waves of workgroups over 256 CUs)
     x (MFMAs per wave per k-step) between 64x64 and 128x128."""
     if M <= 32:
         return 2
+    if wgrad and K >= 4096 and M * N >= 512 * 512:
+        return 4  # long reductions are split over K anyway: take the tile with the best flops per L2 byte
     t64 = -(-M // 64) * -(-N // 64)
     if t64 <= 512 and not wgrad:  # weight gradients split K across workgroups instead (long reduction)
         return 6
@@ -162,7 +164,7 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         gemm(A2, Bv2, C, transA=False, transB=transB, accumulate=accumulate or True, tile=tile)
         return C
     if tile < 0:
-        tile = pick_gemm_tile(M, N, bool(transA))
+        tile = pick_gemm_tile(M, N, bool(transA), K)
         if M <= 32 and not transA:
             tile = 3
         if tile == 6 and A2 is not None and (K1 % 64) != 0:

@@ -28,6 +28,13 @@ SHAPES = [
     (15360, 512, 1536, 0, 1, "behaviour head L0"),
     (14336, 512, 512, 0, 0, "behaviour dgrad"),
     (512, 512, 14336, 1, 0, "wgrad"),
+    (512, 1536, 15360, 1, 0, "wgrad head L0"),
+    (1536, 1024, 1024, 1, 0, "wgrad GRU"),
+    (1024, 512, 1024, 1, 0, "wgrad stat"),
+    (512, 4608, 1024, 1, 0, "wgrad obs_out"),
+    (255, 512, 14336, 1, 0, "wgrad reward head"),
+    (1024, 512, 512, 0, 0, "imagine dgrad"),
+    (1024, 1536, 1024, 0, 0, "imagine dgrad gru"),
     (4096, 4096, 4096, 0, 1, "square 4k"),
 ]
 
