@@ -381,6 +381,7 @@ using T64 = TileShape<2, 2, 1, 1, 32>;     // 64 x 64,  BK 32
 using T128K32 = TileShape<2, 2, 2, 2, 32>;  // 128 x 128, BK 32 (64 MFMAs per wave per barrier)
 using T64K64 = TileShape<2, 2, 1, 1, 64>;   // 64 x 64,  BK 64 (32 MFMAs per wave per barrier)
 using T32x64S = TileShape<1, 2, 1, 1, 64, 2>;  // 32 x 64, BK 64, K split over 2 wave-groups (small M*N)
+using T32x32S4 = TileShape<1, 1, 1, 1, 64, 4>;  // 32 x 32, BK 64, K split over all 4 waves: 2 workgroups per CU at M*N = 512k
 using T32x128 = TileShape<1, 4, 1, 1, 32>;  // 32 x 128, BK 32 (few rows: the observe scan, M = batch)
 
 // Tile choice when the caller passes tile = -1 (the Python wrapper normally decides, same rule).
@@ -388,7 +389,7 @@ static int pick_tile(int M, int N, int K, int accumulate) {
   if (M <= 32) return 2;
   if (accumulate && K >= 4096 && (long)M * N >= 512L * 512) return 4;
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
-  if (t64 <= 512 && !accumulate) return 6;
+  if (t64 <= 512 && !accumulate) return t64 <= 128 ? 8 : 6;
   const long c128 = (((long)((M + 127) / 128) * ((N + 127) / 128)) + 255) / 256 * 4;
   const long c64 = (t64 + 255) / 256;
   return (c64 < c128) ? 1 : 4;
@@ -428,8 +429,8 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   }
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
-  int t = (tile >= 0 && tile <= 6) ? tile : pick_tile(M, N, K, accumulate);
-  if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6)) t = 1;
+  int t = ((tile >= 0 && tile <= 6) || tile == 8) ? tile : pick_tile(M, N, K, accumulate);
+  if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6 || t == 8)) t = 1;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
   if (t == 3) {
@@ -451,6 +452,7 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   else if (t == 4) e = launch_ts<T128K32>(p, transA, transB, s);
   else if (t == 5) e = launch_ts<T64K64>(p, transA, transB, s);
   else if (t == 6) e = launch_ts<T32x64S>(p, transA, transB, s);
+  else if (t == 8) e = launch_ts<T32x32S4>(p, transA, transB, s);
   else if (t == 1) e = launch_ts<T64>(p, transA, transB, s);
   else e = launch_ts<T32x128>(p, transA, transB, s);
   return (int)e;

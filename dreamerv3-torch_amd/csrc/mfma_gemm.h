@@ -331,11 +331,13 @@ __device__ __forceinline__ void mfma_mainloop(const AOp& aop, const BOp& bop, in
       for (int z = 1; z < AccSplit<TS>::N; ++z) out[a][b] += acc[z][a][b];
     }
   if constexpr (TS::WK > 1) {
-    // reduce the wave-groups' partial tiles through LDS (the staging buffers are free now)
-    static_assert(TS::WK == 2, "reduction written for two wave-groups");
+    // reduce the wave-groups' partial tiles through LDS (the staging buffers are free now): wave-group wk > 0
+    // parks its tile in slot (wk-1, wmn); wave-group 0 adds them in wk order
+    constexpr int kTile = TS::TM * TS::TN * 16 * 64;
+    static_assert((TS::WK - 1) * TS::WM * TS::WN * kTile <= TS::lds_floats, "reduction must fit the staging LDS");
     __syncthreads();
-    float* red = lds + (long)wmn * (TS::TM * TS::TN * 16 * 64);
-    if (wk == 1) {
+    if (wk > 0) {
+      float* red = lds + (long)((wk - 1) * TS::WM * TS::WN + wmn) * kTile;
 #pragma unroll
       for (int a = 0; a < TS::TM; ++a)
 #pragma unroll
@@ -346,11 +348,15 @@ __device__ __forceinline__ void mfma_mainloop(const AOp& aop, const BOp& bop, in
     __syncthreads();
     if (wk == 0) {
 #pragma unroll
-      for (int a = 0; a < TS::TM; ++a)
+      for (int g = 1; g < TS::WK; ++g) {
+        const float* red = lds + (long)((g - 1) * TS::WM * TS::WN + wmn) * kTile;
 #pragma unroll
-        for (int b = 0; b < TS::TN; ++b)
+        for (int a = 0; a < TS::TM; ++a)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) out[a][b][r] += red[((a * TS::TN + b) * 16 + r) * 64 + lane];
+          for (int b = 0; b < TS::TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[a][b][r] += red[((a * TS::TN + b) * 16 + r) * 64 + lane];
+      }
     }
     owner = (wk == 0);
   }

@@ -830,7 +830,8 @@ extern "C" int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long l
       // few fat workgroups, which is cheap for small N and does not re-read the (HBM-bound) inputs.
       // (Never when dx overwrites dy in place: the column role re-reads dy while the row role writes dx.)
       const bool col_role = dgamma && dx != dy && N >= 256;
-      const long cap = (dgamma && !col_role) ? 256 : 2048;
+      // narrow rows flush only N (< 256) atomics per workgroup: the grid can stay wide (HBM-bound at R ~ 1M)
+      const long cap = (dgamma && !col_role && N >= 128) ? 256 : 2048;
       const int col_blocks = col_role ? ((N + 63) / 64) * (int)((R + kColRoleRows - 1) / kColRoleRows) : 0;
       DV3_LNV_DISPATCH(ln_act_bwd_vec_kernel, cap, col_blocks, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma,
                        dbeta, R, N, act, accumulate_dx, (int)blocks_);

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
@@ -86,11 +88,12 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
     _lib.check(getattr(lib, fn_name)(*args), fn_name)
 
 
-_TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2", 7: "narrowN"}
+_TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2", 7: "narrowN",
+               8: "32x32x64s4"}
 
 
 _TILE_TEMPLATES = {0: "2, 2, 2, 2, 16, 1", 1: "2, 2, 1, 1, 32, 1", 2: "1, 4, 1, 1, 32, 1", 4: "2, 2, 2, 2, 32, 1",
-                   5: "2, 2, 1, 1, 64, 1", 6: "1, 2, 1, 1, 64, 2"}
+                   5: "2, 2, 1, 1, 64, 1", 6: "1, 2, 1, 1, 64, 2", 8: "1, 1, 1, 1, 64, 4"}
 
 
 def kernel_symbol(key: str) -> str:
@@ -109,6 +112,11 @@ def kernel_symbol(key: str) -> str:
     return key
 
 
+# <= 512k outputs (1024 imagination rows x 512 columns): 32x32 tiles with K split over the four waves put two
+# workgroups on every CU; A/B inside one box: 22.17 vs 22.46 ms per update against the 32x64 tile (6)
+_SMALL_TILE = int(os.environ.get("DV3_SMALL_TILE", "8"))
+
+
 def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
     """Tile choice (mirrors csrc/gemm.hip): small outputs take the 32x64 tile with the K split inside the
     workgroup (fills the 256 CUs when M*N is small); otherwise minimise (waves of workgroups over 256 CUs)
@@ -119,7 +127,7 @@ def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
         return 4  # long reductions are split over K anyway: take the tile with the best flops per L2 byte
     t64 = -(-M // 64) * -(-N // 64)
     if t64 <= 512 and not wgrad:  # weight gradients split K across workgroups instead (long reduction)
-        return 6
+        return _SMALL_TILE if t64 <= 128 else 6
     c128 = ((-(-M // 128) * -(-N // 128)) + 255) // 256 * 4
     c64 = (t64 + 255) // 256 * 1
     return 1 if c64 < c128 else 4
@@ -156,7 +164,7 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         if bias.numel() != N:
             raise ValueError("bias size mismatch")
     s = _stream()
-    if A2 is not None and (K1 % (64 if tile in (5, 6) else 32)) != 0:
+    if A2 is not None and (K1 % (64 if tile in (5, 6, 8) else 32)) != 0:
         # segment edge not on a K-tile boundary: two passes, the second accumulating
         Bv1 = B[:, :K1] if transB else B[:K1]
         Bv2 = B[:, K1:] if transB else B[K1:]
@@ -167,7 +175,7 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         tile = pick_gemm_tile(M, N, bool(transA), K)
         if M <= 32 and not transA:
             tile = 3
-        if tile == 6 and A2 is not None and (K1 % 64) != 0:
+        if tile in (6, 8) and A2 is not None and (K1 % 64) != 0:
             tile = 1
         if N <= 32 and M > 32 and not transA and transB and A2 is None:
             tile = 7

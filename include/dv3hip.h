@@ -35,7 +35,8 @@ int dv3_version(void);
  *   tile: -1 = choose, 0 = 128x128, 1 = 64x64, 2 = 32x128, 3 = skinny (M <= 32, transA = 0: one 16-column
  *         tile per workgroup, K split over its waves, operands straight to the 16x16x4 MFMA registers),
  *         4 = 128x128x32, 5 = 64x64x64, 6 = 32x64x64 with K split inside the workgroup, 7 = narrow output
- *         (N <= 32, transA=0, transB=1, no A2: the skinny kernel on the transposed problem).
+ *         (N <= 32, transA=0, transB=1, no A2: the skinny kernel on the transposed problem), 8 = 32x32x64 with
+ *         K split over all four waves (two workgroups per CU when M*N is ~512k).
  *   accumulate: 0 = overwrite C, 1 = C += product, 2 = C += product with the summation order left free: the
  *         skinny kernel then also splits K over workgroups and adds the partial tiles with atomics (fills the
  *         chip at M <= 32).  The tile kernels treat 1 and 2 alike (they split long-K accumulating products,

@@ -3,7 +3,7 @@
 
     python tools/gemm_bench.py [--reps 50]
 
-Prints, per (shape, layout, tile): average launch time (HIP events around `reps` back-to-back launches)
+Prints, per (shape, layout, tile): average device time per launch (`reps` launches captured into one hipGraph, HIP events around its replay)
 and TFLOP/s against the 157.3 TFLOP/s fp32-MFMA peak.  Development aid for csrc/mfma_gemm.h.
 """
 import argparse
@@ -45,13 +45,22 @@ def bench(M, N, K, tA, tB, tile, reps):
     B = torch.randn((N, K) if tB else (K, N), device=dev)
     C = torch.zeros(M, N, device=dev)
     acc = bool(tA)
+    fn = lambda: ops.gemm(A, B, C, transA=bool(tA), transB=bool(tB), tile=tile, accumulate=acc)
     for _ in range(3):
-        ops.gemm(A, B, C, transA=bool(tA), transB=bool(tB), tile=tile, accumulate=acc)
+        fn()
+    torch.cuda.synchronize()
+    # `reps` launches captured into one hipGraph: device time per launch, as the captured update pays it
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(reps):
+                fn()
+    g.replay()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(reps):
-        ops.gemm(A, B, C, transA=bool(tA), transB=bool(tB), tile=tile, accumulate=acc)
+    g.replay()
     b.record()
     torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3 / reps
