@@ -54,6 +54,7 @@ struct ConvATile {
   static constexpr int CH = BK / 4, RPP = kThreads / CH;
   static constexpr int LD = ROWS + (BK == 16 ? 2 : 1);
   f32x4 v[kVecs];
+  float msk[kVecs];  // 0 for padding taps / rows past the edge of the staged tile, applied in store()
   long base[kVecs];  // n*H*W*C, or -1 when the row is out of range
   int iy0[kVecs], ix0[kVecs];
 
@@ -105,7 +106,8 @@ struct ConvATile {
         const bool ok = base[p] >= 0 && k < op.K && iy >= 0 && iy < op.H && ix >= 0 && ix < op.W;
         const float* src = ok ? op.x + base[p] + ((long)iy * op.W + ix) * op.C + ci : op.x;
         const f32x4 t = *reinterpret_cast<const f32x4u*>(src);
-        v[p] = t * (ok ? 1.f : 0.f);  // multiply keeps the gather unconditional (no exec-mask branch)
+        v[p] = t;                 // consumed only in store(): the gather stays in flight across the MFMAs
+        msk[p] = ok ? 1.f : 0.f;  // (a multiply here would pin a vmcnt(0) wait in front of them)
       }
     } else {
 #pragma unroll
@@ -114,6 +116,7 @@ struct ConvATile {
 #pragma unroll
         for (int e = 0; e < 4; ++e) t[e] = at(op, p, k + e);
         v[p] = t;
+        msk[p] = 1.f;
       }
     }
   }
@@ -123,7 +126,7 @@ struct ConvATile {
     for (int p = 0; p < kVecs; ++p) {
       const int r = p * RPP + rr;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[(4 * c + e) * LD + r] = v[p][e];
+      for (int e = 0; e < 4; ++e) s[(4 * c + e) * LD + r] = v[p][e] * msk[p];
     }
   }
 };
@@ -147,6 +150,7 @@ struct ConvTATile {
   static constexpr int CH = BK / 4, RPP = kThreads / CH;
   static constexpr int LD = ROWS + (BK == 16 ? 2 : 1);
   f32x4 v[kVecs];
+  float msk[kVecs];
   long base[kVecs];
   int y0[kVecs], x0[kVecs];
 
@@ -195,7 +199,8 @@ struct ConvTATile {
         const bool ok = base[p] >= 0 && k < op.K && iy >= 0 && iy < op.IH && ix >= 0 && ix < op.IW;
         const float* src = ok ? op.x + base[p] + ((long)iy * op.IW + ix) * op.C + ci : op.x;
         const f32x4 t = *reinterpret_cast<const f32x4u*>(src);
-        v[p] = t * (ok ? 1.f : 0.f);  // multiply keeps the gather unconditional (no exec-mask branch)
+        v[p] = t;                 // consumed only in store(): the gather stays in flight across the MFMAs
+        msk[p] = ok ? 1.f : 0.f;  // (a multiply here would pin a vmcnt(0) wait in front of them)
       }
     } else {
 #pragma unroll
@@ -204,6 +209,7 @@ struct ConvTATile {
 #pragma unroll
         for (int e = 0; e < 4; ++e) t[e] = at(op, p, k + e);
         v[p] = t;
+        msk[p] = 1.f;
       }
     }
   }
@@ -213,7 +219,7 @@ struct ConvTATile {
     for (int p = 0; p < kVecs; ++p) {
       const int r = p * RPP + rr;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[(4 * c + e) * LD + r] = v[p][e];
+      for (int e = 0; e < 4; ++e) s[(4 * c + e) * LD + r] = v[p][e] * msk[p];
     }
   }
 };
@@ -237,6 +243,7 @@ struct WgradBTile {
   static constexpr int LD = ROWS + 4;
   static_assert(kThreads % CH == 0 && BK % KPP == 0, "bad tile");
   f32x4 v[kVecs];
+  float msk[kVecs];
   int jcol;
 
   __device__ __forceinline__ void init(const WgradB&, int n0, int tid) { jcol = n0 + 4 * (tid % CH); }
@@ -276,7 +283,8 @@ struct WgradBTile {
         const bool ok = colok && m < op.Mrows && iy >= 0 && iy < op.H && ix >= 0 && ix < op.W;
         const float* src = ok ? op.x + ((n * op.H + iy) * op.W + ix) * op.C + ci : op.x;
         const f32x4 t = *reinterpret_cast<const f32x4u*>(src);
-        v[p] = t * (ok ? 1.f : 0.f);  // multiply keeps the gather unconditional (no exec-mask branch)
+        v[p] = t;                 // consumed only in store(): the gather stays in flight across the MFMAs
+        msk[p] = ok ? 1.f : 0.f;  // (a multiply here would pin a vmcnt(0) wait in front of them)
       }
     } else {
 #pragma unroll
@@ -286,13 +294,14 @@ struct WgradBTile {
 #pragma unroll
         for (int e = 0; e < 4; ++e) t[e] = at(op, m, jcol + e);
         v[p] = t;
+        msk[p] = 1.f;
       }
     }
   }
   __device__ __forceinline__ void store(float* s, int tid) const {
     const int c = tid % CH, kr = tid / CH;
 #pragma unroll
-    for (int p = 0; p < kVecs; ++p) *reinterpret_cast<f32x4*>(&s[(p * KPP + kr) * LD + 4 * c]) = v[p];
+    for (int p = 0; p < kVecs; ++p) *reinterpret_cast<f32x4*>(&s[(p * KPP + kr) * LD + 4 * c]) = v[p] * msk[p];
   }
 };
 

@@ -14,7 +14,8 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 _REPO = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_HERE, "libdv3hip.so")
+# DV3HIP_LIB: development override (A/B two builds of the library inside one GPU session)
+LIB_PATH = os.environ.get("DV3HIP_LIB") or os.path.join(_HERE, "libdv3hip.so")
 HEADER_PATH = os.path.join(_REPO, "include", "dv3hip.h")
 
 _CTYPES = {
