@@ -236,7 +236,7 @@ struct WgradB {
   FastDiv dOW, dOH, dC, dC4;
 };
 
-template <int ROWS, int BK>
+template <int ROWS, int BK, bool C3 = false>  // C3: the fine tensor has 3 channels (image side)
 struct WgradBTile {
   static constexpr int kVecs = ROWS * BK / 4 / kThreads;
   static constexpr int CH = ROWS / 4, KPP = kThreads / CH;
@@ -244,6 +244,7 @@ struct WgradBTile {
   static_assert(kThreads % CH == 0 && BK % KPP == 0, "bad tile");
   f32x4 v[kVecs];
   float msk[kVecs];
+  int edge[kVecs];  // C == 3 only: 1 = left image edge (keep loaded[0] as element 3), 2 = right edge (loaded[3] as element 0)
   int jcol;
 
   __device__ __forceinline__ void init(const WgradB&, int n0, int tid) { jcol = n0 + 4 * (tid % CH); }
@@ -261,12 +262,37 @@ struct WgradBTile {
     return op.x[((n * op.H + iy) * op.W + ix) * op.C + ci];
   }
   __device__ __forceinline__ static int full_tiles(const WgradB& op, int kbeg, int kend) {
-    return ((op.C & 3) == 0) ? (kend - kbeg + BK - 1) / BK : 0;
+    return (C3 || (op.C & 3) == 0) ? (kend - kbeg + BK - 1) / BK : 0;
   }
   __device__ __forceinline__ void load_full(const WgradB& op, int r0, int k0, int tid) { load(op, r0, k0, tid); }
   __device__ __forceinline__ void load_tail(const WgradB& op, int r0, int k0, int tid) { load(op, r0, k0, tid); }
   __device__ __forceinline__ void load(const WgradB& op, int, int k0, int tid) {
     const int kr = tid / CH;
+    if constexpr (C3) {
+      // image-side layer: the 12 floats (kx, ci) of one kernel row are CONTIGUOUS in NHWC, so this lane's four
+      // columns j = jcol..jcol+3 are one 16-byte load at x[n][iy][2ox-1][0] + jcol % 12.  Only the first and
+      // last output column of an image row reach outside it: there the load is shifted by one pixel to stay
+      // inside the row and store() keeps the single float that belongs to this lane (edge = 1 / 2).
+      const int ky = jcol / 12, off = jcol - 12 * ky;
+      const bool colok = jcol < 48;
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        const long m = (long)k0 + p * KPP + kr;
+        const long mc = (m < op.Mrows) ? m : 0;
+        const int ox = op.dOW.rem(mc);
+        const long q = op.dOW.quot(mc);
+        const int oy = op.dOH.rem(q);
+        const long n = op.dOH.quot(q);
+        const int iy = 2 * oy - 1 + ky;
+        const bool ok = colok && m < op.Mrows && iy >= 0 && iy < op.H;
+        const int e1 = (ox == 0 && off == 0) ? 1 : (ox == op.OW - 1 && off == 8) ? 2 : 0;
+        const long f = ((n * op.H + iy) * op.W + (2 * ox - 1)) * 3 + off + (e1 == 1 ? 3 : e1 == 2 ? -3 : 0);
+        v[p] = *reinterpret_cast<const f32x4u*>(ok ? op.x + f : op.x);
+        msk[p] = ok ? 1.f : 0.f;
+        edge[p] = e1;
+      }
+      return;
+    }
     if ((op.C & 3) == 0) {
       const int ky = op.dC4.quot(jcol), jj = op.dC4.rem(jcol);
       const int kx = op.dC.quot(jj), ci = op.dC.rem(jj);
@@ -301,7 +327,14 @@ struct WgradBTile {
   __device__ __forceinline__ void store(float* s, int tid) const {
     const int c = tid % CH, kr = tid / CH;
 #pragma unroll
-    for (int p = 0; p < kVecs; ++p) *reinterpret_cast<f32x4*>(&s[(p * KPP + kr) * LD + 4 * c]) = v[p] * msk[p];
+    for (int p = 0; p < kVecs; ++p) {
+      f32x4 t = v[p];
+      if constexpr (C3) {
+        if (edge[p] == 1) t = (f32x4){0.f, 0.f, 0.f, t[0]};
+        else if (edge[p] == 2) t = (f32x4){t[3], 0.f, 0.f, 0.f};
+      }
+      *reinterpret_cast<f32x4*>(&s[(p * KPP + kr) * LD + 4 * c]) = t * msk[p];
+    }
   }
 };
 
@@ -401,11 +434,11 @@ struct WgradParams {
 };
 
 // dw_packed[co][(ky,kx,ci)] += sum_m dy[m][co] * x[n,2oy+ky-1,2ox+kx-1,ci]
-template <class TS>
+template <class TS, bool C3 = false>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
   __shared__ __attribute__((aligned(16))) float lds[TS::lds_floats];
   using ATile = DenseTile<TS::BM, TS::BK, false>;  // A[k=m][row=co], co-contiguous
-  using BTile = WgradBTile<TS::BN, TS::BK>;
+  using BTile = WgradBTile<TS::BN, TS::BK, C3>;
   const int OH = p.H / 2, OW = p.W / 2;
   const long rows = (long)p.Nimg * OH * OW;
   DenseOperand<false> aop{p.dy, nullptr, (long)p.Co, 0, p.Co, (int)rows, (int)rows, true};
@@ -420,8 +453,8 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
   f32x16 acc[TS::TM][TS::TN];
   bool owner;
   mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, (int)kb, (int)ke, lds, acc, owner);
-  if (kb >= ke) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (kb >= ke || !owner) return;
+  const int tid = threadIdx.x, wave = (tid >> 6) % (TS::WM * TS::WN), lane = tid & 63;
   const int wm = wave / TS::WN, wn = wave % TS::WN, col_l = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int a = 0; a < TS::TM; ++a)
@@ -614,6 +647,7 @@ __global__ __launch_bounds__(256) void convT_s2_c3_kernel(const float* __restric
 using C128 = TileShape<2, 2, 2, 2, 16>;    // 128 x 128
 using C64 = TileShape<2, 2, 1, 1, 32>;     // 64 x 64
 using C128x32 = TileShape<4, 1, 1, 1, 32>;  // 128 x 32 (narrow channel counts)
+using C32x64S = TileShape<1, 2, 1, 1, 64, 2>;  // 32 x 64, K split over two wave-groups (first/last layer wgrad)
 
 }  // namespace dv3
 
@@ -693,10 +727,12 @@ extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* 
     splits = (rows + chunk - 1) / chunk;
     p.splits = (int)splits;
     p.chunk = (int)chunk;
-    hipLaunchKernelGGL((conv_wgrad_kernel<TS>), dim3((unsigned)(tiles * splits)), dim3(kThreads), 0, (hipStream_t)stream, p);
+    if (Cfine == 3) hipLaunchKernelGGL((conv_wgrad_kernel<TS, true>), dim3((unsigned)(tiles * splits)), dim3(kThreads), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<TS, false>), dim3((unsigned)(tiles * splits)), dim3(kThreads), 0, (hipStream_t)stream, p);
   };
   // 128x128 tiles halve the L2->LDS traffic per flop; they need >= 128 output channels to fill their rows
   if (Ccoarse >= 128) go(C128{}, 512);
+  else if (Ccoarse <= 32) go(C32x64S{}, 1024);  // image-side layers: 32 output channels x 48 (ky,kx,ci) columns
   else go(C64{}, 1024);
   const long total = 16L * Ccoarse * Cfine;
   unsigned ub = (unsigned)((total + 255) / 256);

@@ -512,7 +512,8 @@ def test_adam_clip_matches_oracle(ops):
 
 # ------------------------------------------------------------------------------------------ conv stacks
 CONV_CASES = [(4, 64, 64, 3, 32), (3, 32, 32, 32, 64), (2, 16, 16, 64, 128), (5, 8, 8, 128, 256),
-              (3, 64, 64, 3, 2), (3, 32, 32, 2, 4), (2, 8, 8, 8, 16), (1, 4, 4, 6, 5)]
+              (3, 64, 64, 3, 2), (3, 32, 32, 2, 4), (2, 8, 8, 8, 16), (1, 4, 4, 6, 5),
+              (2, 64, 64, 3, 32), (5, 2, 2, 3, 32), (2, 4, 4, 3, 96), (33, 8, 8, 3, 40)]  # image-side wgrad path
 
 
 def nhwc(x):
