@@ -104,6 +104,48 @@ def cpu_baseline(name, updates=2):
             "sec_per_update": t}
 
 
+def phase_timers(wm, beh, data, H, t_upd_ms, reps=10):
+    """T_img / T_beh of SURVEY 8(d): device time of one hipGraph replay each (median of `reps`)."""
+    from dv3hip import ops
+
+    def replay_ms(fn):
+        fn()  # warm (workspace allocation happens outside capture)
+        torch.cuda.synchronize()
+        st = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(st):
+            with torch.cuda.graph(g, stream=st):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return float(np.median(ts))
+
+    post, _, _ = wm._train(data)
+    ops.PROFILE.by_shape = False
+    ops.PROFILE.start()
+    beh._imagine_fwd(post, H)
+    prof = ops.PROFILE.stop()
+    gflop = sum(v["flops"] for v in prof.values()) / 1e9
+    t_img = replay_ms(lambda: beh._imagine_fwd(post, H))
+
+    def behaviour():
+        beh.train_fwd_bwd(post)
+        beh.train_opt(allreduce=False)
+
+    t_beh = replay_ms(behaviour)
+    return {"T_upd_ms": t_upd_ms, "T_beh_ms": t_beh, "T_img_ms": t_img,
+            "method": "hipGraph replay of the phase, HIP events, median of 10",
+            "imagine_fwd_gflop": gflop, "imagine_fwd_tflops": gflop / t_img}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +264,20 @@ def main():
                                       "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
                                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:(40 if args.by_shape else 16)]}}
 
+    # ---- SURVEY 8(d) timers: T_img (= _imagine forward only) and T_beh (= ImagBehavior._train) beside T_upd,
+    # each captured into its own hipGraph and replayed (single rank only: T_beh contains the actor/critic
+    # all-reduces, which stay outside capture)
+    timers = None
+    if world == 1:
+        timers = phase_timers(wm, beh, data, H, elapsed / args.steps * 1e3)
+        if roofline is not None:
+            roofline["imagine_fwd"] = {
+                "gflop_executed": timers.pop("imagine_fwd_gflop"), "ms": timers["T_img_ms"],
+                "achieved": timers["imagine_fwd_tflops"], "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
+                "frac": timers.pop("imagine_fwd_tflops") / PEAK_F32_MFMA_TFLOPS,
+                "note": "MFMA utilisation of the imagination rollout (15 actor evaluations + 14 img_steps at 1024 "
+                        "rows; the discarded 15th successor of models.py:546 is not computed)"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(name)
@@ -239,7 +295,7 @@ def main():
                                    "gradient all-reduce, 3x clip+Adam)",
                        "global_batch": B * world, "seq_len": T, "horizon": H, "parallelism": f"dp{world}",
                        "launch": "eager" if args.no_graph else "hipGraph replay"},
-            "model_loss": loss,
+            "model_loss": loss, "timers": timers,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
