@@ -311,14 +311,17 @@ class WorldModel(nn.Module):
         rng.commit()
         self._pending = (post, context, metrics, loss[0])
 
-    def video_pred(self, data):
-        """models.py:192-213 (forward-only open-loop prediction for logging)."""
+    def video_pred(self, data, noise=None):
+        """models.py:192-213 (forward-only open-loop prediction for logging).  noise (tests): dict of Exp(1)
+        draws q_prior, q_post [5,Bv,S,D] and q_open [T-5,Bv,S,D]; default = the Philox stream."""
         data = self.preprocess(data)
         embed = self.encoder(data)
-        states, _ = self.dynamics.observe(embed[:6, :5], data["action"][:6, :5], data["is_first"][:6, :5])
+        nz = noise or {}
+        states, _ = self.dynamics.observe(embed[:6, :5], data["action"][:6, :5], data["is_first"][:6, :5],
+                                          noise=noise)
         recon = self.heads["decoder"](self.dynamics.get_feat(states))["image"].mode()[:6]
         init = {k: v[:, -1] for k, v in states.items()}
-        prior = self.dynamics.imagine_with_action(data["action"][:6, 5:], init)
+        prior = self.dynamics.imagine_with_action(data["action"][:6, 5:], init, noise=nz.get("q_open"))
         openl = self.heads["decoder"](self.dynamics.get_feat(prior))["image"].mode()
         model = torch.cat([recon[:, :5], openl], 1)
         truth = data["image"][:6]

@@ -215,13 +215,14 @@ class RSSM(nn.Module):
         prior = {"stoch": bt(out["prior_stoch"]), "deter": bt(out["deter"]), "logit": bt(out["prior_logit"])}
         return post, prior
 
-    def imagine_with_action(self, action, state):
-        """networks.py:145-152: open-loop rollout of given actions [B,T,A] from `state` {[B,...]}."""
+    def imagine_with_action(self, action, state, noise=None):
+        """networks.py:145-152: open-loop rollout of given actions [B,T,A] from `state` {[B,...]}.
+        noise (tests): Exp(1) draws [T,B,S,D] for the prior samples; default = the Philox stream."""
         assert isinstance(state, dict), state
         outs = []
         cur = state
         for t in range(action.shape[1]):
-            cur = self.img_step(cur, action[:, t])
+            cur = self.img_step(cur, action[:, t], noise=None if noise is None else noise[t])
             outs.append(cur)
         return {k: torch.stack([o[k] for o in outs], 1) for k in outs[0]}
 

@@ -566,6 +566,29 @@ def imagine(cfg: PathConfig, p, start: Dict[str, Tensor], act_noise: Tensor, q_p
     return torch.stack(feats, 0), states, torch.stack(actions, 0)
 
 
+def video_pred(cfg: PathConfig, p, data: Dict, q_prior: Tensor, q_post: Tensor, q_open: Tensor) -> Tensor:
+    """WorldModel.video_pred (models.py:192-213): posterior reconstruction of the first 5 steps of the first 6
+    sequences, open-loop prior rollout (RSSM.imagine_with_action, networks.py:145-152) of the rest, stacked
+    with the truth and the error along the image height.  q_prior/q_post [5,Bv,S,D], q_open [T-5,Bv,S,D].
+    Returns [Bv, T, 3*64, 64, 3]."""
+    obs = preprocess(cfg, data)
+    embed = conv_encoder(cfg, p, obs["image"])
+    states, _ = observe(cfg, p, embed[:6, :5], obs["action"][:6, :5], obs["is_first"][:6, :5], q_prior, q_post)
+    recon = conv_decoder(cfg, p, get_feat(cfg, states))[:6]
+    cur = {k: v[:, -1] for k, v in states.items()}
+    act = obs["action"][:6, 5:]
+    outs = []
+    for t in range(act.shape[1]):
+        cur = img_step(cfg, p, cur["stoch"], cur["deter"], act[:, t], q_open[t])
+        outs.append(cur)
+    prior = {k: torch.stack([o[k] for o in outs], 1) for k in outs[0]}
+    openl = conv_decoder(cfg, p, get_feat(cfg, prior))
+    model = torch.cat([recon[:, :5], openl], 1)
+    truth = obs["image"][:6]
+    error = (model - truth + 1.0) / 2.0
+    return torch.cat([truth, model, error], 2)
+
+
 def lambda_return(reward: Tensor, value: Tensor, disc: Tensor, lam: float) -> Tensor:
     """models.py:627-634 + tools.lambda_return (tools.py:702-728).
 

@@ -226,6 +226,27 @@ def imagine_tape(noise: Dict[str, np.ndarray]) -> List[np.ndarray]:
     return tape
 
 
+def make_video_noise(name: str, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Draws of WorldModel.video_pred (models.py:192-213): 5 observed steps of the first 6 sequences
+    (q_prior, q_post [5,Bv,S,D]) and the open-loop rest (q_open [T-5,Bv,S,D]), all ~ Exp(1)."""
+    s = SHAPES[name]
+    bv, T, S, D = min(6, s["B"]), s["T"], s["stoch"], s["discrete"]
+    rs = np.random.RandomState(2000 + seed)
+    out = {"q_prior": rs.exponential(size=(5, bv, S, D)).astype(np.float32),
+           "q_post": rs.exponential(size=(5, bv, S, D)).astype(np.float32),
+           "q_open": rs.exponential(size=(T - 5, bv, S, D)).astype(np.float32)}
+    for k in out:
+        np.maximum(out[k], 1e-20, out=out[k])
+    return out
+
+
+def video_tape(noise: Dict[str, np.ndarray]) -> List[np.ndarray]:
+    """Order in which the reference's video_pred draws: observe (prior, post per step), then the rollout."""
+    tape = observe_tape(noise)
+    tape.extend(noise["q_open"][t] for t in range(noise["q_open"].shape[0]))
+    return tape
+
+
 def checksum(x: np.ndarray) -> np.ndarray:
     """(sum, abs-sum, max-abs) in float64 -- cheap whole-tensor pin for large outputs."""
     x = np.asarray(x, np.float64)

@@ -369,6 +369,30 @@ def run_config(name, tools, networks, models, full: bool):
           f"value_loss={float(out['value_loss']):.6f}")
 
 
+def run_video(name, tools, networks, models):
+    """WorldModel.video_pred of the reference (models.py:192-213) with injected noise -> {name}_video.npz
+    (full output for the tiny config; checksum + the first sequence's rows 0/4/5/T-1 otherwise)."""
+    global TAPE
+    cfg, wm, beh, w = build_reference(name, tools, networks, models)
+    data = common.make_batch(name)
+    noise = common.make_video_noise(name)
+    TAPE = Tape(common.video_tape(noise))
+    with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+        video = wm.video_pred({k: v.copy() for k, v in data.items()})
+    assert TAPE.pos == len(TAPE.arrays)
+    TAPE = None
+    v = to_np(video)
+    out = {"sum/video": common.checksum(v), "meta/shape": np.array(v.shape)}
+    if name.startswith("tiny"):
+        out["video"] = v
+    else:
+        T = v.shape[1]
+        out["video_rows"] = v[0, [0, 4, 5, T - 1]]
+    path = os.path.join(HERE, f"{name}_video.npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB, video {v.shape}, mean {v.mean():.6f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -382,6 +406,9 @@ def main():
         if args.only and name != args.only:
             continue
         run_config(name, tools, networks, models, full)
+    for name in ("tiny", "cfg2"):
+        if args.only in (None, name + "_video"):
+            run_video(name, tools, networks, models)
 
 
 if __name__ == "__main__":

@@ -109,3 +109,27 @@ def test_policy_step_matches_oracle():
     mean, std = O.actor_stats(pc, p, feat)
     assert torch.allclose(latent["deter"].cpu(), post["deter"], atol=1e-4)
     assert torch.allclose(latent["logit"].cpu(), post["logit"], atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg2"])
+def test_video_pred_matches_reference_golden(name):
+    """WorldModel.video_pred (models.py:192-213) on the GPU path, same weights / batch / noise,
+    against the video the reference itself produced (tests/golden/*_video.npz).  fp32, tolerance 1e-4."""
+    import os
+
+    import numpy as np
+
+    path = os.path.join(os.path.dirname(__file__), "golden", name + "_video.npz")
+    g = np.load(path, allow_pickle=False)
+    _, wm, _ = Hh.build_models(name)
+    noise = {k: torch.from_numpy(v).cuda() for k, v in common.make_video_noise(name).items()}
+    video = wm.video_pred(common.make_batch(name), noise=noise).cpu().numpy()
+    assert tuple(video.shape) == tuple(g["meta/shape"])
+    if "video" in g.files:
+        assert np.abs(video - g["video"]).max() <= 1e-4
+    else:
+        T = video.shape[1]
+        assert np.abs(video[0, [0, 4, 5, T - 1]] - g["video_rows"]).max() <= 1e-4
+    ref = g["sum/video"]
+    got = common.checksum(video)
+    assert abs(got[0] - ref[0]) <= 1e-4 * ref[1] and abs(got[1] - ref[1]) <= 1e-4 * ref[1]

@@ -222,3 +222,21 @@ def test_full_size_slices_and_checksums(name):
         # a flip changes the row's future; teacher-forced comparison covers this in the GPU tests
         flips = (out["post"]["stoch"][sel].numpy() != g["post/stoch"]).any(-1).any(-1).mean()
         assert flips < 0.05, f"too many sample flips vs reference: {flips}"
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg2"])
+def test_video_pred_matches_reference(name):
+    """Open-loop prediction video (models.py:192-213) against the reference's own output."""
+    g = load(name + "_video")
+    cfg = common.path_config(name)
+    p = tparams(name)
+    n = {k: torch.from_numpy(v) for k, v in common.make_video_noise(name).items()}
+    with torch.no_grad():
+        v = O.video_pred(cfg, p, common.make_batch(name), n["q_prior"], n["q_post"], n["q_open"])
+    assert tuple(v.shape) == tuple(g["meta/shape"])
+    check_sum(g, "video", _np(v), tol=2e-5)
+    if "video" in g.files:
+        close(v, g["video"], what="video")
+    else:
+        T = v.shape[1]
+        close(v[0, [0, 4, 5, T - 1]], g["video_rows"], what="video rows")
