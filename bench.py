@@ -278,6 +278,22 @@ def main():
                 "note": "MFMA utilisation of the imagination rollout (15 actor evaluations + 14 img_steps at 1024 "
                         "rows; the discarded 15th successor of models.py:546 is not computed)"}
 
+    # ---- PCIe-inclusive rate (never `value`): every step stages a fresh HOST batch through the pinned,
+    # double-buffered stager (dv3hip/staging.py), overlapped with the previous update
+    if world == 1 and timers is not None:
+        from dv3hip.staging import BatchStager
+
+        host = {k: v.cpu().numpy() for k, v in data.items()}
+        stager = BatchStager(device)
+        for _ in range(3):
+            runner.step(stager.stage(host))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            runner.step(stager.stage(host))
+        torch.cuda.synchronize()
+        timers["T_upd_host_staged_ms"] = (time.perf_counter() - t0) / args.steps * 1e3
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(name)

@@ -365,6 +365,56 @@ def static_scan(fn, inputs, start):
     return res
 
 
+# ---------------------------------------------------------------------------------------------
+# Replay sampling: the two generators between the episode store and WorldModel._train.
+# Same draws, same batches as the reference for the same seed (tests/golden/replay.npz), without its
+# per-piece np.append / per-key Python list stacking: every sequence is written once into a preallocated
+# [length, ...] array and every batch into preallocated [B, T, ...] arrays.
+# ---------------------------------------------------------------------------------------------
+def sample_episodes(episodes, length, seed=0):
+    """tools.py:324-371: endless generator of dicts of [length, ...] arrays cut from `episodes` (dict
+    name -> dict of per-step arrays).  A sequence starts at a uniform offset of an episode drawn with
+    probability proportional to its length and continues from the START of further draws until `length`
+    steps are collected; is_first is forced at the first step and at every join; keys containing "log_"
+    are dropped; episodes shorter than 2 steps are redrawn.  Data-parallel ranks pass seed + rank."""
+    rng = np.random.RandomState(seed)
+    while True:
+        eps = list(episodes.values())
+        lens = np.array([len(next(iter(ep.values()))) for ep in eps])
+        p = lens / np.sum(lens)
+        out, size = None, 0
+        while size < length:
+            ep = eps[int(rng.choice(len(eps), p=p))]
+            total = len(next(iter(ep.values())))
+            if total < 2:
+                continue
+            if out is None:
+                index = int(rng.randint(0, total - 1))
+                keys = [k for k in ep if "log_" not in k]
+                out = {k: np.empty((length,) + ep[k].shape[1:], ep[k].dtype) for k in keys}
+            else:
+                index = 0
+            n = min(length - size, total - index)
+            for k in out:
+                out[k][size:size + n] = ep[k][index:index + n]
+            if "is_first" in out:
+                out["is_first"][size] = True
+            size += n
+        yield out
+
+
+def from_generator(generator, batch_size):
+    """tools.py:310-321: stack `batch_size` draws of `generator` on a new leading axis."""
+    while True:
+        first = next(generator)
+        data = {k: np.empty((batch_size,) + v.shape, v.dtype) for k, v in first.items()}
+        for i in range(batch_size):
+            item = first if i == 0 else next(generator)
+            for k, v in item.items():
+                data[k][i] = v
+        yield data
+
+
 class Every:  # tools.py:853-868
     def __init__(self, every):
         self._every, self._last = every, None

@@ -247,6 +247,34 @@ def video_tape(noise: Dict[str, np.ndarray]) -> List[np.ndarray]:
     return tape
 
 
+REPLAY_LENGTH, REPLAY_BATCH = 16, 4
+
+
+def make_episodes():
+    """Synthetic episode store in the reference's in-memory format (tools.load_episodes: ordered dict
+    name -> dict of per-step arrays).  Lengths include a 1-step episode (skipped by the sampler), episodes
+    shorter than the sequence length (joined) and long ones.  reward = 1000*episode + index is a unique id."""
+    import collections
+
+    rs = np.random.RandomState(77)
+    eps = collections.OrderedDict()
+    for e, n in enumerate((1, 7, 30, 50, 3, 21)):
+        first = np.zeros(n, bool)
+        first[0] = True
+        term = np.zeros(n, bool)
+        term[-1] = e % 2 == 0
+        eps[f"ep{e}"] = {
+            "image": rs.randint(0, 256, (n, 4, 4, 3)).astype(np.uint8),
+            "action": rs.uniform(-1, 1, (n, 3)).astype(np.float32),
+            "reward": (1000.0 * e + np.arange(n)).astype(np.float32),
+            "discount": np.ones(n, np.float32),
+            "is_first": first, "is_terminal": term,
+            "logprob": rs.randn(n).astype(np.float32),
+            "log_entropy": rs.randn(n).astype(np.float32),  # "log_" keys are dropped by the sampler
+        }
+    return eps
+
+
 def checksum(x: np.ndarray) -> np.ndarray:
     """(sum, abs-sum, max-abs) in float64 -- cheap whole-tensor pin for large outputs."""
     x = np.asarray(x, np.float64)

@@ -133,3 +133,31 @@ def test_video_pred_matches_reference_golden(name):
     ref = g["sum/video"]
     got = common.checksum(video)
     assert abs(got[0] - ref[0]) <= 1e-4 * ref[1] and abs(got[1] - ref[1]) <= 1e-4 * ref[1]
+
+
+def test_batch_stager_matches_direct_upload_and_trains():
+    """Pinned double-buffered staging: what lands in HBM is the host batch (uint8 images, flags
+    as float), slots are recycled, and an update on a staged batch equals the update on the host batch."""
+    from dv3hip.staging import BatchStager
+
+    name = "tiny"
+    stager = BatchStager("cuda:0", depth=2)
+    batches = [common.make_batch(name, seed=s) for s in range(3)]
+    for b in batches:  # 3 batches through 2 slots
+        d = stager.stage(b)
+        torch.cuda.synchronize()
+        assert d["image"].dtype == torch.uint8 and d["is_first"].dtype == torch.float32
+        for k, v in b.items():
+            want = torch.from_numpy(np.ascontiguousarray(v))
+            assert torch.equal(d[k].cpu().to(want.dtype), want), k
+    noise = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(name).items()}
+    outs = []
+    for staged in (False, True):
+        _, wm, _ = Hh.build_models(name)
+        data = stager.stage(batches[0]) if staged else batches[0]
+        post, _, mets = wm._train(data, noise=noise)
+        outs.append((post["deter"].clone(), float(mets["model_loss"]),
+                     torch.cat([p.detach().reshape(-1) for p in wm.parameters()]).clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]  # forward: bit-equal
+    # the backward adds split-K partial sums with atomics (order not fixed): parameters agree to fp32 rounding
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=0, atol=1e-6)
