@@ -29,21 +29,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // state[2] = grad norm (output, for the `*_grad_norm` metric)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
-                                                   float* __restrict__ state, float lr, float b1, float b2,
-                                                   float eps, float clip, float wd, float gscale) {
+                                                   float* __restrict__ state, double lr, double b1d, double b2d,
+                                                   double epsd, float clip, float wd, float gscale) {
   const float step = state[0] + 1.f;
   const float norm = sqrtf(state[1]) * gscale;
   float coef = 1.f;
   if (clip > 0.f) coef = fminf(clip / (norm + 1e-6f), 1.f);
-  const float bc1 = 1.f - powf(b1, step);
-  const float bc2s = sqrtf(1.f - powf(b2, step));
-  const float step_size = lr / bc1;
+  // per-step scalars in double, rounded to float once -- exactly what torch.optim.Adam's single-tensor path does
+  // (bias_correction = 1 - beta ** step, step_size = lr / bias_correction1, value = 1 - beta2, ...)
+  const float w1 = (float)(1.0 - b1d), w2 = (float)(1.0 - b2d), b2 = (float)b2d, eps = (float)epsd;
+  const float bc2s = (float)sqrt(1.0 - pow(b2d, (double)step));
+  const float step_size = (float)(lr / (1.0 - pow(b1d, (double)step)));
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * (coef * gscale);
     float pi = p[i];
     if (wd > 0.f) pi *= (1.f - wd);  // tools.py:778-783 (applied before the step, as the reference does)
-    const float mi = m[i] + (1.f - b1) * (gi - m[i]);
-    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    const float mi = m[i] + w1 * (gi - m[i]);
+    const float vi = v[i] * b2 + w2 * gi * gi;
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2s + eps;
@@ -104,7 +106,7 @@ extern "C" int dv3_sumsq_accumulate(const float* x, long n, float* out, void* st
 }
 
 extern "C" int dv3_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float* state,
-                             float lr, float beta1, float beta2, float eps, float clip, float weight_decay,
+                             double lr, double beta1, double beta2, double eps, float clip, float weight_decay,
                              float grad_scale, void* stream) {
   if (n <= 0) return 0;
   if (!param || !grad || !exp_avg || !exp_avg_sq || !state) return DV3_ERR_ARG;

@@ -30,6 +30,7 @@ _CTYPES = {
     "long": ctypes.c_long,
     "int": ctypes.c_int,
     "float": ctypes.c_float,
+    "double": ctypes.c_double,
 }
 
 

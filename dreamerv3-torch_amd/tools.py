@@ -298,6 +298,59 @@ def lambda_return(reward, value, pcont, bootstrap, lambda_, axis):
 # ---------------------------------------------------------------------------------------------
 # optimizer
 # ---------------------------------------------------------------------------------------------
+class _BucketAdam(torch.optim.Optimizer):
+    """The `_opt` member of the reference's Optimizer (tools.py:752: torch.optim.Adam) as far as checkpoints see
+    it: tools.recursively_collect_optim_state_dict (tools.py:975-1002) looks for torch.optim.Optimizer instances
+    and saves their state_dict() under the attribute path (`_wm._model_opt._opt`, ...).  This one serialises the
+    flat bucket in torch.optim.Adam's format and loads that format back, so `optims_state_dict` of a reference
+    checkpoint and of this build are interchangeable.  The update itself is ParamBucket.step (dv3_adam_step)."""
+
+    def __init__(self, bucket, lr, eps, weight_decay):
+        self._bucket = bucket
+        super().__init__(bucket.params, dict(lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=weight_decay,
+                                             amsgrad=False, maximize=False, foreach=None, capturable=False,
+                                             differentiable=False, fused=None))
+
+    def step(self, closure=None):
+        raise RuntimeError("the update runs in tools.Optimizer.finish() (flat-bucket clip + Adam kernel)")
+
+    def state_dict(self):
+        b = self._bucket.ensure()
+        steps = float(b.state[0])
+        state = {}
+        if steps > 0:
+            for i, (p, (off, n)) in enumerate(zip(b.params, b._layout)):
+                state[i] = {"step": torch.tensor(steps, dtype=torch.float32),
+                            "exp_avg": b.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": b.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        groups = [dict({k: v for k, v in g.items() if k != "params"}, params=list(range(len(g["params"]))))
+                  for g in self.param_groups]
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        b = self._bucket.ensure()
+        st = state_dict["state"]
+        if len(st) not in (0, len(b.params)):
+            raise ValueError(f"optimizer state has {len(st)} entries for {len(b.params)} parameters")
+        b.exp_avg.zero_(), b.exp_avg_sq.zero_()
+        steps = 0.0
+        for i, (p, (off, n)) in enumerate(zip(b.params, b._layout)):
+            e = st.get(i, st.get(str(i)))
+            if e is None:
+                continue
+            if tuple(e["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state {i}: shape {tuple(e['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
+            b.exp_avg[off:off + n].copy_(e["exp_avg"].reshape(-1))
+            b.exp_avg_sq[off:off + n].copy_(e["exp_avg_sq"].reshape(-1))
+            steps = float(e["step"])
+        b.state.zero_()
+        b.state[0] = steps
+        g = state_dict["param_groups"][0]
+        for k in ("lr", "eps", "weight_decay"):
+            if k in g:
+                self.param_groups[0][k] = g[k]
+
+
 class Optimizer:
     """tools.py:731-783 surface over a flat bucket: zero_grad / (caller runs backward into .grad) /
     all-reduce / clip / Adam.  `__call__(loss, params)` of the reference is split in two because the
@@ -313,8 +366,21 @@ class Optimizer:
             raise NotImplementedError("precision 16 is not supported: the path is fp32 (configs.yaml:18)")
         if wd_pattern != r".*":
             raise NotImplementedError
-        self._name, self._lr, self._eps, self._clip, self._wd = name, float(lr), float(eps), clip, wd or 0.0
+        self._name, self._clip = name, clip
         self.bucket = ParamBucket(name, parameters)
+        self._opt = _BucketAdam(self.bucket, float(lr), float(eps), wd or 0.0)  # hyper-parameters live in its group
+
+    @property
+    def _lr(self):
+        return self._opt.param_groups[0]["lr"]
+
+    @property
+    def _eps(self):
+        return self._opt.param_groups[0]["eps"]
+
+    @property
+    def _wd(self):
+        return self._opt.param_groups[0]["weight_decay"]
 
     def begin(self):
         self.bucket.ensure().zero_grad()
@@ -333,14 +399,39 @@ class Optimizer:
         return {f"{self._name}_loss": loss, f"{self._name}_grad_norm": self.bucket.grad_norm}
 
     def state_dict(self):
-        b = self.bucket.ensure()
-        return {"exp_avg": b.exp_avg, "exp_avg_sq": b.exp_avg_sq, "state": b.state}
+        """torch.optim.Adam format (see _BucketAdam)."""
+        return self._opt.state_dict()
 
     def load_state_dict(self, sd):
-        b = self.bucket.ensure()
-        b.exp_avg.copy_(sd["exp_avg"])
-        b.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        b.state.copy_(sd["state"])
+        self._opt.load_state_dict(sd)
+
+
+def recursively_collect_optim_state_dict(obj, path="", optimizers_state_dicts=None, visited=None):
+    """tools.py:975-1002: {attribute path: state_dict} of every torch.optim.Optimizer reachable from obj."""
+    out = {} if optimizers_state_dicts is None else optimizers_state_dicts
+    seen = set() if visited is None else visited
+    if id(obj) in seen:
+        return out
+    seen.add(id(obj))
+    attrs = dict(getattr(obj, "__dict__", {}))
+    if isinstance(obj, torch.nn.Module):
+        attrs.update({k: m for k, m in obj.named_modules() if k and "." not in k})
+    for name, attr in attrs.items():
+        here = f"{path}.{name}" if path else name
+        if isinstance(attr, torch.optim.Optimizer):
+            out[here] = attr.state_dict()
+        elif hasattr(attr, "__dict__"):
+            recursively_collect_optim_state_dict(attr, here, out, seen)
+    return out
+
+
+def recursively_load_optim_state_dict(obj, optimizers_state_dicts):
+    """tools.py:1005-1011."""
+    for path, sd in optimizers_state_dicts.items():
+        cur = obj
+        for key in path.split("."):
+            cur = getattr(cur, key)
+        cur.load_state_dict(sd)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -226,8 +226,11 @@ int dv3_obs_blend_bwd(const float* dsin, long ld_dsin, const float* ddin, long l
  * clears the accumulator -- all on device.  dv3_axpby: y = a*x + b*y (slow critic, models.py:683-689). */
 int dv3_sumsq_accumulate(const float* x, long n, float* out, void* stream);
 int dv3_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float* state,
-                  float lr, float beta1, float beta2, float eps, float clip, float weight_decay, float grad_scale,
-                  void* stream);
+                  double lr, double beta1, double beta2, double eps, float clip, float weight_decay,
+                  float grad_scale, void* stream);
+/* lr / betas / eps are doubles because torch.optim.Adam derives its per-step scalars (1-beta, the bias
+ * corrections, lr / (1 - beta1^t)) in double before rounding them to float: the kernel does the same, so that
+ * its moments and parameters track a torch.optim.Adam run (and its saved state_dict) to fp32 rounding. */
 /* grad_scale multiplies every gradient (and the norm) first: 1/world_size after a SUM all-reduce. */
 int dv3_axpby(const float* x, float* y, long n, float a, float b, void* stream);
 int dv3_rng_advance(unsigned long long* rng_state, unsigned long long increment, void* stream);

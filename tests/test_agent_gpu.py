@@ -161,3 +161,55 @@ def test_batch_stager_matches_direct_upload_and_trains():
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]  # forward: bit-equal
     # the backward adds split-K partial sums with atomics (order not fixed): parameters agree to fp32 rounding
     assert torch.allclose(outs[0][2], outs[1][2], rtol=0, atol=1e-6)
+
+
+def test_optimizer_state_is_interchangeable_with_torch_adam():
+    """Checkpoint contract (dreamer.py:563-567, tools.py:975-1011): `optims_state_dict` holds torch.optim.Adam
+    state_dicts keyed by attribute path.  The flat-bucket optimizer (a) steps like clip_grad_norm_ + Adam,
+    (b) serialises to that format, (c) resumes from a state_dict produced by torch.optim.Adam itself."""
+    import tools
+
+    name = "tiny"
+    noise = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(name).items()}
+    _, wm, _ = Hh.build_models(name)
+    cfg = wm._config
+    names = [n for n, _ in wm.named_parameters()]
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for p in wm.parameters()]
+    ref = torch.optim.Adam(ref_params, lr=cfg.model_lr, eps=cfg.opt_eps)
+
+    def both_step(seed):
+        wm._train(common.make_batch(name, seed=seed), noise=noise)
+        for rp, p in zip(ref_params, wm.parameters()):
+            rp.grad = p.grad.detach().clone()  # the gradient the bucket just consumed (kept until the next begin())
+        torch.nn.utils.clip_grad_norm_(ref_params, cfg.grad_clip)
+        ref.step()
+
+    both_step(0)
+    for n, rp, p in zip(names, ref_params, wm.parameters()):
+        assert torch.allclose(rp, p, rtol=0, atol=1e-6), n
+    # (b) format: same structure and values as torch.optim.Adam's own state_dict
+    mine, theirs = wm._model_opt.state_dict(), ref.state_dict()
+    assert set(mine) == set(theirs) and set(mine["state"]) == set(theirs["state"])
+    assert mine["param_groups"][0]["params"] == theirs["param_groups"][0]["params"]
+    for k in ("lr", "betas", "eps", "weight_decay", "amsgrad"):
+        assert mine["param_groups"][0][k] == theirs["param_groups"][0][k], k
+    for i in theirs["state"]:
+        assert float(mine["state"][i]["step"]) == float(theirs["state"][i]["step"]) == 1.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.allclose(mine["state"][i][k], theirs["state"][i][k], rtol=1e-5, atol=1e-10), (i, k)
+    # the reference's collector finds it under the reference's attribute path
+    agent = type("Agent", (), {})()
+    agent._wm = wm
+    collected = tools.recursively_collect_optim_state_dict(agent)
+    assert list(collected) == ["_wm._model_opt._opt"]
+    # (c) resume a FRESH model from torch.optim.Adam's state (+ the reference-format weights), then step both again
+    _, wm2, _ = Hh.build_models(name)
+    wm2.load_state_dict({n: rp.detach() for n, rp in zip(names, ref_params)})
+    agent2 = type("Agent", (), {})()
+    agent2._wm = wm2
+    tools.recursively_load_optim_state_dict(agent2, {"_wm._model_opt._opt": ref.state_dict()})
+    wm_old, wm = wm, wm2
+    both_step(1)
+    for n, rp, p in zip(names, ref_params, wm2.parameters()):
+        assert torch.allclose(rp, p, rtol=0, atol=2e-6), n
+    assert float(wm2._model_opt.state_dict()["state"][0]["step"]) == 2.0
