@@ -11,6 +11,8 @@
 //   wgrad    dW = dy^T x : transA=1 transB=0   (A = dy [rows][N_out], B = x [rows][K_in])
 // The two-segment A ([A | A2] along K) is the reference's torch.cat([...], -1) in front of the
 // Linear (networks.py:196, 216, 762; get_feat networks.py:154-159), done without materialising it.
+#include <stdlib.h>
+
 #include "mfma_gemm.h"
 #include "dv3_common.h"
 
@@ -212,6 +214,176 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-direct GEMM for mid-size outputs (the 1024 imagination rows x 512..1536 columns): the same
+// no-LDS scheme as the few-row kernel, tiled over M.  A workgroup owns 32 rows x 16*RN columns; its waves split
+// K (LDS reduce at the end); per 16-k chunk a wave loads 2 A fragments and RN B fragments (16 bytes per lane,
+// 64 contiguous bytes per matrix row) and issues 8*RN v_mfma_f32_16x16x4_f32 -- each loaded fragment is used
+// RN (A) or 2 (B) times from registers, which is what the LDS staging of the tile engine buys at this size,
+// without its LDS write+read of every element and its barriers.  TB: B is [N][K] (else [K][N], scalar loads).
+// grid = (ceil(N / (16*RN)), 1, ceil(M / 32)); blockDim = 64 * waves (4 or 8).
+// ------------------------------------------------------------------------------------------------
+template <bool TB, int RN, int BATCH>
+__global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float dred[];  // [waves][2][RN][256]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nwaves = blockDim.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * (16 * RN), m0 = blockIdx.z * 32;
+  const int chunks = (p.K + 15) >> 4;
+  const int per = (chunks + nwaves - 1) / nwaves;
+  const int cb = wave * per, ce = min(chunks, cb + per);
+  f32x4 acc[2][RN];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < RN; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* bcol[RN];
+  float bmask[RN];
+#pragma unroll
+  for (int c = 0; c < RN; ++c) {
+    const int ncol = n0 + 16 * c + i;
+    const bool ok = ncol < p.N;
+    bcol[c] = p.B + (TB ? (long)(ok ? ncol : 0) * p.ldb : (long)(ok ? ncol : 0));
+    bmask[c] = ok ? 1.f : 0.f;
+  }
+  float amask[2];
+  const float* arow[2];
+  const float* arow2[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = m0 + i + 16 * t;
+    const bool ok = row < p.M;
+    amask[t] = ok ? 1.f : 0.f;
+    arow[t] = p.A + (long)(ok ? row : 0) * p.lda;
+    arow2[t] = p.A2 ? p.A2 + (long)(ok ? row : 0) * p.lda2 : nullptr;
+  }
+  // software pipeline: the loads of batch t+1 are issued before the MFMAs of batch t (two register sets)
+  f32x4 a0[BATCH][2], b0[BATCH][RN], a1[BATCH][2], b1[BATCH][RN];
+  const int clast = ce - 1;
+  auto load = [&](f32x4 (&a)[BATCH][2], f32x4 (&b)[BATCH][RN], int c0) {
+    if (c0 >= ce) return;
+    const int cend = min(c0 + BATCH, ce);
+    const bool fast = (cend * 16 <= p.K) && ((c0 * 16 >= p.K1) || (cend * 16 <= p.K1));
+    if (fast) {
+      const bool seg2 = c0 * 16 >= p.K1;
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int k = (min(c0 + u, clast) << 4) + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          a[u][t] = *reinterpret_cast<const f32x4u*>(seg2 ? arow2[t] + (k - p.K1) : arow[t] + k);
+#pragma unroll
+        for (int c = 0; c < RN; ++c) {
+          if (TB) {
+            b[u][c] = *reinterpret_cast<const f32x4u*>(bcol[c] + k);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[u][c][e] = bcol[c][(long)(k + e) * p.ldb];
+          }
+        }
+      }
+    } else {  // ragged end of K or a segment edge inside the batch
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int cc = c0 + u;
+        const int k = (cc << 4) + 4 * q;
+        const bool seg2 = k >= p.K1;
+        const int ka = seg2 ? k - p.K1 : k;
+        const int kend = seg2 ? p.K - p.K1 : p.K1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          const float* src = (seg2 ? arow2[t] : arow[t]) + ka;
+          if (cc < ce) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (ka + e < kend) v[e] = src[e];
+          }
+          a[u][t] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < RN; ++c) {
+          f32x4 w = {0.f, 0.f, 0.f, 0.f};
+          if (cc < ce) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (k + e < p.K) w[e] = TB ? bcol[c][k + e] : bcol[c][(long)(k + e) * p.ldb];
+          }
+          b[u][c] = w;
+        }
+      }
+    }
+  };
+  auto compute = [&](const f32x4 (&a)[BATCH][2], const f32x4 (&b)[BATCH][RN], int c0) {
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u)
+      if (c0 + u < ce) {  // wave-uniform
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float av = a[u][t][g] * amask[t];
+#pragma unroll
+            for (int c = 0; c < RN; ++c)
+              acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u][c][g] * bmask[c], acc[t][c], 0, 0, 0);
+          }
+      }
+  };
+  load(a0, b0, cb);
+  for (int c0 = cb; c0 < ce; c0 += 2 * BATCH) {
+    load(a1, b1, c0 + BATCH);
+    compute(a0, b0, c0);
+    load(a0, b0, c0 + 2 * BATCH);
+    compute(a1, b1, c0 + BATCH);
+  }
+  float* red = dred + (long)wave * (2 * RN * 256);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < RN; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(t * RN + c) * 256 + r * 64 + lane] = acc[t][c][r];
+  __syncthreads();
+  // element x = r*64 + l of tile (t, c): row 16 t + 4 (l >> 4) + r, column 16 c + (l & 15)
+  for (int e = tid; e < 2 * RN * 256; e += blockDim.x) {
+    const int tc = e >> 8, x = e & 255;
+    const int t = tc / RN, c = tc % RN;
+    const int r = x >> 6, l = x & 63;
+    const int row = m0 + 16 * t + 4 * (l >> 4) + r, col = n0 + 16 * c + (l & 15);
+    if (row < p.M && col < p.N) {
+      float v = 0.f;
+      for (int w = 0; w < nwaves; ++w) v += dred[(long)w * (2 * RN * 256) + e];
+      if (p.bias) v += p.bias[col];
+      float* o = p.C + (long)row * p.ldc + col;
+      if (p.accumulate) v += *o;
+      *o = v;
+    }
+  }
+}
+
+template <bool TB, int RN>
+static void launch_direct_rn(const GemmParams& p, int waves, hipStream_t s) {
+  const dim3 grid((p.N + 16 * RN - 1) / (16 * RN), 1, (p.M + 31) / 32), block(64 * waves);
+  const size_t sh = (size_t)waves * 2 * RN * 256 * sizeof(float);
+  hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 2>), grid, block, sh, s, p);
+}
+template <bool TB>
+static void launch_direct(const GemmParams& p, hipStream_t s) {
+  static const int env_waves = getenv("DV3_DIRECT_WAVES") ? atoi(getenv("DV3_DIRECT_WAVES")) : 0;
+  static const int env_rn = getenv("DV3_DIRECT_RN") ? atoi(getenv("DV3_DIRECT_RN")) : 0;
+  const int chunks = (p.K + 15) / 16;
+  // K over 8 waves while the grid is at most one workgroup per CU (1024 x 512 outputs), else 4 (measured)
+  const long wgs = (long)((p.N + 63) / 64) * ((p.M + 31) / 32);
+  int waves = (wgs <= 256 && chunks >= 16) ? 8 : 4;
+  if (env_waves == 4 || env_waves == 8) waves = env_waves;
+  int rn = 4;
+  if (env_rn == 2 || env_rn == 4 || env_rn == 8) rn = env_rn;
+  if (rn == 2) launch_direct_rn<TB, 2>(p, waves, s);
+  else if (rn == 8) launch_direct_rn<TB, 8>(p, waves, s);
+  else launch_direct_rn<TB, 4>(p, waves, s);
+}
+
 // Few-row product against an n-contiguous B (data gradients: dX = dY * W, W [K,N] row-major), K split over
 // workgroups, partial tiles added atomically (accumulate == 2 only).  The 16-column kernel above needs four
 // 4-byte loads per lane per chunk here (a lane's B operand is one column); this one gives a wave 64 columns
@@ -389,7 +561,7 @@ static int pick_tile(int M, int N, int K, int accumulate) {
   if (M <= 32) return 2;
   if (accumulate && K >= 4096 && (long)M * N >= 512L * 512) return 4;
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
-  if (t64 <= 512 && !accumulate) return t64 <= 128 ? 8 : 6;
+  if (t64 <= 512 && !accumulate) return t64 <= 128 ? 9 : 6;
   const long c128 = (((long)((M + 127) / 128) * ((N + 127) / 128)) + 255) / 256 * 4;
   const long c64 = (t64 + 255) / 256;
   return (c64 < c128) ? 1 : 4;
@@ -429,7 +601,8 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   }
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
-  int t = ((tile >= 0 && tile <= 6) || tile == 8) ? tile : pick_tile(M, N, K, accumulate);
+  int t = ((tile >= 0 && tile <= 6) || tile == 8 || tile == 9) ? tile : pick_tile(M, N, K, accumulate);
+  if (t == 9 && tile < 0 && (transA || (A2 && (K1 % 16) != 0))) t = 8;
   if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6 || t == 8)) t = 1;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
@@ -446,6 +619,13 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
       if (transB) launch_skinny<true, 2>(p, accumulate, s);
       else launch_skinny<false, 2>(p, accumulate, s);
     }
+    return (int)hipGetLastError();
+  }
+  if (t == 9) {
+    // register-direct kernel: A k-contiguous; segment edge on a 16-k chunk boundary
+    if (transA || (A2 && (K1 % 16) != 0)) return DV3_ERR_ARG;
+    if (transB) launch_direct<true>(p, s);
+    else launch_direct<false>(p, s);
     return (int)hipGetLastError();
   }
   if (t == 0) e = launch_ts<T128>(p, transA, transB, s);

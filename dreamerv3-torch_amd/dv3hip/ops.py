@@ -89,7 +89,7 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
 
 
 _TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2", 7: "narrowN",
-               8: "32x32x64s4"}
+               8: "32x32x64s4", 9: "direct32x64"}
 
 
 _TILE_TEMPLATES = {0: "2, 2, 2, 2, 16, 1", 1: "2, 2, 1, 1, 32, 1", 2: "1, 4, 1, 1, 32, 1", 4: "2, 2, 2, 2, 32, 1",
@@ -106,15 +106,21 @@ def kernel_symbol(key: str) -> str:
         ta, tb = ("true" if m.group(2) == "1" else "false"), ("true" if m.group(3) == "1" else "false")
         if tile in (3, 7):
             return f"void dv3::gemm_skinny_kernel<{tb if tile == 3 else 'true'}, 1>(dv3::GemmParams)"
+        if tile == 9:
+            return f"void dv3::gemm_direct_kernel<{tb}, 4, 2>(dv3::GemmParams)"
         return f"void dv3::gemm_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, {ta}, {tb}>(dv3::GemmParams)"
-    if key.startswith("conv_wgrad_kernel"):
-        return "void dv3::conv_wgrad_kernel<dv3::TileShape<2, 2, 1, 1, 32, 1> >(dv3::WgradParams)"
+    m = re.match(r"conv_wgrad_kernel<([^,>]+)(,c3)?>", key)
+    if m:
+        tile = {v: k for k, v in _TILE_NAMES.items()}[m.group(1)]
+        return (f"void dv3::conv_wgrad_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, "
+                f"{'true' if m.group(2) else 'false'}>(dv3::WgradParams)")
     return key
 
 
-# <= 512k outputs (1024 imagination rows x 512 columns): 32x32 tiles with K split over the four waves put two
-# workgroups on every CU; A/B inside one box: 22.17 vs 22.46 ms per update against the 32x64 tile (6)
-_SMALL_TILE = int(os.environ.get("DV3_SMALL_TILE", "8"))
+# <= 512k outputs (1024 imagination rows x 512 columns): the register-direct kernel (tile 9: no LDS staging,
+# 16x16x4 MFMA, 32 x 64 outputs per workgroup, K over its waves).  A/B inside one box, ms per update:
+# 32x64 LDS tile (6) 22.46, 32x32 LDS tile with K over the waves (8) 21.65, direct (9) 21.42.
+_SMALL_TILE = int(os.environ.get("DV3_SMALL_TILE", "9"))
 
 
 def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
@@ -177,6 +183,8 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
             tile = 3
         if tile in (6, 8) and A2 is not None and (K1 % 64) != 0:
             tile = 1
+        if tile == 9 and (transA or (A2 is not None and (K1 % 16) != 0)):
+            tile = 8 if not (A2 is not None and (K1 % 64) != 0) else 1
         if N <= 32 and M > 32 and not transA and transB and A2 is None:
             tile = 7
     _call("dv3_gemm_f32", int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(A2), lda2, K1, _ptr(B), ldb,
@@ -594,7 +602,8 @@ def conv_s2_wgrad(coarse, fine, dw):
         scratch = torch.zeros(dw.numel(), dtype=F32, device=dw.device)
         _WGRAD_SCRATCH[key] = scratch
     _call("dv3_conv_s2_wgrad", _ptr(coarse), _ptr(fine), _ptr(scratch), _ptr(dw), N, H, W, Cf, Cc, _stream(),
-          key="conv_wgrad_kernel" + (f"[N{N} {H}x{W} Cf{Cf} Cc{Cc}]" if PROFILE.by_shape else ""),
+          key=f"conv_wgrad_kernel<{'128x128x16' if Cc >= 128 else '32x64x64s2' if Cc <= 32 else '64x64x32'}"
+              f"{',c3' if Cf == 3 else ''}>" + (f"[N{N} {H}x{W} Cf{Cf} Cc{Cc}]" if PROFILE.by_shape else ""),
           flops=2.0 * N * (H // 2) * (W // 2) * 16 * Cf * Cc,
           nbytes=4.0 * (coarse.numel() + fine.numel() + dw.numel()))
     return dw

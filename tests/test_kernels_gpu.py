@@ -54,9 +54,9 @@ GEMM_SHAPES = [
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm_nt_bias(ops, M, N, K, tile):
-    if M * N * K > 5e9 and tile in (1, 2, 5, 6, 8):
+    if M * N * K > 5e9 and tile in (1, 2, 5, 6, 8, 9):
         pytest.skip("large shape: default tile only")
     if tile == 3 and M > 32:
         pytest.skip("skinny path is for M <= 32")
@@ -98,6 +98,25 @@ def test_gemm_few_rows_accumulate(ops, M, N, K, transB, mode):
     want = C0.clone()
     want[:, :N] += A @ (W.t() if transB else W) + b
     assert_close(C, want, what=f"gemm few rows accumulate={mode}")
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [(1024, 512, 1024, 6), (1024, 1536, 512, 512), (77, 45, 32, 3), (100, 130, 48, 0),
+                                       (33, 64, 16, 17), (1024, 512, 512, 0)])
+@pytest.mark.parametrize("transB", [True, False])
+@pytest.mark.parametrize("acc", [False, True])
+def test_gemm_register_direct_kernel(ops, M, N, K1, K2, transB, acc):
+    """tile 9 (no LDS staging, 16x16x4 MFMA, K over the waves): both B layouts, [A | A2] concat, bias,
+    accumulate, ragged M / N / K."""
+    g = torch.Generator().manual_seed(M + N + K1 + K2)
+    K = K1 + K2
+    A, A2 = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g)
+    W = torch.randn((N, K) if transB else (K, N), generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    C = dev(C0.clone())
+    ops.gemm(dev(A), dev(W), C, A2=dev(A2) if K2 else None, transB=transB, bias=dev(b), accumulate=acc, tile=9)
+    want = torch.cat([A, A2], -1) @ (W.t() if transB else W) + b + (C0 if acc else 0)
+    assert_close(C, want, what="gemm tile 9")
 
 
 @pytest.mark.parametrize("rows,Nout,Kin", [(1024, 512, 1030), (1024, 1536, 1024), (333, 70, 45), (14336, 255, 512)])
