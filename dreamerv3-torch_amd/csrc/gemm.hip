@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
 // 64 contiguous bytes per matrix row) and issues 8*RN v_mfma_f32_16x16x4_f32 -- each loaded fragment is used
 // RN (A) or 2 (B) times from registers, which is what the LDS staging of the tile engine buys at this size,
 // without its LDS write+read of every element and its barriers.  TB: B is [N][K] (else [K][N], scalar loads).
-// grid = (ceil(N / (16*RN)), 1, ceil(M / 32)); blockDim = 64 * waves (4 or 8).
+// grid = ceil(N / (16*RN)) * ceil(M / 32) workgroups (XCD-aware order, see below); blockDim = 64 * waves (4 or 8).
 // ------------------------------------------------------------------------------------------------
 template <bool TB, int RN, int BATCH>
 __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
@@ -229,7 +229,18 @@ __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nwaves = blockDim.x >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int n0 = blockIdx.x * (16 * RN), m0 = blockIdx.z * 32;
+  // 1-D grid of tiles_m x tiles_n workgroups.  Workgroups go to the 8 XCDs round-robin and each XCD's L2 pulls
+  // its own copy of every panel its workgroups touch, so an XCD is given whole ROW tiles (tiles_m / 8 of them, all
+  // column tiles): its A rows are private and only B is replicated, instead of every XCD streaming all of A.
+  int tm, tn;
+  {
+    const int id = blockIdx.x, tiles = p.tiles_m * p.tiles_n;
+    int lin = id;
+    if ((p.tiles_m & 7) == 0) lin = (id & 7) * (tiles >> 3) + (id >> 3);
+    tm = lin / p.tiles_n;
+    tn = lin % p.tiles_n;
+  }
+  const int n0 = tn * (16 * RN), m0 = tm * 32;
   const int chunks = (p.K + 15) >> 4;
   const int per = (chunks + nwaves - 1) / nwaves;
   const int cb = wave * per, ce = min(chunks, cb + per);
@@ -363,8 +374,11 @@ __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
 }
 
 template <bool TB, int RN>
-static void launch_direct_rn(const GemmParams& p, int waves, hipStream_t s) {
-  const dim3 grid((p.N + 16 * RN - 1) / (16 * RN), 1, (p.M + 31) / 32), block(64 * waves);
+static void launch_direct_rn(const GemmParams& p0, int waves, hipStream_t s) {
+  GemmParams p = p0;
+  p.tiles_n = (p.N + 16 * RN - 1) / (16 * RN);
+  p.tiles_m = (p.M + 31) / 32;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(64 * waves);
   const size_t sh = (size_t)waves * 2 * RN * 256 * sizeof(float);
   hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 2>), grid, block, sh, s, p);
 }
