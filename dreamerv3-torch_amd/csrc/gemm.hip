@@ -575,7 +575,7 @@ static int pick_tile(int M, int N, int K, int accumulate) {
   if (M <= 32) return 2;
   if (accumulate && K >= 4096 && (long)M * N >= 512L * 512) return 4;
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
-  if (t64 <= 512 && !accumulate) return t64 <= 128 ? 9 : 6;
+  if (t64 <= 512 && !accumulate) return 9;
   const long c128 = (((long)((M + 127) / 128) * ((N + 127) / 128)) + 255) / 256 * 4;
   const long c64 = (t64 + 255) / 256;
   return (c64 < c128) ? 1 : 4;
@@ -616,7 +616,7 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
   int t = ((tile >= 0 && tile <= 6) || tile == 8 || tile == 9) ? tile : pick_tile(M, N, K, accumulate);
-  if (t == 9 && tile < 0 && (transA || (A2 && (K1 % 16) != 0))) t = 8;
+  if (t == 9 && tile < 0 && (transA || (A2 && (K1 % 16) != 0))) t = ((long)M * N <= 512L * 1024) ? 8 : 6;
   if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6 || t == 8)) t = 1;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;

@@ -121,6 +121,9 @@ def kernel_symbol(key: str) -> str:
 # 16x16x4 MFMA, 32 x 64 outputs per workgroup, K over its waves).  A/B inside one box, ms per update:
 # 32x64 LDS tile (6) 22.46, 32x32 LDS tile with K over the waves (8) 21.65, direct (9) 21.42.
 _SMALL_TILE = int(os.environ.get("DV3_SMALL_TILE", "9"))
+# 512k .. 2M outputs (1024 rows x 1024 / 1536 columns): direct again (4 waves per workgroup), 45.8 vs 48.3 us on
+# the GRU matmul against the 32x64 LDS tile (6)
+_MID_TILE = int(os.environ.get("DV3_MID_TILE", "9"))
 
 
 def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
@@ -133,7 +136,7 @@ def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
         return 4  # long reductions are split over K anyway: take the tile with the best flops per L2 byte
     t64 = -(-M // 64) * -(-N // 64)
     if t64 <= 512 and not wgrad:  # weight gradients split K across workgroups instead (long reduction)
-        return _SMALL_TILE if t64 <= 128 else 6
+        return _SMALL_TILE if t64 <= 128 else _MID_TILE
     c128 = ((-(-M // 128) * -(-N // 128)) + 255) // 256 * 4
     c64 = (t64 + 255) // 256 * 1
     return 1 if c64 < c128 else 4
@@ -184,7 +187,7 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         if tile in (6, 8) and A2 is not None and (K1 % 64) != 0:
             tile = 1
         if tile == 9 and (transA or (A2 is not None and (K1 % 16) != 0)):
-            tile = 8 if not (A2 is not None and (K1 % 64) != 0) else 1
+            tile = (8 if M * N <= 512 * 1024 else 6) if not (A2 is not None and (K1 % 64) != 0) else 1
         if N <= 32 and M > 32 and not transA and transB and A2 is None:
             tile = 7
     _call("dv3_gemm_f32", int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(A2), lda2, K1, _ptr(B), ldb,
