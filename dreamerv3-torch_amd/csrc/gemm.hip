@@ -398,6 +398,122 @@ static void launch_direct(const GemmParams& p, hipStream_t s) {
   else launch_direct_rn<TB, 4>(p, waves, s);
 }
 
+// Register-direct weight gradient: C[M,N] += A^T B with A [K][M] and B [K][N] (both row-major over the batch
+// rows K): every fragment element is one 4-byte load (a lane's four k values sit in four different rows), 16
+// lanes per 64 contiguous bytes.  K is split over gridDim.y workgroups (atomic adds) and then over the waves.
+template <int RN, int BATCH>
+__global__ __launch_bounds__(256) void gemm_direct_tn_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float dred[];  // [waves][2][RN][256]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nwaves = blockDim.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+  const int n0 = tn * (16 * RN), m0 = tm * 32;
+  const int chunks = (p.K + 15) >> 4;
+  const int per_wg = (chunks + gridDim.y - 1) / gridDim.y;
+  const int wcb = blockIdx.y * per_wg, wce = min(chunks, wcb + per_wg);
+  const int per = (max(wce - wcb, 0) + nwaves - 1) / nwaves;
+  const int cb = wcb + wave * per, ce = min(wce, cb + per);
+  f32x4 acc[2][RN];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < RN; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* acol[2];
+  const float* bcol[RN];
+  float amask[2], bmask[RN];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int r = m0 + 16 * t + i;
+    amask[t] = r < p.M ? 1.f : 0.f;
+    acol[t] = p.A + (r < p.M ? r : 0);
+  }
+#pragma unroll
+  for (int c = 0; c < RN; ++c) {
+    const int n = n0 + 16 * c + i;
+    bmask[c] = n < p.N ? 1.f : 0.f;
+    bcol[c] = p.B + (n < p.N ? n : 0);
+  }
+  f32x4 a0[BATCH][2], b0[BATCH][RN], a1[BATCH][2], b1[BATCH][RN];
+  auto load = [&](f32x4 (&a)[BATCH][2], f32x4 (&b)[BATCH][RN], int c0) {
+    if (c0 >= ce) return;
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int k = (min(c0 + u, ce - 1) << 4) + 4 * q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kk = min(k + e, p.K - 1);  // rows past K are clamped here and zeroed through kmask below
+        const float kmask = (k + e < p.K) ? 1.f : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[u][t][e] = acol[t][(long)kk * p.lda] * kmask;
+#pragma unroll
+        for (int c = 0; c < RN; ++c) b[u][c][e] = bcol[c][(long)kk * p.ldb];
+      }
+    }
+  };
+  auto compute = [&](const f32x4 (&a)[BATCH][2], const f32x4 (&b)[BATCH][RN], int c0) {
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u)
+      if (c0 + u < ce) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float av = a[u][t][g] * amask[t];
+#pragma unroll
+            for (int c = 0; c < RN; ++c)
+              acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u][c][g] * bmask[c], acc[t][c], 0, 0, 0);
+          }
+      }
+  };
+  load(a0, b0, cb);
+  for (int c0 = cb; c0 < ce; c0 += 2 * BATCH) {
+    load(a1, b1, c0 + BATCH);
+    compute(a0, b0, c0);
+    load(a0, b0, c0 + 2 * BATCH);
+    compute(a1, b1, c0 + BATCH);
+  }
+  float* red = dred + (long)wave * (2 * RN * 256);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < RN; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(t * RN + c) * 256 + r * 64 + lane] = acc[t][c][r];
+  __syncthreads();
+  const bool split = gridDim.y > 1;
+  for (int e = tid; e < 2 * RN * 256; e += blockDim.x) {
+    const int tc = e >> 8, x = e & 255;
+    const int t = tc / RN, c = tc % RN;
+    const int r = x >> 6, l = x & 63;
+    const int row = m0 + 16 * t + 4 * (l >> 4) + r, col = n0 + 16 * c + (l & 15);
+    if (row < p.M && col < p.N) {
+      float v = 0.f;
+      for (int w = 0; w < nwaves; ++w) v += dred[(long)w * (2 * RN * 256) + e];
+      float* o = p.C + (long)row * p.ldc + col;
+      if (split) atomicAdd(o, v);
+      else *o = p.accumulate ? (*o + v) : v;
+    }
+  }
+}
+
+static void launch_direct_tn(const GemmParams& p0, hipStream_t s) {
+  constexpr int RN = 4, WAVES = 4;
+  GemmParams p = p0;
+  p.tiles_n = (p.N + 16 * RN - 1) / (16 * RN);
+  p.tiles_m = (p.M + 31) / 32;
+  const int tiles = p.tiles_m * p.tiles_n, chunks = (p.K + 15) / 16;
+  int splits = 1;
+  if (p.accumulate) {  // ~1k workgroups, every wave at least four 16-k chunks
+    splits = (1024 + tiles - 1) / tiles;
+    const int maxs = chunks / (4 * WAVES);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+  }
+  const size_t sh = (size_t)WAVES * 2 * RN * 256 * sizeof(float);
+  hipLaunchKernelGGL((gemm_direct_tn_kernel<RN, 2>), dim3(tiles, splits), dim3(64 * WAVES), sh, s, p);
+}
+
 // Few-row product against an n-contiguous B (data gradients: dX = dY * W, W [K,N] row-major), K split over
 // workgroups, partial tiles added atomically (accumulate == 2 only).  The 16-column kernel above needs four
 // 4-byte loads per lane per chunk here (a lane's B operand is one column); this one gives a wave 64 columns
@@ -573,7 +689,7 @@ using T32x128 = TileShape<1, 4, 1, 1, 32>;  // 32 x 128, BK 32 (few rows: the ob
 // Tile choice when the caller passes tile = -1 (the Python wrapper normally decides, same rule).
 static int pick_tile(int M, int N, int K, int accumulate) {
   if (M <= 32) return 2;
-  if (accumulate && K >= 4096 && (long)M * N >= 512L * 512) return 4;
+  if (accumulate && K >= 4096 && (long)M * N >= 512L * 1024) return 4;
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
   if (t64 <= 512 && !accumulate) return 9;
   const long c128 = (((long)((M + 127) / 128) * ((N + 127) / 128)) + 255) / 256 * 4;
@@ -615,7 +731,7 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   }
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
-  int t = ((tile >= 0 && tile <= 6) || tile == 8 || tile == 9) ? tile : pick_tile(M, N, K, accumulate);
+  int t = ((tile >= 0 && tile <= 6) || (tile >= 8 && tile <= 10)) ? tile : pick_tile(M, N, K, accumulate);
   if (t == 9 && tile < 0 && (transA || (A2 && (K1 % 16) != 0))) t = ((long)M * N <= 512L * 1024) ? 8 : 6;
   if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6 || t == 8)) t = 1;
   hipStream_t s = (hipStream_t)stream;
@@ -633,6 +749,12 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
       if (transB) launch_skinny<true, 2>(p, accumulate, s);
       else launch_skinny<false, 2>(p, accumulate, s);
     }
+    return (int)hipGetLastError();
+  }
+  if (t == 10) {
+    // register-direct weight gradient: A [K][M], B [K][N]
+    if (!transA || transB || A2 || bias) return DV3_ERR_ARG;
+    launch_direct_tn(p, s);
     return (int)hipGetLastError();
   }
   if (t == 9) {

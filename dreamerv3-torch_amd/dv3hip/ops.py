@@ -89,7 +89,7 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
 
 
 _TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2", 7: "narrowN",
-               8: "32x32x64s4", 9: "direct32x64"}
+               8: "32x32x64s4", 9: "direct32x64", 10: "directTN32x64"}
 
 
 _TILE_TEMPLATES = {0: "2, 2, 2, 2, 16, 1", 1: "2, 2, 1, 1, 32, 1", 2: "1, 4, 1, 1, 32, 1", 4: "2, 2, 2, 2, 32, 1",
@@ -108,6 +108,8 @@ def kernel_symbol(key: str) -> str:
             return f"void dv3::gemm_skinny_kernel<{tb if tile == 3 else 'true'}, 1>(dv3::GemmParams)"
         if tile == 9:
             return f"void dv3::gemm_direct_kernel<{tb}, 4, 2>(dv3::GemmParams)"
+        if tile == 10:
+            return "void dv3::gemm_direct_tn_kernel<4, 2>(dv3::GemmParams)"
         return f"void dv3::gemm_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, {ta}, {tb}>(dv3::GemmParams)"
     m = re.match(r"conv_wgrad_kernel<([^,>]+)(,c3)?>", key)
     if m:
@@ -132,8 +134,10 @@ def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
     x (MFMAs per wave per k-step) between 64x64 and 128x128."""
     if M <= 32:
         return 2
-    if wgrad and K >= 4096 and M * N >= 512 * 512:
-        return 4  # long reductions are split over K anyway: take the tile with the best flops per L2 byte
+    if wgrad:
+        # big outputs with a long reduction: the 128x128 LDS tile (best flops per L2 byte); everything else
+        # the register-direct weight-gradient kernel (K split over workgroups, atomics)
+        return 4 if (K >= 4096 and M * N >= 512 * 1024) else 10
     t64 = -(-M // 64) * -(-N // 64)
     if t64 <= 512 and not wgrad:  # weight gradients split K across workgroups instead (long reduction)
         return _SMALL_TILE if t64 <= 128 else _MID_TILE
@@ -188,6 +192,8 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
             tile = 1
         if tile == 9 and (transA or (A2 is not None and (K1 % 16) != 0)):
             tile = (8 if M * N <= 512 * 1024 else 6) if not (A2 is not None and (K1 % 64) != 0) else 1
+        if tile == 10 and (transB or A2 is not None or bias is not None):
+            tile = 1
         if N <= 32 and M > 32 and not transA and transB and A2 is None:
             tile = 7
     _call("dv3_gemm_f32", int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(A2), lda2, K1, _ptr(B), ldb,

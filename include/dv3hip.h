@@ -38,7 +38,8 @@ int dv3_version(void);
  *         (N <= 32, transA=0, transB=1, no A2: the skinny kernel on the transposed problem), 8 = 32x32x64 with
  *         K split over all four waves (two workgroups per CU when M*N is ~512k), 9 = register-direct (transA=0:
  *         32 x 64 outputs per workgroup, operands straight from global memory to 16x16x4 MFMA registers, K split
- *         over the waves; the default for <= 512k outputs).
+ *         over the waves; the default for <= 2M outputs), 10 = register-direct weight gradient (transA=1,
+ *         transB=0, no A2 / bias; K split over workgroups when accumulating).
  *   accumulate: 0 = overwrite C, 1 = C += product, 2 = C += product with the summation order left free: the
  *         skinny kernel then also splits K over workgroups and adds the partial tiles with atomics (fills the
  *         chip at M <= 32).  The tile kernels treat 1 and 2 alike (they split long-K accumulating products,

@@ -128,6 +128,12 @@ def test_gemm_tn_wgrad_accumulate(ops, rows, Nout, Kin):
     C = dev(C0.clone())
     ops.gemm(dev(dY), dev(X), C, transA=True, transB=False, accumulate=True)
     assert_close(C, C0 + dY.t() @ X, what="gemm_tn")
+    C = dev(C0.clone())  # register-direct weight-gradient kernel
+    ops.gemm(dev(dY), dev(X), C, transA=True, transB=False, accumulate=True, tile=10)
+    assert_close(C, C0 + dY.t() @ X, what="gemm_tn direct")
+    C = torch.full((Nout, Kin), float("nan")).cuda()
+    ops.gemm(dev(dY), dev(X), C, transA=True, transB=False, accumulate=False, tile=10)
+    assert_close(C, dY.t() @ X, what="gemm_tn direct, overwrite")
 
 
 @pytest.mark.parametrize("M,K1,K2,N", [(1024, 1024, 6, 512), (1024, 512, 512, 1536), (16, 512, 4096, 512),
