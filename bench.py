@@ -114,7 +114,7 @@ def phase_timers(wm, beh, data, H, t_upd_ms, reps=10):
         st = torch.cuda.Stream()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(st):
-            with torch.cuda.graph(g, stream=st):
+            with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
                 fn()
         g.replay()
         torch.cuda.synchronize()
@@ -310,7 +310,7 @@ def main():
                                    "one step = full Dreamer._train update (world model + actor + critic fwd/bwd, "
                                    "gradient all-reduce, 3x clip+Adam)",
                        "global_batch": B * world, "seq_len": T, "horizon": H, "parallelism": f"dp{world}",
-                       "launch": "eager" if args.no_graph else "hipGraph replay"},
+                       "launch": "hipGraph replay" if (runner.use_graph and not args.no_graph) else "eager"},
             "model_loss": loss, "timers": timers,
             "roofline": roofline, "cpu_baseline": cpu,
         }

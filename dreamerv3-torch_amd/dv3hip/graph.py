@@ -45,15 +45,18 @@ class UpdateRunner:
         wm, beh = self.wm, self.beh
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g1, pool=pool):
+        # thread_local: with a process group alive, RCCL's watchdog thread polls events while we capture; the
+        # default (global) mode would treat that as a capture violation
+        mode = dict(capture_error_mode="thread_local")
+        with torch.cuda.graph(g1, pool=pool, **mode):
             wm.train_fwd_bwd(self._static)
         wm._model_opt.bucket.allreduce()
-        with torch.cuda.graph(g2, pool=pool):
+        with torch.cuda.graph(g2, pool=pool, **mode):
             post, _, m1 = wm.train_opt(allreduce=False)
             beh.train_fwd_bwd(post)
         beh._actor_opt.bucket.allreduce()
         beh._value_opt.bucket.allreduce()
-        with torch.cuda.graph(g3, pool=pool):
+        with torch.cuda.graph(g3, pool=pool, **mode):
             m2 = beh.train_opt(allreduce=False)[-1]
         self._graphs = (g1, g2, g3)
         self.last_metrics = {**m1, **m2}
@@ -67,7 +70,17 @@ class UpdateRunner:
         self._load(data)
         if self._graphs is None:
             torch.cuda.synchronize()
-            self._capture()  # records only: nothing has executed yet, so fall through and replay
+            try:
+                self._capture()  # records only: nothing has executed yet, so fall through and replay
+            except Exception as e:  # e.g. a runtime that refuses capture: keep training, launch eagerly
+                import sys
+
+                print(f"[dv3hip] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
+                      file=sys.stderr)
+                self.use_graph, self._graphs = False, None
+                torch.cuda.synchronize()
+                self._eager(data)
+                return
         g1, g2, g3 = self._graphs
         g1.replay()
         self.wm._model_opt.bucket.allreduce()
