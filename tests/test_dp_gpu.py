@@ -1,0 +1,74 @@
+"""Data parallel on the GPU: two ranks (gloo; both on cuda:0 -- a one-GPU box, same code path as
+RCCL) train on half of a global batch each; the world-model update they reach must equal the single-process
+update on the whole batch: the loss is a mean over rows, so the SUM all-reduce of the flat gradient bucket with the
+1/world scale folded into clip+Adam is the gradient of the global batch, and clipping sees the global norm.
+(The behaviour update is only checked for replica consistency: its return normalisation uses per-rank quantiles,
+as the reference's would.)"""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as Hh
+from tests.golden import common
+
+pytestmark = pytest.mark.gpu
+NAME = "tiny"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_inputs(rank):
+    """Batch and observe noise of one rank: the tiny batch / noise with seed = rank."""
+    return common.make_batch(NAME, seed=rank), common.make_noise(NAME, seed=rank)
+
+
+def _worker(rank, world, port, outdir):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, wm, beh = Hh.build_models(NAME)  # identical replica
+        batch, noise = _rank_inputs(rank)
+        nz = {k: torch.from_numpy(v).cuda() for k, v in noise.items()}
+        post, _, mets = wm._train(batch, noise=dict(q_prior=nz["q_prior"], q_post=nz["q_post"]))
+        wm_params = torch.cat([p.detach().reshape(-1) for p in wm.parameters()]).cpu()
+        beh._train(post, None)
+        beh_params = torch.cat([p.detach().reshape(-1) for p in list(beh.actor.parameters()) + list(beh.value.parameters())]).cpu()
+        torch.save({"wm": wm_params, "beh": beh_params, "grad_norm": float(mets["model_grad_norm"]),
+                    "loss": float(mets["model_loss"])}, os.path.join(outdir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_on_the_global_batch():
+    import torch.multiprocessing as mp
+
+    world = 2
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_worker, args=(world, _free_port(), outdir), nprocs=world, join=True)
+        r0 = torch.load(os.path.join(outdir, "rank0.pt"), weights_only=True)
+        r1 = torch.load(os.path.join(outdir, "rank1.pt"), weights_only=True)
+    # replicas stay in sync (same all-reduced gradient, same optimizer state)
+    assert torch.allclose(r0["wm"], r1["wm"], rtol=0, atol=1e-7)
+    assert torch.allclose(r0["beh"], r1["beh"], rtol=0, atol=1e-7)
+    assert r0["grad_norm"] == pytest.approx(r1["grad_norm"], rel=1e-6)  # the norm of the GLOBAL gradient on both
+    # single process, global batch = the two rank batches side by side (batch axis 0; noise [T, B, ...] axis 1)
+    (b0, n0), (b1, n1) = _rank_inputs(0), _rank_inputs(1)
+    batch = {k: np.concatenate([b0[k], b1[k]], 0) for k in b0}
+    noise = {k: torch.from_numpy(np.concatenate([n0[k], n1[k]], 1)).cuda() for k in ("q_prior", "q_post")}
+    _, wm, _ = Hh.build_models(NAME)
+    _, _, mets = wm._train(batch, noise=noise)
+    single = torch.cat([p.detach().reshape(-1) for p in wm.parameters()]).cpu()
+    assert float(mets["model_loss"]) == pytest.approx(0.5 * (r0["loss"] + r1["loss"]), rel=1e-5)
+    assert float(mets["model_grad_norm"]) == pytest.approx(r0["grad_norm"], rel=1e-4)
+    assert torch.allclose(single, r0["wm"], rtol=0, atol=2e-6)
