@@ -27,7 +27,10 @@ __global__ __launch_bounds__(256) void onehot_sample_kernel(const float* __restr
                                                             const unsigned long long* __restrict__ rng_state,
                                                             float* __restrict__ out, int* __restrict__ idx_out,
                                                             long R, int D, float unimix, int mode,
-                                                            unsigned long long offset_add) {
+                                                            unsigned long long offset_add,
+                                                            const float* __restrict__ nb_first,
+                                                            const float* __restrict__ nb_init,
+                                                            float* __restrict__ nb_out, int nb_groups) {
   constexpr int GPB = 256 / G;
   const int sub = threadIdx.x / G, d = threadIdx.x % G;
   const bool valid = d < D;
@@ -70,7 +73,14 @@ __global__ __launch_bounds__(256) void onehot_sample_kernel(const float* __restr
         bi = oi;
       }
     }
-    if (rv && valid) out[r * D + d] = (d == bi) ? 1.f : 0.f;
+    if (rv && valid) {
+      const float v = (d == bi) ? 1.f : 0.f;
+      out[r * D + d] = v;
+      if (nb_out) {  // next observe step's reset blend of this sample: row b = r / groups, init [groups][D]
+        const float m = nb_first[r / nb_groups];
+        nb_out[r * D + d] = v * (1.f - m) + nb_init[(r % nb_groups) * D + d] * m;
+      }
+    }
     if (rv && d == 0 && idx_out) idx_out[r] = bi;
   }
 }
@@ -272,7 +282,25 @@ extern "C" int dv3_onehot_sample_fwd(const float* logit, const float* noise, con
   if (!mode && !noise && !rng_state) return DV3_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_sample_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
-                                       logit, noise, rng_state, onehot, idx, R, D, unimix, mode, rng_offset));
+                                       logit, noise, rng_state, onehot, idx, R, D, unimix, mode, rng_offset, nullptr,
+                                       nullptr, nullptr, 1));
+  return (int)hipGetLastError();
+}
+
+// as dv3_onehot_sample_fwd, plus next_out[r][d] = onehot*(1 - next_first[r / groups]) + init[r % groups][d] *
+// next_first[...]: the following observe step's reset blend of the sampled state (networks.py:183-191)
+extern "C" int dv3_onehot_sample_fwd_blend(const float* logit, const float* noise, const unsigned long long* rng_state,
+                                           unsigned long long rng_offset, float* onehot, long R, int D, float unimix,
+                                           int mode, const float* next_first, const float* init, float* next_out,
+                                           int groups, void* stream) {
+  if (R <= 0) return 0;
+  if (D <= 0 || D > 64 || !logit || !onehot || !next_first || !init || !next_out || groups <= 0 || R % groups)
+    return DV3_ERR_ARG;
+  if (!mode && !noise && !rng_state) return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_sample_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
+                                       logit, noise, rng_state, onehot, (int*)nullptr, R, D, unimix, mode, rng_offset,
+                                       next_first, init, next_out, groups));
   return (int)hipGetLastError();
 }
 

@@ -552,6 +552,15 @@ __global__ __launch_bounds__(256) void ln_act_bwd_vec_kernel(const float* __rest
   }
 }
 
+// Optional second output of the kernels that finish a state of the observe scan: the NEXT step's input after its
+// reset blend, out[r] = v*(1 - first[r]) + init*first[r] (init = the learned initial state, one row).
+struct NextBlend {
+  const float* first;  // [rows] is_first of the next step
+  const float* init;   // [cols]
+  float* out;          // nullptr = no second output
+  long ld;
+};
+
 // GRU gates, vectorised: De % 256 == 0, NVG = De/256 float4 chunks per gate per lane.  Lane l owns chunks
 // l + 64*v of each gate, so r, c, u of one hidden unit sit in the same lane.  One wave per row, whole row
 // of p (3*De floats) in registers, single pass.
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(256) void gru_fwd_vec_kernel(const float* __restric
                                                           const float* __restrict__ beta, const float* __restrict__ h,
                                                           long ldh, float* __restrict__ hn, long ldhn,
                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                          int M, int De) {
+                                                          int M, int De, NextBlend nb) {
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const float inv_n = 1.f / (float)(3 * De);
   for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
@@ -601,6 +610,10 @@ __global__ __launch_bounds__(256) void gru_fwd_vec_kernel(const float* __restric
         o[e] = ug * cg + (1.f - ug) * hp[e];
       }
       *reinterpret_cast<f4u*>(hn + (long)r * ldhn + j) = o;
+      if (nb.out) {  // the next observe step's reset blend of this state (networks.py:183-191), fused here
+        const float m = nb.first[r];
+        *reinterpret_cast<f4u*>(nb.out + (long)r * nb.ld + j) = o * (1.f - m) + *reinterpret_cast<const f4u*>(nb.init + j) * m;
+      }
     }
     if (l == 0) {
       mean_out[r] = mean;
@@ -843,18 +856,36 @@ extern "C" int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long l
   return (int)hipGetLastError();
 }
 
+static int gru_fwd_impl(const float* p, long ldp, const float* gamma, const float* beta, const float* h, long ldh,
+                        float* h_new, long ldhn, float* mean, float* rstd, int M, int De, NextBlend nb, void* stream);
+
 extern "C" int dv3_gru_fwd(const float* p, long ldp, const float* gamma, const float* beta, const float* h, long ldh,
                            float* h_new, long ldhn, float* mean, float* rstd, int M, int De, void* stream) {
+  return gru_fwd_impl(p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De, NextBlend{nullptr, nullptr, nullptr, 0},
+                      stream);
+}
+
+extern "C" int dv3_gru_fwd_blend(const float* p, long ldp, const float* gamma, const float* beta, const float* h,
+                                 long ldh, float* h_new, long ldhn, float* mean, float* rstd, int M, int De,
+                                 const float* next_first, const float* init, float* next_out, long ld_next,
+                                 void* stream) {
+  if (!next_first || !init || !next_out || ld_next < De || De % 256 != 0 || De > 1024) return DV3_ERR_ARG;
+  return gru_fwd_impl(p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De,
+                      NextBlend{next_first, init, next_out, ld_next}, stream);
+}
+
+static int gru_fwd_impl(const float* p, long ldp, const float* gamma, const float* beta, const float* h, long ldh,
+                        float* h_new, long ldhn, float* mean, float* rstd, int M, int De, NextBlend nb, void* stream) {
   if (M <= 0) return 0;
   if (De <= 0 || !p || !gamma || !beta || !h || !h_new || !mean || !rstd) return DV3_ERR_ARG;
   int blocks = (M + 3) / 4;
   if (blocks > 4096) blocks = 4096;
   if (De % 256 == 0 && De <= 1024) {
     hipStream_t s = (hipStream_t)stream;
-    if (De == 256) hipLaunchKernelGGL((gru_fwd_vec_kernel<1>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De);
-    else if (De == 512) hipLaunchKernelGGL((gru_fwd_vec_kernel<2>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De);
-    else if (De == 768) hipLaunchKernelGGL((gru_fwd_vec_kernel<3>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De);
-    else hipLaunchKernelGGL((gru_fwd_vec_kernel<4>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De);
+    if (De == 256) hipLaunchKernelGGL((gru_fwd_vec_kernel<1>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De, nb);
+    else if (De == 512) hipLaunchKernelGGL((gru_fwd_vec_kernel<2>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De, nb);
+    else if (De == 768) hipLaunchKernelGGL((gru_fwd_vec_kernel<3>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De, nb);
+    else hipLaunchKernelGGL((gru_fwd_vec_kernel<4>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De, nb);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(gru_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, ldp, gamma, beta, h, ldh,

@@ -20,6 +20,8 @@ Parameter containers hold torch.nn.Parameters whose .grad are views into a flat 
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -28,6 +30,9 @@ import torch
 from . import ops
 
 F32 = torch.float32
+
+
+_FUSE_BLEND = os.environ.get("DV3_FUSE_BLEND", "1") != "0"  # development switch (A/B runs)
 
 
 class SideStream:
@@ -324,19 +329,27 @@ class RSSMEngine:
         post_logit, post_stoch = g("obs.post_logit", (T, B, S, D)), g("obs.post_stoch", (T, B, S, D))
         # embed half of obs_out for all steps at once: x3pre = embed @ W_obs[:, De:]^T
         ops.gemm(v2(embed_tm, E), P.obs_out.W[:, De:], v2(x3pre, Hd))
+        # Reset blends (networks.py:183-191) off the per-step critical path: the action blend needs no state (one
+        # launch for all T), step 0 starts from the initial state, and the blend of step t+1's stoch / deter is a
+        # second output of the kernels that produce them at step t (fused when the vector GRU kernel applies).
+        ops.reset_blend(v2(action_tm, A), None, first.view(TB), v2(ain, A))
+        fuse = De % 256 == 0 and De <= 1024 and _FUSE_BLEND
         for t in range(T):
-            ft = first[t]
-            prev_s = post_stoch[t - 1].view(B, SD) if t > 0 else None
-            prev_d = deter[t - 1] if t > 0 else None
-            ops.obs_blend(prev_s, s0.view(SD), prev_d, d0.view(De), action_tm[t], ft, sin[t], din[t], ain[t])
+            if t == 0 or not fuse:
+                prev_s = post_stoch[t - 1].view(B, SD) if t > 0 else None
+                prev_d = deter[t - 1] if t > 0 else None
+                ops.obs_blend(prev_s, s0.view(SD), prev_d, d0.view(De), action_tm[t], first[t], sin[t], din[t], ain[t])
+            nxt = fuse and t + 1 < T
             dense_ln_fwd(P.img_in, sin[t], ain[t], x1pre[t], m1[t], r1[t], x1[t])
             ops.gemm(x1[t], P.gru.W, gpre[t], A2=din[t])
-            ops.gru_fwd(gpre[t], P.gru.g, P.gru.b, din[t], deter[t], mg[t], rg[t])
+            ops.gru_fwd(gpre[t], P.gru.g, P.gru.b, din[t], deter[t], mg[t], rg[t],
+                        next_blend=(first[t + 1], d0.view(De), din[t + 1]) if nxt else None)
             ops.gemm(deter[t], P.obs_out.W[:, :De], x3pre[t], accumulate=True)
             ops.ln_act_fwd(x3pre[t], P.obs_out.g, P.obs_out.b, x3[t], m3[t], r3[t], act=True)
             ops.gemm(x3[t], P.obs.W, post_logit[t].view(B, SD), bias=P.obs.b)
             ops.onehot_sample(post_logit[t], post_stoch[t], noise=None if q_post is None else q_post[t], rng=rng,
-                              unimix=self.unimix)
+                              unimix=self.unimix,
+                              next_blend=(first[t + 1], s0.view(SD), sin[t + 1].view(B, S, D)) if nxt else None)
         # prior head for all steps at once
         x2pre, x2 = g("obs.x2pre", (T, B, Hd)), g("obs.x2", (T, B, Hd))
         m2, r2 = g("obs.m2", (T, B)), g("obs.r2", (T, B))

@@ -260,7 +260,9 @@ def ln_act_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma=None, dbeta=None, *, a
     return dx
 
 
-def gru_fwd(p, gamma, beta, h, h_new, mean, rstd):
+def gru_fwd(p, gamma, beta, h, h_new, mean, rstd, *, next_blend=None):
+    """next_blend = (next_first [M], init [De], next_out [M,De]): also write the next observe step's reset blend of
+    h_new (fused second output)."""
     M, N3, ldp = _rows2d(p, "p")
     Mh, De, ldh = _rows2d(h, "h")
     Mn, Dn, ldhn = _rows2d(h_new, "h_new")
@@ -269,6 +271,15 @@ def gru_fwd(p, gamma, beta, h, h_new, mean, rstd):
     _contig(gamma, "gamma"), _contig(beta, "beta"), _contig(mean, "mean"), _contig(rstd, "rstd")
     if gamma.numel() != N3 or beta.numel() != N3 or mean.numel() != M or rstd.numel() != M:
         raise ValueError("gru param sizes mismatch")
+    if next_blend is not None:
+        nf, init, nout = next_blend
+        _contig(nf, "next_first"), _contig(init, "init")
+        Mo, Do, ldo = _rows2d(nout, "next_out")
+        if nf.numel() != M or init.numel() != De or (Mo, Do) != (M, De):
+            raise ValueError("next_blend shapes mismatch")
+        _call("dv3_gru_fwd_blend", _ptr(p), ldp, _ptr(gamma), _ptr(beta), _ptr(h), ldh, _ptr(h_new), ldhn, _ptr(mean),
+              _ptr(rstd), M, De, _ptr(nf), _ptr(init), _ptr(nout), ldo, _stream(), key="dv3_gru_fwd")
+        return h_new
     _call("dv3_gru_fwd", _ptr(p), ldp, _ptr(gamma), _ptr(beta), _ptr(h), ldh, _ptr(h_new), ldhn, _ptr(mean),
           _ptr(rstd), M, De, _stream())
     return h_new
@@ -327,7 +338,9 @@ class RngStream:
         self.cursor = 0
 
 
-def onehot_sample(logit, out, *, noise=None, rng=None, idx=None, unimix=0.01, mode=False):
+def onehot_sample(logit, out, *, noise=None, rng=None, idx=None, unimix=0.01, mode=False, next_blend=None):
+    """next_blend = (next_first [B], init [S*D], next_out [B,S,D]) for logit [B,S,D]: also write the next observe
+    step's reset blend of the sample (fused second output)."""
     D = logit.shape[-1]
     R = _groups(logit, "logit", D)
     if _groups(out, "out", D) != R:
@@ -343,6 +356,15 @@ def onehot_sample(logit, out, *, noise=None, rng=None, idx=None, unimix=0.01, mo
         _contig(idx, "idx", torch.int32)
         if idx.numel() != R:
             raise ValueError("idx size mismatch")
+    if next_blend is not None:
+        nf, init, nout = next_blend
+        _contig(nf, "next_first"), _contig(init, "init"), _contig(nout, "next_out")
+        if idx is not None or R % nf.numel() or init.numel() * nf.numel() != R * D or nout.numel() != R * D:
+            raise ValueError("next_blend shapes mismatch")
+        _call("dv3_onehot_sample_fwd_blend", _ptr(logit), _ptr(noise), _ptr(rng_state), int(rng_off), _ptr(out), R, D,
+              float(unimix), int(mode), _ptr(nf), _ptr(init), _ptr(nout), R // nf.numel(), _stream(),
+              key="dv3_onehot_sample_fwd")
+        return out
     _call("dv3_onehot_sample_fwd", _ptr(logit), _ptr(noise), _ptr(rng_state), int(rng_off), _ptr(out), _ptr(idx), R,
           D, float(unimix), int(mode), _stream())
     return out

@@ -69,6 +69,11 @@ int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const f
  * r=sigmoid, c=tanh(r*c), u=sigmoid(u-1), h' = u*c + (1-u)*h.   De <= 2048 for the backward. */
 int dv3_gru_fwd(const float* p, long ldp, const float* gamma, const float* beta, const float* h, long ldh,
                 float* h_new, long ldhn, float* mean, float* rstd, int M, int De, void* stream);
+/* dv3_gru_fwd plus the NEXT observe step's reset blend of the new state (networks.py:183-191), fused:
+ * next_out[r] = h_new[r]*(1 - next_first[r]) + init*next_first[r].  De % 256 == 0, De <= 1024. */
+int dv3_gru_fwd_blend(const float* p, long ldp, const float* gamma, const float* beta, const float* h, long ldh,
+                      float* h_new, long ldhn, float* mean, float* rstd, int M, int De, const float* next_first,
+                      const float* init, float* next_out, long ld_next, void* stream);
 int dv3_gru_bwd(const float* dh_new, long lddhn, const float* p, long ldp, const float* gamma, const float* beta,
                 const float* h, long ldh, const float* mean, const float* rstd, float* dp, long lddp, float* dh,
                 long lddh, float* dgamma, float* dbeta, int M, int De, int accumulate_dh, void* stream);
@@ -82,6 +87,12 @@ int dv3_gru_bwd(const float* dh_new, long lddhn, const float* p, long ldp, const
 int dv3_onehot_sample_fwd(const float* logit, const float* noise, const unsigned long long* rng_state,
                           unsigned long long rng_offset, float* onehot, int* idx, long R, int D, float unimix,
                           int mode, void* stream);
+int dv3_onehot_sample_fwd_blend(const float* logit, const float* noise, const unsigned long long* rng_state,
+                                unsigned long long rng_offset, float* onehot, long R, int D, float unimix, int mode,
+                                const float* next_first, const float* init, float* next_out, int groups,
+                                void* stream);
+/* ... plus next_out[r][d] = onehot*(1 - f) + init[r % groups][d]*f, f = next_first[r / groups]: the next observe
+ * step's reset blend of the sampled state, fused (groups = stoch groups per batch row). */
 /* rng_offset is added to rng_state's offset for this call (R*D/4+1 counters are consumed): the caller lays
  * the calls of one update out on disjoint counter ranges and advances rng_state once, so the launch
  * sequence stays static under hipGraph replay. */

@@ -685,3 +685,32 @@ def test_three_channel_image_layers(ops, CW):
     dx = torch.empty(N, 32, 32, CW).cuda()
     ops.conv_s2_c3_fwd(dev(nhwc(dy)), dev(wt), dx, CW=CW)
     assert_close(dx, nhwc(xi2.grad), what="convT c3 dgrad")
+
+
+def test_fused_next_step_reset_blend_outputs(ops):
+    """gru_fwd / onehot_sample with next_blend: the second output equals a separate reset blend of the first."""
+    g = torch.Generator().manual_seed(5)
+    M, De, S, D = 16, 512, 32, 32
+    p = torch.randn(M, 3 * De, generator=g)
+    h = torch.randn(M, De, generator=g)
+    gamma, beta = torch.rand(3 * De, generator=g) + 0.5, torch.randn(3 * De, generator=g) * 0.1
+    first = (torch.rand(M, generator=g) < 0.3).float()
+    init_d = torch.randn(De, generator=g)
+    hn, mean, rstd = torch.empty(M, De).cuda(), torch.empty(M).cuda(), torch.empty(M).cuda()
+    nxt = torch.full((M, De + 8), float("nan")).cuda()  # row-strided destination
+    ops.gru_fwd(dev(p), dev(gamma), dev(beta), dev(h), hn, mean, rstd, next_blend=(dev(first), dev(init_d), nxt[:, :De]))
+    hn2 = torch.empty(M, De).cuda()
+    ops.gru_fwd(dev(p), dev(gamma), dev(beta), dev(h), hn2, mean, rstd)
+    assert torch.equal(hn, hn2)
+    want = hn.cpu() * (1 - first[:, None]) + init_d[None] * first[:, None]
+    assert_close(nxt[:, :De], want, what="gru next blend")
+    logit = torch.randn(M, S, D, generator=g)
+    q = torch.empty(M, S, D).exponential_(1.0, generator=g).clamp_min(1e-20)
+    init_s = torch.randn(S * D, generator=g)
+    st, nxt_s = torch.empty(M, S, D).cuda(), torch.empty(M, S, D).cuda()
+    ops.onehot_sample(dev(logit), st, noise=dev(q), next_blend=(dev(first), dev(init_s), nxt_s))
+    st2 = torch.empty(M, S, D).cuda()
+    ops.onehot_sample(dev(logit), st2, noise=dev(q))
+    assert torch.equal(st, st2)
+    want = st.cpu() * (1 - first[:, None, None]) + init_s.view(1, S, D) * first[:, None, None]
+    assert_close(nxt_s, want, what="sample next blend")
