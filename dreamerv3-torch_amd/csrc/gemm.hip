@@ -380,16 +380,20 @@ static void launch_direct_rn(const GemmParams& p0, int waves, hipStream_t s) {
   p.tiles_m = (p.M + 31) / 32;
   const dim3 grid(p.tiles_m * p.tiles_n), block(64 * waves);
   const size_t sh = (size_t)waves * 2 * RN * 256 * sizeof(float);
-  hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 2>), grid, block, sh, s, p);
+  // one chunk of lookahead (BATCH 1) measured best: ~100 VGPRs keep 4 waves per SIMD resident, which hides more
+  // latency than deeper register prefetch at 170-230 VGPRs (DV3_DIRECT_BATCH: development switch)
+  static const int env_batch = getenv("DV3_DIRECT_BATCH") ? atoi(getenv("DV3_DIRECT_BATCH")) : 0;
+  if (env_batch == 2) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 2>), grid, block, sh, s, p);
+  else if (env_batch == 3) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 3>), grid, block, sh, s, p);
+  else hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 1>), grid, block, sh, s, p);
 }
 template <bool TB>
 static void launch_direct(const GemmParams& p, hipStream_t s) {
   static const int env_waves = getenv("DV3_DIRECT_WAVES") ? atoi(getenv("DV3_DIRECT_WAVES")) : 0;
   static const int env_rn = getenv("DV3_DIRECT_RN") ? atoi(getenv("DV3_DIRECT_RN")) : 0;
   const int chunks = (p.K + 15) / 16;
-  // K over 8 waves while the grid is at most one workgroup per CU (1024 x 512 outputs), else 4 (measured)
-  const long wgs = (long)((p.N + 63) / 64) * ((p.M + 31) / 32);
-  int waves = (wgs <= 256 && chunks >= 16) ? 8 : 4;
+  // K over 8 waves once every wave still gets four 16-k chunks (measured: never worse than 4, better at N = 512..1024)
+  int waves = chunks >= 32 ? 8 : 4;
   if (env_waves == 4 || env_waves == 8) waves = env_waves;
   int rn = 4;
   if (env_rn == 2 || env_rn == 4 || env_rn == 8) rn = env_rn;
