@@ -515,7 +515,9 @@ static void launch_direct_tn(const GemmParams& p0, hipStream_t s) {
     if (splits < 1) splits = 1;
   }
   const size_t sh = (size_t)WAVES * 2 * RN * 256 * sizeof(float);
-  hipLaunchKernelGGL((gemm_direct_tn_kernel<RN, 2>), dim3(tiles, splits), dim3(64 * WAVES), sh, s, p);
+  static const int env_batch = getenv("DV3_DIRECT_BATCH") ? atoi(getenv("DV3_DIRECT_BATCH")) : 0;
+  if (env_batch == 2) hipLaunchKernelGGL((gemm_direct_tn_kernel<RN, 2>), dim3(tiles, splits), dim3(64 * WAVES), sh, s, p);
+  else hipLaunchKernelGGL((gemm_direct_tn_kernel<RN, 1>), dim3(tiles, splits), dim3(64 * WAVES), sh, s, p);
 }
 
 // Few-row product against an n-contiguous B (data gradients: dX = dY * W, W [K,N] row-major), K split over

@@ -107,9 +107,9 @@ def kernel_symbol(key: str) -> str:
         if tile in (3, 7):
             return f"void dv3::gemm_skinny_kernel<{tb if tile == 3 else 'true'}, 1>(dv3::GemmParams)"
         if tile == 9:
-            return f"void dv3::gemm_direct_kernel<{tb}, 4, 2>(dv3::GemmParams)"
+            return f"void dv3::gemm_direct_kernel<{tb}, 4, 1>(dv3::GemmParams)"
         if tile == 10:
-            return "void dv3::gemm_direct_tn_kernel<4, 2>(dv3::GemmParams)"
+            return "void dv3::gemm_direct_tn_kernel<4, 1>(dv3::GemmParams)"
         return f"void dv3::gemm_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, {ta}, {tb}>(dv3::GemmParams)"
     m = re.match(r"conv_wgrad_kernel<([^,>]+)(,c3)?>", key)
     if m:
