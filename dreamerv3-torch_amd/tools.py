@@ -506,6 +506,27 @@ def from_generator(generator, batch_size):
         yield data
 
 
+class TimeRecording:  # tools.py:41-53
+    """`with TimeRecording("label"):` -- HIP-event timer around a region of the current stream; prints the label
+    and the elapsed seconds on exit (and keeps them in .seconds)."""
+
+    def __init__(self, comment):
+        self._comment = comment
+        self.seconds = None
+
+    def __enter__(self):
+        self._start = torch.cuda.Event(enable_timing=True)
+        self._stop = torch.cuda.Event(enable_timing=True)
+        self._start.record()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.record()
+        self._stop.synchronize()
+        self.seconds = self._start.elapsed_time(self._stop) / 1000
+        print(self._comment, self.seconds)
+
+
 class Every:  # tools.py:853-868
     def __init__(self, every):
         self._every, self._last = every, None
