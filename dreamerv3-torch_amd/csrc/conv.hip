@@ -12,6 +12,8 @@
 //                [out|in][in|out][4][4] layout)
 // A Conv2d weight [Co][Ci][4][4] read as a ConvTranspose2d weight [in=Co][out=Ci][4][4] is its
 // adjoint, so the same packed images serve forward and backward.
+#include <stdlib.h>
+
 #include "mfma_gemm.h"
 #include "dv3_common.h"
 
@@ -425,6 +427,212 @@ __global__ __launch_bounds__(kThreads) void convT_s2_kernel(ConvParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Narrow transposed convolution (Co <= 32: the decoder layer in front of the image layer, and the encoder's
+// second layer read backwards), register-direct: on the 128x32 LDS tile every gathered A element is staged in LDS
+// to be read exactly once (46 TF/s).  Here a WAVE owns 32 rows (input pixels of one parity class) x 32 output
+// channels over the whole K = 4*Ci: per 16-k chunk two 16-byte gathers (one per 16-row tile) and two 16-byte
+// weight loads (32 KB of weights per class, cache resident) feed 16 v_mfma_f32_16x16x4_f32; no LDS, no barriers,
+// ~80 registers, so many waves per SIMD hide the gather latency.  Ci % 4 == 0.
+// grid = (ceil(M / 128), 4 parity classes), 4 waves per workgroup (4 consecutive 32-row groups).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+template <int RN>  // 16*RN output channels per wave
+__global__ __launch_bounds__(256) void convT_s2_direct_kernel(ConvParams p) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int cls = blockIdx.y, py = cls >> 1, px = cls & 1;
+  const long M = (long)p.Nimg * p.H * p.W;
+  const int K = 4 * p.Ci;
+  const long row0 = (long)blockIdx.x * 128 + wave * 32;
+  if (row0 >= M) return;
+  const FastDiv dW = FastDiv::make(p.W), dH = FastDiv::make(p.H), dC = FastDiv::make(p.Ci);
+  // the two rows (input pixels) this lane gathers for: row0 + 16 t + i
+  long base[2];
+  int y0[2], x0[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const long r = row0 + 16 * t + i;
+    const long rc = r < M ? r : 0;
+    const int x2 = dW.rem(rc);
+    const long tq = dW.quot(rc);
+    const int y2 = dH.rem(tq);
+    const long n = dH.quot(tq);
+    base[t] = r < M ? n * p.H * p.W * p.Ci : -1;
+    y0[t] = y2 + py;
+    x0[t] = x2 + px;
+  }
+  const float* wrow[RN];
+  float bmask[RN];
+#pragma unroll
+  for (int c = 0; c < RN; ++c) {
+    const int co = 16 * c + i;
+    bmask[c] = co < p.Co ? 1.f : 0.f;
+    wrow[c] = p.wp + ((long)cls * p.Co + (co < p.Co ? co : 0)) * K;
+  }
+  f32x4n acc[2][RN];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < RN; ++c) acc[t][c] = (f32x4n){0.f, 0.f, 0.f, 0.f};
+  const int chunks = (K + 15) >> 4;
+  f32x4n a0[2], b0[RN], a1[2], b1[RN];
+  float m0[2], m1[2];
+  auto load = [&](f32x4n (&a)[2], f32x4n (&b)[RN], float (&msk)[2], int c) {
+    if (c >= chunks) return;
+    const int k = (c << 4) + 4 * q;
+    const bool kok = k < K;  // K % 4 == 0: a lane's four k values are all in or all out
+    const int kk = kok ? k : 0;
+    const int tap = dC.quot(kk), ci = dC.rem(kk);
+    const int ta = tap >> 1, tb = tap & 1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int iy = y0[t] - ta, ix = x0[t] - tb;
+      const bool ok = kok && base[t] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const float* src = ok ? p.x + base[t] + ((long)iy * p.W + ix) * p.Ci + ci : p.x;
+      a[t] = *reinterpret_cast<const f32x4u*>(src);
+      msk[t] = ok ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int cc = 0; cc < RN; ++cc) b[cc] = *reinterpret_cast<const f32x4u*>(wrow[cc] + kk);
+  };
+  auto compute = [&](const f32x4n (&a)[2], const f32x4n (&b)[RN], const float (&msk)[2], int c) {
+    if (c >= chunks) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float av = a[t][g] * msk[t];
+#pragma unroll
+        for (int cc = 0; cc < RN; ++cc)
+          acc[t][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[cc][g] * bmask[cc], acc[t][cc], 0, 0, 0);
+      }
+  };
+  load(a0, b0, m0, 0);
+  for (int c = 0; c < chunks; c += 2) {
+    load(a1, b1, m1, c + 1);
+    compute(a0, b0, m0, c);
+    load(a0, b0, m0, c + 2);
+    compute(a1, b1, m1, c + 1);
+  }
+  // acc[t][cc][r]: row 16 t + 4 (lane >> 4) + r, channel 16 cc + (lane & 15)
+  const int OH = 2 * p.H, OW = 2 * p.W;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long m = row0 + 16 * t + 4 * q + r;
+      if (m >= M) continue;
+      const int x2 = dW.rem(m);
+      const long tq = dW.quot(m);
+      const int y2 = dH.rem(tq);
+      const long img = dH.quot(tq);
+      float* orow = p.y + ((img * OH + 2 * y2 + py) * OW + 2 * x2 + px) * p.Co;
+#pragma unroll
+      for (int cc = 0; cc < RN; ++cc) {
+        const int co = 16 * cc + i;
+        if (co < p.Co) {
+          const float val = acc[t][cc][r] + (p.bias ? p.bias[co] : 0.f) + p.out_add;
+          orow[co] = p.accumulate ? (orow[co] + val) : val;
+        }
+      }
+    }
+}
+
+// The stride-2 forward convolution in the same register-direct form (Co <= 64, where it measured faster than the
+// LDS tiles: encoder layer 2 and the decoder's data gradients; DV3_CONV_DIRECT / DV3_CONVT_DIRECT = 0 switch both
+// off for A/B runs): row = output pixel (n, oy, ox), k = (ky, kx, ci) over K = 16*Ci, input pixel
+// (2oy + ky - 1, 2ox + kx - 1).  grid = ceil(M / 128) workgroups of 4 waves, 32 rows each.
+template <int RN>
+__global__ __launch_bounds__(256) void conv_s2_direct_kernel(ConvParams p) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int OH = p.H / 2, OW = p.W / 2;
+  const long M = (long)p.Nimg * OH * OW;
+  const int K = 16 * p.Ci;
+  const long row0 = (long)blockIdx.x * 128 + wave * 32;
+  if (row0 >= M) return;
+  const FastDiv dW = FastDiv::make(OW), dH = FastDiv::make(OH), dC = FastDiv::make(p.Ci);
+  long base[2];
+  int y0[2], x0[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const long r = row0 + 16 * t + i;
+    const long rc = r < M ? r : 0;
+    const int ox = dW.rem(rc);
+    const long tq = dW.quot(rc);
+    const int oy = dH.rem(tq);
+    const long n = dH.quot(tq);
+    base[t] = r < M ? n * p.H * p.W * p.Ci : -1;
+    y0[t] = 2 * oy - 1;
+    x0[t] = 2 * ox - 1;
+  }
+  const float* wrow[RN];
+  float bmask[RN];
+#pragma unroll
+  for (int c = 0; c < RN; ++c) {
+    const int co = 16 * c + i;
+    bmask[c] = co < p.Co ? 1.f : 0.f;
+    wrow[c] = p.wp + (long)(co < p.Co ? co : 0) * K;
+  }
+  f32x4n acc[2][RN];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < RN; ++c) acc[t][c] = (f32x4n){0.f, 0.f, 0.f, 0.f};
+  const int chunks = (K + 15) >> 4;
+  f32x4n a0[2], b0[RN], a1[2], b1[RN];
+  float m0[2], m1[2];
+  auto load = [&](f32x4n (&a)[2], f32x4n (&b)[RN], float (&msk)[2], int c) {
+    if (c >= chunks) return;
+    const int k = (c << 4) + 4 * q;  // K % 16 == 0
+    const int tap = dC.quot(k), ci = dC.rem(k);
+    const int ky = tap >> 2, kx = tap & 3;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int iy = y0[t] + ky, ix = x0[t] + kx;
+      const bool ok = base[t] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const float* src = ok ? p.x + base[t] + ((long)iy * p.W + ix) * p.Ci + ci : p.x;
+      a[t] = *reinterpret_cast<const f32x4u*>(src);
+      msk[t] = ok ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int cc = 0; cc < RN; ++cc) b[cc] = *reinterpret_cast<const f32x4u*>(wrow[cc] + k);
+  };
+  auto compute = [&](const f32x4n (&a)[2], const f32x4n (&b)[RN], const float (&msk)[2], int c) {
+    if (c >= chunks) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float av = a[t][g] * msk[t];
+#pragma unroll
+        for (int cc = 0; cc < RN; ++cc)
+          acc[t][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[cc][g] * bmask[cc], acc[t][cc], 0, 0, 0);
+      }
+  };
+  load(a0, b0, m0, 0);
+  for (int c = 0; c < chunks; c += 2) {
+    load(a1, b1, m1, c + 1);
+    compute(a0, b0, m0, c);
+    load(a0, b0, m0, c + 2);
+    compute(a1, b1, m1, c + 1);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long m = row0 + 16 * t + 4 * q + r;
+      if (m >= M) continue;
+      float* orow = p.y + m * p.Co;
+#pragma unroll
+      for (int cc = 0; cc < RN; ++cc) {
+        const int co = 16 * cc + i;
+        if (co < p.Co) orow[co] = p.accumulate ? (orow[co] + acc[t][cc][r]) : acc[t][cc][r];
+      }
+    }
+}
+
 struct WgradParams {
   const float* dy;  // [rows][Co]   coarse-grid tensor (conv: dY; convT: the layer input)
   const float* x;   // [Nimg][H][W][Ci]  fine-grid tensor (conv: the layer input; convT: dOut)
@@ -682,6 +890,14 @@ extern "C" int dv3_conv_s2_fwd(const float* x, const float* w_packed, float* y, 
   // 128x128 tiles need more than one workgroup per CU to pay for themselves: the deepest encoder layer
   // (16k rows x 256 channels = 256 such tiles) runs 14 % faster on 64x64 tiles (1024 workgroups)
   const long tiles128 = ((M + 127) / 128) * ((Co + 127) / 128);
+  static const int env_direct = getenv("DV3_CONV_DIRECT") ? atoi(getenv("DV3_CONV_DIRECT")) : 64;
+  if ((Ci & 3) == 0 && Co <= env_direct && Co <= 128) {
+    const dim3 grid((unsigned)((M + 127) / 128));
+    if (Co <= 32) hipLaunchKernelGGL(conv_s2_direct_kernel<2>, grid, dim3(256), 0, s, p);
+    else if (Co <= 64) hipLaunchKernelGGL(conv_s2_direct_kernel<4>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_s2_direct_kernel<8>, grid, dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+  }
   if (Co <= 32) go(C128x32{});
   else if (Co <= 64 || tiles128 <= 256) go(C64{});
   else go(C128{});
@@ -702,6 +918,14 @@ extern "C" int dv3_convT_s2_fwd(const float* x, const float* w_packed, const flo
     p.tiles_n = (Co + TS::BN - 1) / TS::BN;
     hipLaunchKernelGGL((convT_s2_kernel<TS>), dim3(p.tiles_m * p.tiles_n, 4), dim3(kThreads), 0, s, p);
   };
+  static const int env_direct = getenv("DV3_CONVT_DIRECT") ? atoi(getenv("DV3_CONVT_DIRECT")) : 128;
+  if ((Ci & 3) == 0 && Co <= env_direct && Co <= 128) {
+    const dim3 grid((unsigned)((M + 127) / 128), 4);
+    if (Co <= 32) hipLaunchKernelGGL(convT_s2_direct_kernel<2>, grid, dim3(256), 0, s, p);
+    else if (Co <= 64) hipLaunchKernelGGL(convT_s2_direct_kernel<4>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(convT_s2_direct_kernel<8>, grid, dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+  }
   if (Co <= 32) go(C128x32{});  // (a 256 x 32 tile measured 36 % slower)
   else if (Co <= 64) go(C64{});
   else go(C128{});
