@@ -160,7 +160,10 @@ def test_batch_stager_matches_direct_upload_and_trains():
                      torch.cat([p.detach().reshape(-1) for p in wm.parameters()]).clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]  # forward: bit-equal
     # the backward adds split-K partial sums with atomics (order not fixed): parameters agree to fp32 rounding
-    assert torch.allclose(outs[0][2], outs[1][2], rtol=0, atol=1e-6)
+    # (Adam's first step is lr * g / (|g| + eps): where a gradient is ~0 a rounding-level difference moves a weight
+    # by a fraction of lr, so: almost all within 1e-6, none further than 2 * lr apart)
+    diff = (outs[0][2] - outs[1][2]).abs()
+    assert float((diff > 1e-6).float().mean()) < 2e-3 and float(diff.max()) <= 2.1e-4
 
 
 def test_optimizer_state_is_interchangeable_with_torch_adam():

@@ -42,9 +42,10 @@ def _worker(rank, world, port, outdir):
         nz = {k: torch.from_numpy(v).cuda() for k, v in noise.items()}
         post, _, mets = wm._train(batch, noise=dict(q_prior=nz["q_prior"], q_post=nz["q_post"]))
         wm_params = torch.cat([p.detach().reshape(-1) for p in wm.parameters()]).cpu()
+        wm_grad = torch.cat([p.grad.detach().reshape(-1) for p in wm.parameters()]).cpu() / world  # SUM over ranks
         beh._train(post, None)
         beh_params = torch.cat([p.detach().reshape(-1) for p in list(beh.actor.parameters()) + list(beh.value.parameters())]).cpu()
-        torch.save({"wm": wm_params, "beh": beh_params, "grad_norm": float(mets["model_grad_norm"]),
+        torch.save({"wm": wm_params, "wm_grad": wm_grad, "beh": beh_params, "grad_norm": float(mets["model_grad_norm"]),
                     "loss": float(mets["model_loss"])}, os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -69,6 +70,15 @@ def test_two_ranks_equal_one_process_on_the_global_batch():
     _, wm, _ = Hh.build_models(NAME)
     _, _, mets = wm._train(batch, noise=noise)
     single = torch.cat([p.detach().reshape(-1) for p in wm.parameters()]).cpu()
+    single_grad = torch.cat([p.grad.detach().reshape(-1) for p in wm.parameters()]).cpu()
     assert float(mets["model_loss"]) == pytest.approx(0.5 * (r0["loss"] + r1["loss"]), rel=1e-5)
     assert float(mets["model_grad_norm"]) == pytest.approx(r0["grad_norm"], rel=1e-4)
-    assert torch.allclose(single, r0["wm"], rtol=0, atol=2e-6)
+    # the all-reduced gradient IS the gradient of the global batch (fp32 rounding: different batch shapes take
+    # different tiles / summation orders)
+    gscale = float(single_grad.abs().max())
+    assert float((r0["wm_grad"] - single_grad).abs().max()) <= 2e-5 * gscale
+    # ... and so are the parameters, except where the first Adam step (lr * g / (|g| + eps)) turns a rounding-level
+    # difference of a near-zero gradient into a fraction of lr: those must be rare and bounded by 2 * lr
+    diff = (single - r0["wm"]).abs()
+    assert float((diff > 2e-6).float().mean()) < 2e-3
+    assert float(diff.max()) <= 2.1 * wm._config.model_lr
