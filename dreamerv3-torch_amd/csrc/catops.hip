@@ -21,11 +21,14 @@ __device__ __forceinline__ void unimix_probs(float l, bool valid, int D, float u
 
 // sample: idx = argmax_d p_hat[d] / q[d], q ~ Exp(1) (the single-draw path of torch.multinomial);
 // mode: idx = argmax_d p_hat[d].  Ties resolve to the lowest class index, as torch.argmax does.
+// forced (optional, [R]): the class to emit instead of the kernel's own draw; flips counts the disagreements.
 template <int G>
 __global__ __launch_bounds__(256) void onehot_sample_kernel(const float* __restrict__ logit,
                                                             const float* __restrict__ noise,
                                                             const unsigned long long* __restrict__ rng_state,
                                                             float* __restrict__ out, int* __restrict__ idx_out,
+                                                            const int* __restrict__ forced,
+                                                            unsigned int* __restrict__ flips,
                                                             long R, int D, float unimix, int mode,
                                                             unsigned long long offset_add,
                                                             const float* __restrict__ nb_first,
@@ -72,6 +75,13 @@ __global__ __launch_bounds__(256) void onehot_sample_kernel(const float* __restr
         best = ob;
         bi = oi;
       }
+    }
+    if (forced) {
+      // teacher forcing (parity tests): the state follows the given draw; a draw of this kernel that differs is
+      // counted (argmax(p/q) flips when two ratios are within an ulp)
+      const int f = rv ? forced[r] : 0;
+      if (rv && d == 0 && flips && f != bi) atomicAdd(flips, 1u);
+      bi = f;
     }
     if (rv && valid) {
       const float v = (d == bi) ? 1.f : 0.f;
@@ -282,8 +292,29 @@ extern "C" int dv3_onehot_sample_fwd(const float* logit, const float* noise, con
   if (!mode && !noise && !rng_state) return DV3_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_sample_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
-                                       logit, noise, rng_state, onehot, idx, R, D, unimix, mode, rng_offset, nullptr,
-                                       nullptr, nullptr, 1));
+                                       logit, noise, rng_state, onehot, idx, (const int*)nullptr,
+                                       (unsigned int*)nullptr, R, D, unimix, mode, rng_offset, nullptr, nullptr,
+                                       nullptr, 1));
+  return (int)hipGetLastError();
+}
+
+// General form: optional class indices out (idx), optional teacher forcing (forced [R] int32: emit that class;
+// flips += number of rows whose own draw differs), optional fused reset blend (next_first != NULL, as
+// dv3_onehot_sample_fwd_blend).
+extern "C" int dv3_onehot_sample_fwd_ex(const float* logit, const float* noise, const unsigned long long* rng_state,
+                                        unsigned long long rng_offset, float* onehot, int* idx, const int* forced,
+                                        unsigned int* flips, long R, int D, float unimix, int mode,
+                                        const float* next_first, const float* init, float* next_out, int groups,
+                                        void* stream) {
+  if (R <= 0) return 0;
+  if (D <= 0 || D > 64 || !logit || !onehot) return DV3_ERR_ARG;
+  if (!mode && !noise && !rng_state) return DV3_ERR_ARG;
+  if (next_first && (!init || !next_out || groups <= 0 || R % groups)) return DV3_ERR_ARG;
+  if (!next_first) { init = nullptr; next_out = nullptr; groups = 1; }
+  hipStream_t s = (hipStream_t)stream;
+  DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_sample_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
+                                       logit, noise, rng_state, onehot, idx, forced, flips, R, D, unimix, mode,
+                                       rng_offset, next_first, init, next_out, groups));
   return (int)hipGetLastError();
 }
 
@@ -299,8 +330,9 @@ extern "C" int dv3_onehot_sample_fwd_blend(const float* logit, const float* nois
   if (!mode && !noise && !rng_state) return DV3_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_sample_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
-                                       logit, noise, rng_state, onehot, (int*)nullptr, R, D, unimix, mode, rng_offset,
-                                       next_first, init, next_out, groups));
+                                       logit, noise, rng_state, onehot, (int*)nullptr, (const int*)nullptr,
+                                       (unsigned int*)nullptr, R, D, unimix, mode, rng_offset, next_first, init,
+                                       next_out, groups));
   return (int)hipGetLastError();
 }
 

@@ -61,17 +61,26 @@ class Dreamer(nn.Module):
                 self._logger.step = self._config.action_repeat * self._step
         return policy_output, state
 
-    def _policy(self, obs, state, training):
+    def _policy(self, obs, state, training, noise=None):
+        """dreamer.py:116-188 for expl_behavior 'greedy' (expl_until 0 makes _should_expl always true there, so
+        training samples the task actor; the counterfactual branch behind `_best_candidate` is unreachable, SURVEY.md
+        section 0 gotcha 2).  noise (tests): dict(prior, post [n_envs,S,D] ~ Exp(1); act [n_envs,A], N(0,1) or
+        Exp(1) for the one-hot actor) injected instead of the Philox stream."""
         latent, action = (None, None) if state is None else state
+        nz = noise or {}
         obs = self._wm.preprocess(obs)
         embed = self._wm.encoder(obs)
-        latent, _ = self._wm.dynamics.obs_step(latent, action, embed, obs["is_first"])
+        latent, _ = self._wm.dynamics.obs_step(latent, action, embed, obs["is_first"], noise=nz or None)
+        if getattr(self._config, "eval_state_mean", False):
+            raise NotImplementedError("eval_state_mean needs continuous latents (dyn_discrete: 0)")
         feat = self._wm.dynamics.get_feat(latent)
         actor = self._task_behavior.actor(feat)
-        action = actor.sample() if training else actor.mode()
+        action = actor.sample(noise=nz.get("act")) if training else actor.mode()
         logprob = actor.log_prob(action)
         latent = {k: v.detach() for k, v in latent.items()}
         action = action.detach()
+        if self._config.actor["dist"] == "onehot_gumble":
+            raise NotImplementedError("actor dist onehot_gumble")
         return {"action": action, "logprob": logprob}, (latent, action)
 
     def _train(self, data):

@@ -25,6 +25,8 @@ _CTYPES = {
     "const unsigned long long*": ctypes.c_void_p,
     "unsigned long long*": ctypes.c_void_p,
     "int*": ctypes.c_void_p,
+    "const int*": ctypes.c_void_p,
+    "unsigned int*": ctypes.c_void_p,
     "void*": ctypes.c_void_p,
     "unsigned long long": ctypes.c_ulonglong,
     "long": ctypes.c_long,

@@ -305,15 +305,18 @@ class RSSMEngine:
         ops.tanh_bwd(d0, dd, _g(P.W0), accumulate=True)
 
     # -- observe ------------------------------------------------------------------------------------
-    def observe_fwd(self, embed_tm, action_tm, first_tm, *, q_prior=None, q_post=None, rng=None):
+    def observe_fwd(self, embed_tm, action_tm, first_tm, *, q_prior=None, q_post=None, rng=None, force=None):
         """embed_tm [T,B,E], action_tm [T,B,A], first_tm [T,B] (float 0/1; row 0 is forced to 1, as
         prev_state=None does in networks.py:176-180).  Noise [T,B,S,D] ~ Exp(1) or rng state.
-        Returns dict of time-major buffers."""
+        force (parity tests): dict(post=[T,B,S] int32, prior=[T,B,S] int32, flips=int32[1]) teacher-forces the
+        sampled classes and counts the draws that differ.  Returns dict of time-major buffers."""
         P, ws = self.P, self.ws
         T, B = embed_tm.shape[0], embed_tm.shape[1]
         S, D, SD, De, Hd, A, E = self.S, self.D, self.SD, self.De, self.Hd, self.A, self.E
         self.T, self.B = T, B
         TB = T * B
+        force = force or {}
+        f_post, f_prior, flips = force.get("post"), force.get("prior"), force.get("flips")
         s0, d0 = self.init_state_fwd()
         first = ws.get("obs.first", (T, B))
         first.copy_(first_tm)
@@ -349,14 +352,16 @@ class RSSMEngine:
             ops.gemm(x3[t], P.obs.W, post_logit[t].view(B, SD), bias=P.obs.b)
             ops.onehot_sample(post_logit[t], post_stoch[t], noise=None if q_post is None else q_post[t], rng=rng,
                               unimix=self.unimix,
-                              next_blend=(first[t + 1], s0.view(SD), sin[t + 1].view(B, S, D)) if nxt else None)
+                              next_blend=(first[t + 1], s0.view(SD), sin[t + 1].view(B, S, D)) if nxt else None,
+                              forced=None if f_post is None else f_post[t], flips=flips)
         # prior head for all steps at once
         x2pre, x2 = g("obs.x2pre", (T, B, Hd)), g("obs.x2", (T, B, Hd))
         m2, r2 = g("obs.m2", (T, B)), g("obs.r2", (T, B))
         prior_logit, prior_stoch = g("obs.prior_logit", (T, B, S, D)), g("obs.prior_stoch", (T, B, S, D))
         dense_ln_fwd(P.img_out, v2(deter, De), None, v2(x2pre, Hd), m2.view(TB), r2.view(TB), v2(x2, Hd))
         ops.gemm(v2(x2, Hd), P.ims.W, v2(prior_logit, SD), bias=P.ims.b)
-        ops.onehot_sample(prior_logit, prior_stoch, noise=q_prior, rng=rng, unimix=self.unimix)
+        ops.onehot_sample(prior_logit, prior_stoch, noise=q_prior, rng=rng, unimix=self.unimix, forced=f_prior,
+                          flips=flips)
         self._embed = embed_tm
         return dict(post_stoch=post_stoch, post_logit=post_logit, deter=deter, prior_stoch=prior_stoch,
                     prior_logit=prior_logit, action=ain)
@@ -443,7 +448,8 @@ class RSSMEngine:
         return side
 
     # -- one img_step on a row block (networks.py:208-233), used by the policy path and imagine ---------
-    def img_step_fwd(self, stoch, deter, action, bufs, *, noise=None, rng=None, sample=True):
+    def img_step_fwd(self, stoch, deter, action, bufs, *, noise=None, rng=None, sample=True, forced=None,
+                     flips=None):
         """stoch [M,SD], deter [M,De], action [M,A]; bufs: dict of per-step buffers (see imagine_fwd)."""
         P = self.P
         M = stoch.shape[0]
@@ -452,7 +458,8 @@ class RSSMEngine:
         ops.gru_fwd(bufs["gpre"], P.gru.g, P.gru.b, deter, bufs["deter"], bufs["mg"], bufs["rg"])
         dense_ln_fwd(P.img_out, bufs["deter"], None, bufs["x2pre"], bufs["m2"], bufs["r2"], bufs["x2"])
         ops.gemm(bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD), bias=P.ims.b)
-        ops.onehot_sample(bufs["logit"], bufs["stoch"], noise=noise, rng=rng, unimix=self.unimix, mode=not sample)
+        ops.onehot_sample(bufs["logit"], bufs["stoch"], noise=noise, rng=rng, unimix=self.unimix, mode=not sample,
+                          forced=forced, flips=flips)
 
     def img_step_bwd(self, dstoch, ddeter, prev_deter, bufs, scratch, dprev_stoch, dprev_deter, daction,
                      accumulate_prev=False):

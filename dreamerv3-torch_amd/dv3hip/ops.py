@@ -338,9 +338,12 @@ class RngStream:
         self.cursor = 0
 
 
-def onehot_sample(logit, out, *, noise=None, rng=None, idx=None, unimix=0.01, mode=False, next_blend=None):
+def onehot_sample(logit, out, *, noise=None, rng=None, idx=None, unimix=0.01, mode=False, next_blend=None,
+                  forced=None, flips=None):
     """next_blend = (next_first [B], init [S*D], next_out [B,S,D]) for logit [B,S,D]: also write the next observe
-    step's reset blend of the sample (fused second output)."""
+    step's reset blend of the sample (fused second output).  idx (int32 [R]) receives the class indices.
+    forced (int32 [R], parity tests): emit these classes instead of the kernel's own draw and count the draws
+    that differ into flips (int32 [1], incremented)."""
     D = logit.shape[-1]
     R = _groups(logit, "logit", D)
     if _groups(out, "out", D) != R:
@@ -352,21 +355,26 @@ def onehot_sample(logit, out, *, noise=None, rng=None, idx=None, unimix=0.01, mo
         if rng is None:
             raise ValueError("sampling needs noise or an RngStream")
         rng_state, rng_off = rng.state, rng.take(R * D)
-    if idx is not None:
-        _contig(idx, "idx", torch.int32)
-        if idx.numel() != R:
-            raise ValueError("idx size mismatch")
+    for t, nm in ((idx, "idx"), (forced, "forced")):
+        if t is not None:
+            _contig(t, nm, torch.int32)
+            if t.numel() != R:
+                raise ValueError(nm + " size mismatch")
+    if flips is not None:
+        _contig(flips, "flips", torch.int32)
+        if flips.numel() != 1:
+            raise ValueError("flips: one int32 counter")
+    nf = init = nout = None
+    groups = 1
     if next_blend is not None:
         nf, init, nout = next_blend
         _contig(nf, "next_first"), _contig(init, "init"), _contig(nout, "next_out")
-        if idx is not None or R % nf.numel() or init.numel() * nf.numel() != R * D or nout.numel() != R * D:
+        if R % nf.numel() or init.numel() * nf.numel() != R * D or nout.numel() != R * D:
             raise ValueError("next_blend shapes mismatch")
-        _call("dv3_onehot_sample_fwd_blend", _ptr(logit), _ptr(noise), _ptr(rng_state), int(rng_off), _ptr(out), R, D,
-              float(unimix), int(mode), _ptr(nf), _ptr(init), _ptr(nout), R // nf.numel(), _stream(),
-              key="dv3_onehot_sample_fwd")
-        return out
-    _call("dv3_onehot_sample_fwd", _ptr(logit), _ptr(noise), _ptr(rng_state), int(rng_off), _ptr(out), _ptr(idx), R,
-          D, float(unimix), int(mode), _stream())
+        groups = R // nf.numel()
+    _call("dv3_onehot_sample_fwd_ex", _ptr(logit), _ptr(noise), _ptr(rng_state), int(rng_off), _ptr(out), _ptr(idx),
+          _ptr(forced), _ptr(flips), R, D, float(unimix), int(mode), _ptr(nf), _ptr(init), _ptr(nout), groups,
+          _stream(), key="dv3_onehot_sample_fwd")
     return out
 
 

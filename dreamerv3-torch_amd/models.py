@@ -200,8 +200,11 @@ class WorldModel(nn.Module):
         E_ = embed.shape[1]
 
         # ---- RSSM scan
+        force = None
+        if "force_post" in nz or "force_prior" in nz:  # parity tests: teacher-forced draws + flip counter
+            force = dict(post=nz.get("force_post"), prior=nz.get("force_prior"), flips=nz.get("flips"))
         out = rssm.observe_fwd(embed.view(T, B, E_), act_tm, first_tm, q_prior=nz.get("q_prior"),
-                               q_post=nz.get("q_post"), rng=rng)
+                               q_post=nz.get("q_post"), rng=rng, force=force)
         ps, dt = out["post_stoch"].view(TB, SD), out["deter"].view(TB, De)
         kl = ws.get("wm.kl", (T, B))
         ent_p, ent_q = ws.get("wm.ent_post", (T, B)), ws.get("wm.ent_prior", (T, B))
@@ -209,11 +212,12 @@ class WorldModel(nn.Module):
 
         # ---- heads, losses and their upstream gradients (loss = mean over B*T of the per-row sum)
         up = 1.0 / TB
-        acc = ws.zeros("wm.acc", (8,))  # [model_loss, image, reward, cont, kl, ent_prior, ent_post, vector]
+        dec = self.heads["decoder"]
+        # [model_loss, image, reward, cont, kl, ent_prior, ent_post, spare, one slot per vector-decoder key ...]
+        acc = ws.zeros("wm.acc", (8 + len(dec.mlp_shapes),))
         gs, gd = ws.get("wm.gs", (T, B, SD)), ws.get("wm.gd", (T, B, De))
         wrote = False
         deferred = []  # weight-gradient launches that can run beside the reverse scan (E.SideStream)
-        dec = self.heads["decoder"]
         grad_heads = cfg.grad_heads
         if dec.cnn_shapes:
             dec_eng = dec._cnn.engine
@@ -231,7 +235,7 @@ class WorldModel(nn.Module):
             deng = mdec.engine_for(".wm")
             h, _, _ = deng.forward(ps, dt)
             dh = ws.zeros("wm.dec_dh", h.shape)
-            for k, shp in dec.mlp_shapes.items():
+            for ki, (k, shp) in enumerate(dec.mlp_shapes.items()):
                 lin = mdec.mean_layer[k]
                 w = int(np.prod(shp))
                 mode = ws.get(f"wm.dec.{k}", (TB, w))
@@ -240,7 +244,7 @@ class WorldModel(nn.Module):
                 lk = ws.get(f"wm.loss.{k}", (TB,))
                 dmode = ws.get(f"wm.dmode.{k}", (TB, w))
                 ops.symlog_mse(mode, tgt, lk, dmode, upstream=up)
-                ops.dot_accumulate(lk, acc[7:8], scale=up)
+                ops.dot_accumulate(lk, acc[8 + ki:9 + ki], scale=up)
                 ops.gemm(dmode, lin.weight, dh, transB=False, accumulate=True)
                 E.lin_wgrad(lin.weight, dmode, h)
                 ops.colsum(dmode, lin.bias.grad, accumulate=True)
@@ -294,13 +298,13 @@ class WorldModel(nn.Module):
         ops.dot_accumulate(ent_q.view(TB), acc[5:6], scale=up)
         ops.dot_accumulate(ent_p.view(TB), acc[6:7], scale=up)
         # model_loss = image + vector + reward*scale + cont*scale + (dyn_scale + rep_scale) * clipped KL
-        loss.copy_(acc[1:2] + acc[7:8] + self._scales["reward"] * acc[2:3] + self._scales["cont"] * acc[3:4]
-                   + (cfg.dyn_scale + cfg.rep_scale) * acc[4:5])
+        loss.copy_(acc[1:2] + acc[8:].sum(0, keepdim=True) + self._scales["reward"] * acc[2:3]
+                   + self._scales["cont"] * acc[3:4] + (cfg.dyn_scale + cfg.rep_scale) * acc[4:5])
         metrics = {}
         if dec.cnn_shapes:
             metrics["image_loss"] = acc[1]
-        for k in dec.mlp_shapes:
-            metrics[f"{k}_loss"] = acc[7]
+        for ki, k in enumerate(dec.mlp_shapes):
+            metrics[f"{k}_loss"] = acc[8 + ki]  # each key's own -log_prob mean (models.py:150)
         metrics.update(reward_loss=acc[2], cont_loss=acc[3], kl_free=cfg.kl_free, dyn_scale=cfg.dyn_scale,
                        rep_scale=cfg.rep_scale, dyn_loss=acc[4], rep_loss=acc[4], kl=ws.get("wm.kl_mean", (1,))[0],
                        prior_ent=acc[5], post_ent=acc[6])
@@ -449,6 +453,7 @@ class ImagBehavior(nn.Module):
         actor_eng = self.actor.engine_for(".imag")
         normal = cfg.actor["dist"] == "normal"
         q_img, act_noise = nz.get("q_img"), nz.get("act")
+        f_img, f_act, flips = nz.get("force_img"), nz.get("force_act"), nz.get("flips")  # parity tests
         for t in range(H):
             _, mean_raw, std_raw = actor_eng.forward(stoch[t], deter[t], row0=t * N, total=H * N)
             if normal:
@@ -460,12 +465,14 @@ class ImagBehavior(nn.Module):
                                      max_std=cfg.actor["max_std"])
             else:
                 ops.onehot_sample(mean_raw, action[t], noise=None if act_noise is None else act_noise[t], rng=rng,
-                                  unimix=cfg.actor["unimix_ratio"])
+                                  unimix=cfg.actor["unimix_ratio"], forced=None if f_act is None else f_act[t],
+                                  flips=flips)
                 ops.onehot_ent_logp_fwd(mean_raw, None, ent[t], None, unimix=cfg.actor["unimix_ratio"])
             if t < H - 1:
                 b = {k: v[t] for k, v in step.items()}
                 b.update(deter=deter[t + 1], logit=logit[t + 1].view(N, S, D), stoch=stoch[t + 1].view(N, S, D))
-                rssm.img_step_fwd(stoch[t], deter[t], action[t], b, noise=None if q_img is None else q_img[t], rng=rng)
+                rssm.img_step_fwd(stoch[t], deter[t], action[t], b, noise=None if q_img is None else q_img[t], rng=rng,
+                                  forced=None if f_img is None else f_img[t], flips=flips)
         rng.commit()
         self._im = dict(H=H, N=N, stoch=stoch, deter=deter, logit=logit, action=action, ent=ent, eps=eps, step=step,
                         actor=actor_eng)

@@ -93,6 +93,13 @@ int dv3_onehot_sample_fwd_blend(const float* logit, const float* noise, const un
                                 void* stream);
 /* ... plus next_out[r][d] = onehot*(1 - f) + init[r % groups][d]*f, f = next_first[r / groups]: the next observe
  * step's reset blend of the sampled state, fused (groups = stoch groups per batch row). */
+/* General form of the two above.  forced (optional, int32 [R]): teacher forcing for the parity tests -- the class
+ * emitted is forced[r]; *flips (optional, device uint32) is incremented once per row whose own draw differs
+ * (argmax(p/q) can flip on an ulp).  next_first == NULL disables the fused blend. */
+int dv3_onehot_sample_fwd_ex(const float* logit, const float* noise, const unsigned long long* rng_state,
+                             unsigned long long rng_offset, float* onehot, int* idx, const int* forced,
+                             unsigned int* flips, long R, int D, float unimix, int mode, const float* next_first,
+                             const float* init, float* next_out, int groups, void* stream);
 /* rng_offset is added to rng_state's offset for this call (R*D/4+1 counters are consumed): the caller lays
  * the calls of one update out on disjoint counter ranges and advances rng_state once, so the launch
  * sequence stays static under hipGraph replay. */

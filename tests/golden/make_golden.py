@@ -401,7 +401,8 @@ def main():
     torch.set_num_threads(8)
     tools, networks, models = import_reference()
     install_noise_hooks(tools)
-    plan = [("tiny", True), ("tiny_onehot", True), ("tiny_proprio", True), ("cfg2", False), ("cfg1", False)]
+    plan = [("tiny", True), ("tiny_onehot", True), ("tiny_proprio", True), ("cfg2", False), ("cfg1", False),
+            ("cfg3", False)]
     for name, full in plan:
         if args.only and name != args.only:
             continue

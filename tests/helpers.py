@@ -90,9 +90,12 @@ def from_time_major_rows(x, B, T):
     return x.reshape((sh[0], T, B) + tuple(sh[2:])).transpose(1, 2).reshape(sh)
 
 
-def oracle_update(name, threads=None):
+def oracle_update(name, threads=None, piecewise=False):
     """One full update in the oracle (WM step, slow-critic EMA, behaviour on the UPDATED world model,
-    as dreamer.py:194-200).  Returns everything the GPU tests compare against."""
+    as dreamer.py:194-200).  Returns everything the GPU tests compare against.  piecewise=True also
+    evaluates the behaviour losses and gradients on the world model BEFORE its Adam step and without the
+    slow-critic EMA update (res["beh0"], ...): that is the setting of the golden files' imag/* and
+    grad/actor.*, grad/value.* entries (tests/golden/make_golden.py runs the pieces before the _train calls)."""
     if threads:
         torch.set_num_threads(threads)
     cfg = common.path_config(name)
@@ -103,6 +106,18 @@ def oracle_update(name, threads=None):
     wkeys = [k for k in p if k.split(".")[0] in WM_PREFIXES]
     grads = torch.autograd.grad(out["model_loss"], [p[k] for k in wkeys])
     res = dict(cfg=cfg, wm=out, wm_grads={k: g.clone() for k, g in zip(wkeys, grads)})
+    start = {k: v.detach() for k, v in out["post"].items()}
+    akeys = [k for k in p if k.startswith("actor.")]
+    vkeys = [k for k in p if k.startswith("value.")]
+    if piecewise:
+        ema0 = torch.zeros(2)
+        b0 = O.behavior_forward(cfg, p, start, n["act"], n["q_img"], ema0)
+        ga0 = torch.autograd.grad(b0["actor_loss"], [p[k] for k in akeys], retain_graph=True)
+        gv0 = torch.autograd.grad(b0["value_loss"], [p[k] for k in vkeys])
+        res.update(beh0={k: (v.detach() if isinstance(v, torch.Tensor) else {kk: vv.detach() for kk, vv in v.items()})
+                         for k, v in b0.items()},
+                   ema0=ema0, actor_grads0=dict(zip(akeys, ga0)), value_grads0=dict(zip(vkeys, gv0)))
+        del b0
     with torch.no_grad():
         st = dict(step=0, m=[torch.zeros_like(p[k]) for k in wkeys], v=[torch.zeros_like(p[k]) for k in wkeys])
         res["model_grad_norm"] = O.clip_and_adam([p[k] for k in wkeys], list(grads), st, lr=1e-4, eps=1e-8, clip=1000.0)
@@ -110,11 +125,8 @@ def oracle_update(name, threads=None):
             if k.startswith("value."):
                 sk = "_slow_value." + k[len("value."):]
                 p[sk].copy_(cfg.slow_target_fraction * p[k] + (1 - cfg.slow_target_fraction) * p[sk])
-    start = {k: v.detach() for k, v in out["post"].items()}
     ema = torch.zeros(2)
     bout = O.behavior_forward(cfg, p, start, n["act"], n["q_img"], ema)
-    akeys = [k for k in p if k.startswith("actor.")]
-    vkeys = [k for k in p if k.startswith("value.")]
     ga = torch.autograd.grad(bout["actor_loss"], [p[k] for k in akeys], retain_graph=True)
     gv = torch.autograd.grad(bout["value_loss"], [p[k] for k in vkeys])
     res.update(beh=bout, ema=ema, actor_grads=dict(zip(akeys, ga)), value_grads=dict(zip(vkeys, gv)))
@@ -125,3 +137,28 @@ def oracle_update(name, threads=None):
     res["params_after"] = {k: v.detach() for k, v in p.items()}
     res["data"], res["noise"] = data, n
     return res
+
+
+def onehot_index(x):
+    """one-hot [..., D] -> int32 class index [...] (contiguous, for teacher forcing)."""
+    return x.detach().argmax(-1).to(torch.int32).contiguous()
+
+
+def forced_draws(name, exp, beh_key="beh", device="cuda"):
+    """Teacher-forcing inputs of the GPU path from an oracle run: the classes the oracle drew, laid out as the GPU
+    path indexes them (observe: time-major [T,B,S]; imagination: rows t*B+b, entry t = the draw that produces
+    state t+1).  -> (wm_force, im_force) dicts to merge into the `noise` arguments."""
+    s = common.SHAPES[name]
+    B, T, H = s["B"], s["T"], s["H"]
+    w = exp["wm"]
+    wm_force = dict(force_post=onehot_index(w["post"]["stoch"]).transpose(0, 1).contiguous().to(device),
+                    force_prior=onehot_index(w["prior"]["stoch"]).transpose(0, 1).contiguous().to(device))
+    b = exp[beh_key]
+    st = onehot_index(b["states"]["stoch"])  # [H,N,S], state t; rows b*T+t
+    st = to_time_major_rows(st, B, T)
+    f_img = torch.zeros_like(st)
+    f_img[:-1] = st[1:]  # the draw of step t yields state t+1; the discarded H-th successor is never drawn
+    im_force = dict(force_img=f_img.contiguous().to(device))
+    if s["actor_dist"] == "onehot":
+        im_force["force_act"] = to_time_major_rows(onehot_index(b["actions"]), B, T).contiguous().to(device)
+    return wm_force, im_force

@@ -78,13 +78,9 @@ def test_dreamer_agent_trains_and_acts(name):
         assert torch.equal(v, sd[k]), k
 
 
-def test_policy_step_matches_oracle():
-    """One acting step (Dreamer._policy -> encoder -> obs_step -> actor mode) against the oracle."""
+def _load_agent(name, n_envs=None):
     import dreamer
 
-    from oracle import dv3_oracle as O
-
-    name = "tiny"
     cfg = Hh.make_config(name)
     cfg.pretrain = 0
     agent = dreamer.Dreamer(Hh.obs_space(name), None, cfg, _Logger(), _dataset(name)).to(cfg.device)
@@ -98,17 +94,60 @@ def test_policy_step_matches_oracle():
             sd[k] = torch.from_numpy(w[key])
     agent.load_state_dict(sd)
     agent.requires_grad_(False)
-    obs = _obs(3, True)
-    out, (latent, action) = agent._policy(obs, None, training=False)
+    return agent, w
+
+
+@pytest.mark.parametrize("name,n_envs", [("tiny", 3), ("tiny_onehot", 3), ("cfg2", 1), ("cfg2", 16)])
+def test_policy_steps_match_oracle(name, n_envs):
+    """The acting path: Dreamer._policy -> preprocess -> encoder -> obs_step -> actor, three
+    consecutive env steps against the oracle on the same weights and injected noise:
+      step 0  no carried state (all is_first), training: sampled posterior, sampled action, its log-prob;
+      step 1  carried state, no reset, training;
+      step 2  carried state, a reset on one env only (the reset_blend of state and action, networks.py:183-191),
+              evaluation: posterior still sampled (obs_step's default), action = mode of the actor."""
+    from oracle import dv3_oracle as O
+
+    agent, w = _load_agent(name)
+    s = common.SHAPES[name]
+    S, D, A = s["stoch"], s["discrete"], s["A"]
     pc = common.path_config(name)
     p = {k: torch.from_numpy(v) for k, v in w.items()}
-    img = torch.from_numpy(obs["image"]).float() / 255.0
-    embed = O.conv_encoder(pc, p, img[:, None])[:, 0]
-    post, _ = O.obs_step(pc, p, None, None, embed, torch.ones(3), None, None, sample=False)
-    feat = O.get_feat(pc, post)
-    mean, std = O.actor_stats(pc, p, feat)
-    assert torch.allclose(latent["deter"].cpu(), post["deter"], atol=1e-4)
-    assert torch.allclose(latent["logit"].cpu(), post["logit"], atol=1e-4)
+    rs = np.random.RandomState(5)
+    state, ostate, oaction = None, None, None
+    for step in range(3):
+        first = np.ones(n_envs, bool) if step == 0 else np.zeros(n_envs, bool)
+        if step == 2:
+            first[n_envs // 2] = True
+        obs = {"image": rs.randint(0, 256, (n_envs, 64, 64, 3)).astype(np.uint8), "is_first": first,
+               "is_terminal": np.zeros(n_envs, bool)}
+        qp = np.maximum(rs.exponential(size=(n_envs, S, D)), 1e-20).astype(np.float32)
+        qq = np.maximum(rs.exponential(size=(n_envs, S, D)), 1e-20).astype(np.float32)
+        onehot = s["actor_dist"] == "onehot"
+        eps = (np.maximum(rs.exponential(size=(n_envs, A)), 1e-20) if onehot else rs.randn(n_envs, A)).astype(np.float32)
+        training = step < 2
+        noise = dict(prior=torch.from_numpy(qp).cuda(), post=torch.from_numpy(qq).cuda(), act=torch.from_numpy(eps).cuda())
+        out, state = agent._policy(obs, state, training, noise=noise)
+        # oracle
+        img = torch.from_numpy(obs["image"]).float() / 255.0
+        embed = O.conv_encoder(pc, p, img[:, None])[:, 0]
+        post, _ = O.obs_step(pc, p, ostate, oaction, embed, torch.from_numpy(first).float(), torch.from_numpy(qp),
+                             torch.from_numpy(qq))
+        feat = O.get_feat(pc, post)
+        if training:
+            act = O.actor_sample(pc, p, feat, torch.from_numpy(eps))
+        elif onehot:
+            act = O.onehot_mode(O.actor_stats(pc, p, feat)[0], pc.unimix)
+        else:
+            act = O.actor_stats(pc, p, feat)[0]  # tanh(mean); |.| <= 1 so the absmax rescale is the identity
+        lp = O.actor_logprob(pc, p, feat, act)
+        latent, action = state
+        what = f"{name} x{n_envs} step {step}"
+        assert torch.equal(latent["stoch"].cpu(), post["stoch"]), what + ": sampled posterior"
+        assert torch.allclose(latent["deter"].cpu(), post["deter"], atol=1e-4), what + ": deter"
+        assert torch.allclose(latent["logit"].cpu(), post["logit"], atol=1e-4), what + ": logit"
+        assert out["action"].shape == act.shape and torch.allclose(out["action"].cpu(), act, atol=1e-4), what + ": action"
+        assert torch.allclose(out["logprob"].cpu(), lp, atol=2e-4, rtol=1e-4), what + ": logprob"
+        ostate, oaction = {k: v.detach() for k, v in post.items()}, act.detach()
 
 
 @pytest.mark.parametrize("name", ["tiny", "cfg2"])

@@ -1,11 +1,18 @@
-"""Full-size (BASELINE cfg 2: dmc_vision, B16 x T64, H15, deter 512) parity on the MI355X:
+"""Full-size parity on the MI355X for the BASELINE configs that have a reference fixture
+(cfg 1 dmc_proprio, cfg 2 dmc_vision, cfg 3 atari100k shapes: tests/golden/cfg{1,2,3}.npz):
 
-* against the committed golden vectors that the REFERENCE produced for this config (tests/golden/cfg2.npz),
-* against the CPU oracle run live on the same minibatch / weights / noise,
-* through size-independent properties (batch-row permutation equivariance, replay determinism).
+* against the golden vectors the REFERENCE produced for the config (world-model outputs, imagination rows,
+  lambda-returns, per-frame losses, scalar losses, gradient and post-Adam parameter checksums),
+* against the CPU oracle run live on the same minibatch / weights / noise (every tensor, every gradient, the
+  Adam-updated parameters),
+* free-running (no teacher forcing): rows compared up to their first sample flip, flip count printed and bounded,
+* through size-independent properties (batch-row permutation equivariance, hipGraph replay == eager).
 
-A sampled state is argmax(p/q): an ulp-level difference in p can flip a draw and then that row's future
-differs.  Rows are therefore compared up to their first flip, and the flip rate is bounded.
+Sampling is argmax(p/q): an ulp-level difference in p can flip a draw and that row's future then differs
+(SURVEY.md section 7.3).  The value comparisons therefore run TEACHER-FORCED: the kernels still make their own
+draw from the same noise, but the state follows the oracle's draw and every disagreement is counted
+(dv3_onehot_sample_fwd_ex).  Every assert below is unconditional; the per-draw flip rate is asserted <= 1e-5 and
+printed, so a kernel that drifts shows up as flips, not as a skipped block.
 """
 import os
 
@@ -18,153 +25,344 @@ from tests.golden import common
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-NAME = "cfg2"
+CONFIGS = ["cfg2", "cfg1", "cfg3"]
+# fp32 tolerances (north_star: outputs within 1e-4), relative to max(1, max|ref|) of the tensor compared
+TOL_OUT = 1e-4  # logits, deter, pixels, returns, values, rewards, actions
+TOL_LOSS = 2e-5  # scalar losses (means over >= 1024 rows)
+TOL_GRAD = 1e-3  # gradients, relative to the gradient tensor's own max (sums over 1024..15360 rows / 4M pixels)
+MAX_FLIP_RATE = 1e-5  # per categorical draw
 
 
+def close(got, ref, tol, what, floor=1.0):
+    got = torch.as_tensor(np.asarray(got) if not isinstance(got, torch.Tensor) else got).detach().cpu().double()
+    ref = torch.as_tensor(np.asarray(ref) if not isinstance(ref, torch.Tensor) else ref).detach().cpu().double()
+    assert got.shape == ref.shape, (what, tuple(got.shape), tuple(ref.shape))
+    err = (got - ref).abs().max().item() if got.numel() else 0.0
+    scale = max(floor, ref.abs().max().item() if ref.numel() else floor)
+    assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol:g} * scale {scale:.3e}"
+    return err / scale
+
+
+def checksum_close(got, ref_cs, tol, what):
+    """got: tensor; ref_cs: common.checksum of the reference tensor (sum, abs-sum, max-abs in float64)."""
+    cs = common.checksum(got.detach().cpu().numpy())
+    scale = max(ref_cs[1], 1e-12)
+    assert abs(cs[1] - ref_cs[1]) <= tol * scale, f"{what}: abs-sum {cs[1]:.9e} vs {ref_cs[1]:.9e}"
+    assert abs(cs[0] - ref_cs[0]) <= tol * scale, f"{what}: sum {cs[0]:.9e} vs {ref_cs[0]:.9e}"
+    assert abs(cs[2] - ref_cs[2]) <= max(tol * 10, 1e-3) * max(ref_cs[2], 1e-12), f"{what}: max {cs[2]} vs {ref_cs[2]}"
+
+
+def adam_close(got, ref, lr, what):
+    """Post-Adam parameters: equal to 2e-6 except where the first Adam step (lr * g / (|g| + eps)) turns a
+    rounding-level difference of a near-zero gradient into a fraction of lr -- rare, bounded by 2 lr."""
+    d = (got.detach().cpu().double() - ref.detach().cpu().double()).abs()
+    assert float(d.max()) <= 2.1 * lr, f"{what}: max {float(d.max()):.3e}"
+    assert float((d > 2e-6).double().mean()) <= 5e-3, f"{what}: {float((d > 2e-6).double().mean()):.3e} outliers"
+
+
+def gpu_noise(name, exp, beh_key, flips):
+    s = common.SHAPES[name]
+    n = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(name).items()}
+    wm_force, im_force = Hh.forced_draws(name, exp, beh_key)
+    wm_noise = dict(q_prior=n["q_prior"].contiguous(), q_post=n["q_post"].contiguous(), flips=flips, **wm_force)
+    im_noise = dict(act=Hh.to_time_major_rows(n["act"], s["B"], s["T"]).contiguous(),
+                    q_img=Hh.to_time_major_rows(n["q_img"], s["B"], s["T"]).contiguous(), flips=flips, **im_force)
+    return wm_noise, im_noise
+
+
+def n_draws(s, onehot_actor):
+    wm = 2 * s["T"] * s["B"] * s["stoch"]
+    im = (s["H"] - 1) * s["B"] * s["T"] * s["stoch"] + (s["H"] * s["B"] * s["T"] if onehot_actor else 0)
+    return wm, im
+
+
+@pytest.fixture(scope="module", params=CONFIGS)
+def full(request):
+    """Oracle expectation + two teacher-forced GPU runs: (A) the pieces, world-model forward/backward and the
+    behaviour losses on the NOT yet updated world model (what the golden file's imag/*, grad/* hold); (B) the
+    full update through _train (what its train/* and after/* hold)."""
+    name = request.param
+    s = common.SHAPES[name]
+    exp = Hh.oracle_update(name, threads=min(16, os.cpu_count() or 1), piecewise=True)
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    data = common.make_batch(name)
+    onehot_actor = s["actor_dist"] == "onehot"
+    # ---- run A
+    cfg, wm, beh = Hh.build_models(name)
+    flipsA = torch.zeros(1, dtype=torch.int32, device="cuda")
+    wm_noise, im_noise = gpu_noise(name, exp, "beh0", flipsA)
+    wm.train_fwd_bwd(data, noise=wm_noise)
+    post, _, wm_mets, wm_loss = wm._pending
+    A = dict(post={k: v.clone() for k, v in post.items()}, wm_loss=wm_loss.clone(),
+             wm_mets={k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in wm_mets.items()},
+             wm_grads={k: p.grad.clone() for k, p in wm.named_parameters()},
+             out={k: v.clone() for k, v in wm._last["out"].items()}, embed=wm._last["embed"].clone(),
+             kl=wm._last["kl"].clone(), ent_post=wm._last["ent_post"].clone())
+    ws = wm.dynamics.engine.ws
+    TB = s["B"] * s["T"]
+    A["lp_r"], A["lp_c"] = ws.get("wm.lp_r", (TB,)).clone(), ws.get("wm.lp_c", (TB,)).clone()
+    if s["encoder"] == "cnn":
+        A["recon"] = ws.get("dec.recon", (TB, 64, 64, 3)).clone()
+        A["loss_img"] = ws.get("wm.loss_img", (TB,)).clone()
+    else:
+        A["loss_vec"] = {k: ws.get(f"wm.loss.{k}", (TB,)).clone() for k, _ in common.PROPRIO_KEYS}
+    wm_flips = int(flipsA.item())
+    beh._update_slow_target = lambda: None  # the golden pieces use the critic's slow copy as initialised
+    beh.train_fwd_bwd(A["post"], noise=im_noise)
+    (_, imag_state, action, weights), beh_mets, (aloss, vloss) = beh._pending
+    A.update(imag={k: v.clone() for k, v in imag_state.items()}, action=action.clone(), weights=weights.clone(),
+             last={k: v.clone() for k, v in beh._last.items()}, ent=beh._im["ent"].clone(),
+             actor_loss=aloss.clone(), value_loss=vloss.clone(), ema=beh.ema_vals.clone(),
+             beh_grads={k: p.grad.clone() for k, p in beh.named_parameters()
+                        if k.startswith("actor.") or k.startswith("value.")})
+    im_flips = int(flipsA.item()) - wm_flips
+    # ---- run B
+    cfg, wm2, beh2 = Hh.build_models(name)
+    flipsB = torch.zeros(1, dtype=torch.int32, device="cuda")
+    wm_noise, im_noise = gpu_noise(name, exp, "beh", flipsB)
+    post2, _, mets_wm = wm2._train(data, noise=wm_noise)
+    post2 = {k: v.clone() for k, v in post2.items()}
+    bres = beh2._train(post2, None, noise=im_noise)
+    torch.cuda.synchronize()
+    Bv = dict(wm=wm2, beh=beh2, mets_wm=mets_wm, mets_beh=bres[-1], flips=int(flipsB.item()),
+              last={k: v.clone() for k, v in beh2._last.items()}, imag={k: v.clone() for k, v in bres[1].items()})
+    d_wm, d_im = n_draws(s, onehot_actor)
+    print(f"\n[{name}] teacher-forced sample flips: world model {wm_flips}/{d_wm}, imagination {im_flips}/{d_im}; "
+          f"full update {Bv['flips']}/{d_wm + d_im}")
+    return dict(name=name, s=s, cfg=cfg, exp=exp, g=g, A=A, B=Bv, wm_flips=wm_flips, im_flips=im_flips, data=data)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_sample_flip_rate(full):
+    s = full["s"]
+    d_wm, d_im = n_draws(s, s["actor_dist"] == "onehot")
+    assert full["wm_flips"] <= max(1, MAX_FLIP_RATE * d_wm), (full["wm_flips"], d_wm)
+    assert full["im_flips"] <= max(1, MAX_FLIP_RATE * d_im), (full["im_flips"], d_im)
+    assert full["B"]["flips"] <= max(2, MAX_FLIP_RATE * (d_wm + d_im)), (full["B"]["flips"], d_wm + d_im)
+
+
+def test_world_model_outputs_vs_oracle_and_reference(full):
+    s, A, g, ew = full["s"], full["A"], full["g"], full["exp"]["wm"]
+    B, T = s["B"], s["T"]
+    bt = lambda x: x.transpose(0, 1)  # time-major -> [B,T,...]
+    # live oracle, every row
+    close(bt(A["embed"]), ew["embed"], TOL_OUT, "embed")
+    assert torch.equal(A["post"]["stoch"].cpu(), ew["post"]["stoch"].detach()), "teacher-forced posterior differs"
+    close(A["post"]["logit"], ew["post"]["logit"], TOL_OUT, "post logit")
+    close(A["post"]["deter"], ew["post"]["deter"], TOL_OUT, "deter")
+    close(bt(A["out"]["prior_logit"]), ew["prior"]["logit"], TOL_OUT, "prior logit")
+    close(bt(A["kl"]), ew["kl"], TOL_OUT, "kl value")
+    close(bt(A["ent_post"]), ew["post_ent"], TOL_OUT, "posterior entropy")
+    close(bt(-A["lp_r"].view(T, B)), ew["losses"]["reward"], TOL_OUT, "reward loss per step")
+    close(bt(-A["lp_c"].view(T, B)), ew["losses"]["cont"], TOL_OUT, "cont loss per step")
+    close(A["wm_loss"], ew["model_loss"], TOL_LOSS, "model_loss")
+    # reference golden vectors: rows 0..1 of the batch, per-step losses of every row, scalars
+    close(bt(A["embed"])[:2], g["embed"], TOL_OUT, "embed vs reference")
+    for k in ("logit", "deter"):
+        close(A["post"][k][:2], g["post/" + k], TOL_OUT, f"post {k} vs reference")
+    assert np.array_equal(A["post"]["stoch"][:2].cpu().numpy(), g["post/stoch"]), "posterior draws vs reference"
+    close(bt(A["out"]["prior_logit"])[:2], g["prior/logit"], TOL_OUT, "prior logit vs reference")
+    close(bt(-A["lp_r"].view(T, B)), g["loss/reward"], TOL_OUT, "reward loss vs reference")
+    close(bt(-A["lp_c"].view(T, B)), g["loss/cont"], TOL_OUT, "cont loss vs reference")
+    close(bt(A["kl"]), g["kl_value"], TOL_OUT, "kl vs reference")
+    close(A["wm_loss"], g["model_loss"], TOL_LOSS, "model_loss vs reference")
+    if s["encoder"] == "cnn":
+        close(A["recon"].view(T, B, 64, 64, 3).transpose(0, 1), ew["recon"], TOL_OUT, "decoded pixels")
+        close(bt(A["loss_img"].view(T, B)), ew["losses"]["image"], TOL_OUT, "image loss per frame")
+        # decoded pixels of frames (b=0, t=0..1): GPU rows t*B + 0
+        rec = torch.stack([A["recon"][0], A["recon"][B]], 0)[None]
+        close(rec, g["recon"], TOL_OUT, "decoded pixels vs reference")
+        close(bt(A["loss_img"].view(T, B)), g["loss/image"], TOL_OUT, "image loss vs reference")
+    else:
+        for k, _ in common.PROPRIO_KEYS:
+            close(bt(A["loss_vec"][k].view(T, B)), ew["losses"][k], TOL_OUT, f"{k} loss per step")
+            close(bt(A["loss_vec"][k].view(T, B)), g["loss/" + k], TOL_OUT, f"{k} loss vs reference")
+
+
+def test_world_model_gradients_vs_oracle_and_reference(full):
+    A, g, exp = full["A"], full["g"], full["exp"]
+    worst = 0.0
+    for k, ref in exp["wm_grads"].items():
+        worst = max(worst, close(A["wm_grads"][k], ref, TOL_GRAD, "grad " + k, floor=1e-12))
+        checksum_close(A["wm_grads"][k], g["sum/grad/" + k], TOL_GRAD, "grad checksum vs reference " + k)
+    gn = torch.sqrt(sum((v.double() ** 2).sum() for v in A["wm_grads"].values()))
+    close(gn, exp["model_grad_norm"], 2e-4, "model grad norm")
+    close(gn, g["model_grad_norm"], 2e-4, "model grad norm vs reference")
+    print(f"\n[{full['name']}] worst world-model gradient error (relative to the tensor's max): {worst:.2e}")
+
+
+def test_imagination_and_returns_vs_oracle_and_reference(full):
+    s, A, g, eb = full["s"], full["A"], full["g"], full["exp"]["beh0"]
+    B, T, H = s["B"], s["T"], s["H"]
+    un = lambda x: Hh.from_time_major_rows(x, B, T)  # GPU rows t*B+b -> the reference's b*T+t
+    stoch = un(A["imag"]["stoch"])
+    assert torch.equal(stoch.cpu(), eb["states"]["stoch"]), "teacher-forced imagined states differ"
+    close(un(A["imag"]["deter"]), eb["states"]["deter"], TOL_OUT, "imag deter")
+    close(un(A["imag"]["logit"])[1:], eb["states"]["logit"][1:], TOL_OUT, "imag logit")
+    close(un(A["action"]), eb["actions"], TOL_OUT, "imag action")
+    close(un(A["last"]["reward"]), eb["reward"].squeeze(-1), TOL_OUT, "imag reward")
+    close(un(A["last"]["value"]), eb["value"].squeeze(-1), TOL_OUT, "imag value")
+    close(un(A["last"]["target"]), eb["target"].squeeze(-1), TOL_OUT, "lambda-return")
+    close(un(A["weights"]), eb["weights"], TOL_OUT, "weights")
+    close(un(A["ent"]), eb["actor_ent"], TOL_OUT, "actor entropy")
+    close(A["actor_loss"], eb["actor_loss"], TOL_LOSS, "actor_loss")
+    close(A["value_loss"], eb["value_loss"], TOL_LOSS, "value_loss")
+    close(A["ema"], full["exp"]["ema0"], TOL_OUT, "ema_vals")
+    # the reference's rows 0..7 (b = 0, t = 0..7) of every imagination tensor
+    r8 = lambda x: un(x)[:, :8]
+    assert np.array_equal(r8(A["imag"]["stoch"]).cpu().numpy(), g["imag/stoch"]), "imagined draws vs reference"
+    close(r8(A["imag"]["deter"]), g["imag/deter"], TOL_OUT, "imag deter vs reference")
+    close(r8(A["imag"]["logit"])[1:], g["imag/logit"][1:], TOL_OUT, "imag logit vs reference")
+    feat = torch.cat([A["imag"]["stoch"].flatten(2), A["imag"]["deter"]], -1)
+    close(r8(feat), g["imag/feat"], TOL_OUT, "imag feat vs reference")
+    close(r8(A["action"]), g["imag/action"], TOL_OUT, "imag action vs reference")
+    close(r8(A["last"]["reward"])[..., None], g["imag/reward"], TOL_OUT, "imag reward vs reference")
+    close(r8(A["last"]["value"])[..., None], g["imag/value"], TOL_OUT, "imag value vs reference")
+    close(r8(A["last"]["target"])[..., None], g["imag/target"], TOL_OUT, "lambda-return vs reference")
+    close(r8(A["weights"]), g["imag/weights"], TOL_OUT, "weights vs reference")
+    close(r8(A["ent"]), g["imag/actor_ent"], TOL_OUT, "actor entropy vs reference")
+    close(A["actor_loss"], g["actor_loss"], TOL_LOSS, "actor_loss vs reference")
+    close(A["value_loss"], g["value_loss"], TOL_LOSS, "value_loss vs reference")
+    # whole-tensor pins of the reference (sum, abs-sum, max over all 15 x N rows)
+    checksum_close(un(A["last"]["target"]), g["sum/imag/target"], 2e-4, "lambda-return checksum vs reference")
+    checksum_close(un(A["last"]["reward"]), g["sum/imag/reward"], 2e-4, "reward checksum vs reference")
+    checksum_close(un(A["imag"]["deter"]), g["sum/imag/deter"], 2e-4, "imag deter checksum vs reference")
+
+
+def test_behaviour_gradients_vs_oracle_and_reference(full):
+    A, g, exp = full["A"], full["g"], full["exp"]
+    worst = 0.0
+    for nm, ref_grads in (("actor", exp["actor_grads0"]), ("value", exp["value_grads0"])):
+        for k, ref in ref_grads.items():
+            worst = max(worst, close(A["beh_grads"][k], ref, TOL_GRAD, "grad " + k, floor=1e-12))
+            checksum_close(A["beh_grads"][k], g["sum/grad/" + k], TOL_GRAD, "grad checksum vs reference " + k)
+        gn = torch.sqrt(sum((v.double() ** 2).sum() for k, v in A["beh_grads"].items() if k.startswith(nm + ".")))
+        close(gn, g[nm + "_grad_norm"], 3e-4, nm + " grad norm vs reference")
+    print(f"\n[{full['name']}] worst actor/critic gradient error (relative to the tensor's max): {worst:.2e}")
+
+
+def test_full_update_vs_oracle_and_reference(full):
+    """Run B: WorldModel._train then ImagBehavior._train on the UPDATED world model (dreamer.py:194-200)."""
+    s, Bv, g, exp = full["s"], full["B"], full["g"], full["exp"]
+    B, T = s["B"], s["T"]
+    un = lambda x: Hh.from_time_major_rows(x, B, T)
+    mw, mb, eb = Bv["mets_wm"], Bv["mets_beh"], exp["beh"]
+    f = lambda d, k: torch.tensor(float(d[k]))
+    close(f(mw, "model_loss"), exp["wm"]["model_loss"], TOL_LOSS, "model_loss")
+    close(f(mw, "model_grad_norm"), exp["model_grad_norm"], 2e-4, "model_grad_norm")
+    close(f(mb, "actor_loss"), eb["actor_loss"], TOL_LOSS, "actor_loss")
+    close(f(mb, "value_loss"), eb["value_loss"], TOL_LOSS, "value_loss")
+    close(f(mb, "actor_grad_norm"), exp["actor_grad_norm"], 3e-4, "actor_grad_norm")
+    close(f(mb, "value_grad_norm"), exp["value_grad_norm"], 3e-4, "value_grad_norm")
+    assert torch.equal(un(Bv["imag"]["stoch"]).cpu(), eb["states"]["stoch"].detach())
+    close(un(Bv["last"]["target"]), eb["target"].detach().squeeze(-1), TOL_OUT, "lambda-return (updated model)")
+    close(un(Bv["last"]["reward"]), eb["reward"].detach().squeeze(-1), TOL_OUT, "reward (updated model)")
+    close(un(Bv["last"]["value"]), eb["value"].detach().squeeze(-1), TOL_OUT, "value (updated model)")
+    close(Bv["beh"].ema_vals, exp["ema"], TOL_OUT, "ema_vals")
+    close(Bv["beh"].ema_vals, g["ema_vals_after"], TOL_OUT, "ema_vals vs reference")  # (aliases the buffer after _train)
+    # the reference's own _train metrics for this minibatch
+    for k in ("model_loss", "kl", "prior_ent", "post_ent"):
+        close(f(mw, k), g["train/" + k], TOL_LOSS if k == "model_loss" else TOL_OUT, k + " vs reference")
+    close(f(mw, "model_grad_norm"), g["train/model_grad_norm"], 2e-4, "model_grad_norm vs reference")
+    for k, tol in (("actor_loss", TOL_LOSS), ("value_loss", TOL_LOSS), ("actor_grad_norm", 3e-4),
+                   ("value_grad_norm", 3e-4), ("actor_entropy", TOL_OUT), ("EMA_005", TOL_OUT), ("EMA_095", TOL_OUT),
+                   ("target_mean", TOL_OUT), ("target_std", TOL_OUT), ("imag_reward_mean", TOL_OUT),
+                   ("value_mean", TOL_OUT)):
+        close(f(mb, k), g["train/" + k], tol, k + " vs reference")
+    # Adam-updated parameters: oracle tensors and the reference's checksums
+    sd = dict(Bv["wm"].state_dict())
+    sd.update({k: v for k, v in Bv["beh"].state_dict().items() if not k.startswith("_world_model.")})
+    lr = {"actor": 3e-5, "value": 3e-5}
+    for k, ref in exp["params_after"].items():
+        if k == "ema_vals":
+            continue
+        if k.startswith("_slow_value."):  # EMA of the critic (models.py:683-689), no optimizer step
+            close(sd[k], ref, 1e-6, "after " + k)
+            checksum_close(sd[k], g["sum/after/" + k], 1e-6, "after checksum vs reference " + k)
+            continue
+        this_lr = lr.get(k.split(".")[0], 1e-4)
+        adam_close(sd[k], ref, this_lr, "after " + k)
+        cs, ref_cs = common.checksum(sd[k].detach().cpu().numpy()), g["sum/after/" + k]
+        n = sd[k].numel()
+        # abs-sum moves by at most (outliers <= 5e-3 n) * 2 lr + n * 2e-6 rounding
+        assert abs(cs[1] - ref_cs[1]) <= n * (2e-6 + 5e-3 * 2.1 * this_lr) + 1e-9, f"after checksum {k}"
+        assert abs(cs[2] - ref_cs[2]) <= 2.1 * this_lr + 2e-6, f"after max {k}"
+
+
+# ------------------------------------------------------------------------------------------------------
 def first_flip(got, ref):
     """got/ref one-hot [B,T,S,D] -> per-row index of the first differing step (T if none)."""
     diff = (got != ref).flatten(2).any(-1)  # [B,T]
     T = diff.shape[1]
-    idx = torch.where(diff.any(1), diff.float().argmax(1), torch.full((diff.shape[0],), T))
-    return idx
+    return torch.where(diff.any(1), diff.float().argmax(1), torch.full((diff.shape[0],), T))
 
 
-def close(got, ref, tol, what):
-    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
-    assert got.shape == ref.shape, (what, got.shape, ref.shape)
-    err = (got - ref).abs().max().item() if got.numel() else 0.0
-    scale = max(1.0, ref.abs().max().item() if ref.numel() else 1.0)
-    assert err <= tol * scale, f"{what}: max err {err:.3e} (scale {scale:.3e})"
-
-
-@pytest.fixture(scope="module")
-def run():
-    s = common.SHAPES[NAME]
-    cfg, wm, beh = Hh.build_models(NAME)
-    n = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(NAME).items()}
-    noise = dict(q_prior=n["q_prior"], q_post=n["q_post"])
-    data = common.make_batch(NAME)
-    post, ctx, mets = wm._train(data, noise=noise)
-    post = {k: v.clone() for k, v in post.items()}
-    grads = {k: p.grad.clone() for k, p in wm.named_parameters()}
-    out = wm._last["out"]
-    recon = wm.heads["decoder"]._cnn.engine.ws.get("dec.recon", (s["B"] * s["T"], 64, 64, 3)).clone()
-    embed = wm._last["embed"].clone()
-    torch.cuda.synchronize()
-    return dict(s=s, cfg=cfg, wm=wm, beh=beh, post=post, mets=mets, grads=grads, recon=recon, embed=embed,
-                prior_logit=out["prior_logit"].clone(), noise=n, data=data)
-
-
-def test_against_reference_golden_vectors(run):
-    g = np.load(os.path.join(GOLD, NAME + ".npz"), allow_pickle=False)
-    s = run["s"]
-    B, T = s["B"], s["T"]
-    # encoder output of batch rows 0,1 (time-major rows t*B+b on the GPU)
-    emb = run["embed"].transpose(0, 1)[:2]
-    close(emb, torch.from_numpy(g["embed"]), 2e-4, "embed vs reference")
-    post = {k: v[:2].cpu() for k, v in run["post"].items()}
-    ref_stoch = torch.from_numpy(g["post/stoch"])
-    ff = first_flip(post["stoch"], ref_stoch)
-    assert (ff == T).float().mean() >= 0.5, f"sample flips in the golden rows: first flips at {ff.tolist()}"
-    for b in range(2):
+def test_free_running_matches_until_first_flip(full):
+    """No teacher forcing: the posterior of every replay row equals the oracle's up to the row's first sample
+    flip (there should be none); the number of flipped rows is printed and bounded."""
+    name, s, ew = full["name"], full["s"], full["exp"]["wm"]
+    T = s["T"]
+    cfg, wm, beh = Hh.build_models(name)
+    n = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(name).items()}
+    post, _, mets = wm._train(full["data"], noise=dict(q_prior=n["q_prior"], q_post=n["q_post"]))
+    ff = first_flip(post["stoch"].cpu(), ew["post"]["stoch"].detach())
+    flipped = int((ff < T).sum())
+    print(f"\n[{name}] free-running: {flipped}/{s['B']} replay rows with a sample flip (first flips at "
+          f"{[int(x) for x in ff[ff < T]]})")
+    for b in range(s["B"]):
         t_ok = int(ff[b])
-        close(post["logit"][b, :t_ok], torch.from_numpy(g["post/logit"])[b, :t_ok], 2e-4, f"post logit row {b}")
-        close(post["deter"][b, :t_ok], torch.from_numpy(g["post/deter"])[b, :t_ok], 2e-4, f"deter row {b}")
-    if bool((ff == T).all()):
-        # decoded pixels of frames (b=0, t=0..1): GPU rows t*B + 0
-        rec = torch.stack([run["recon"][0], run["recon"][B]], 0)[None]
-        close(rec, torch.from_numpy(g["recon"]), 2e-4, "decoded pixels vs reference")
-    # scalar losses of the reference for this minibatch (a flip anywhere perturbs them slightly)
-    ml, ref_ml = float(run["mets"]["model_loss"]), float(g["model_loss"])
-    assert abs(ml - ref_ml) <= 2e-3 * abs(ref_ml), (ml, ref_ml)
-    gn, ref_gn = float(run["mets"]["model_grad_norm"]), float(g["model_grad_norm"])
-    assert abs(gn - ref_gn) <= 2e-2 * abs(ref_gn), (gn, ref_gn)
+        close(post["logit"][b, :t_ok + 1], ew["post"]["logit"][b, :t_ok + 1], TOL_OUT, f"free-running post logit row {b}")
+        close(post["deter"][b, :t_ok + 1], ew["post"]["deter"][b, :t_ok + 1], TOL_OUT, f"free-running deter row {b}")
+    # a flip needs two ratios within an ulp: with 2*T*S draws per row the expected count is << 1 row
+    assert flipped <= max(1, 0.01 * s["B"]), f"{flipped} rows flipped"
+    if flipped == 0:
+        close(torch.tensor(float(mets["model_loss"])), ew["model_loss"], TOL_LOSS, "free-running model_loss")
 
 
-def test_against_live_oracle_full_update(run):
-    exp = Hh.oracle_update(NAME, threads=min(16, os.cpu_count() or 1))
-    s = run["s"]
-    B, T = s["B"], s["T"]
-    ew = exp["wm"]
-    close(run["embed"].transpose(0, 1), ew["embed"], 2e-4, "embed")
-    ff = first_flip(run["post"]["stoch"].cpu(), ew["post"]["stoch"].detach())
-    clean = ff == T
-    flip_rate = 1.0 - clean.float().mean().item()
-    assert flip_rate <= 0.25, f"too many rows with a sample flip: {flip_rate:.2f}"
-    for k in ("logit", "deter"):
-        got, ref = run["post"][k].cpu(), ew["post"][k].detach()
-        close(got[clean], ref[clean], 3e-4, "post " + k)
-    pl = run["prior_logit"].transpose(0, 1).cpu()
-    close(pl[clean], ew["prior"]["logit"].detach()[clean], 3e-4, "prior logit")
-    if flip_rate == 0.0:
-        close(torch.tensor(float(run["mets"]["model_loss"])), ew["model_loss"], 1e-5, "model_loss")
-        for k, gr in exp["wm_grads"].items():
-            ref = gr
-            got = run["grads"][k]
-            # gradients: relative to the tensor's own scale (sums over 1024 rows / 4M pixels)
-            err = (got.cpu().double() - ref.double()).abs().max().item()
-            assert err <= 2e-3 * max(1e-6, ref.abs().max().item()), f"grad {k}: {err:.3e}"
-        close(torch.tensor(float(run["mets"]["model_grad_norm"])), exp["model_grad_norm"], 1e-3, "grad norm")
-
-
-def test_batch_rows_are_independent(run):
+def test_batch_rows_are_independent(full):
     """Permuting the replay rows (and their noise) permutes the posterior: no cross-row coupling in the
-    scan, the reset blend or the skinny GEMM tiling."""
-    s = run["s"]
+    scan, the reset blend or the few-row GEMM tiling."""
+    name, s = full["name"], full["s"]
     B = s["B"]
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
-    data = {k: v[perm.numpy()] for k, v in run["data"].items()}
-    n = run["noise"]
+    data = {k: v[perm.numpy()] for k, v in full["data"].items()}
+    n = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(name).items()}
     pc = perm.cuda()
+    cfg, wm, beh = Hh.build_models(name)
+    ref_post, _, _ = wm._train(full["data"], noise=dict(q_prior=n["q_prior"], q_post=n["q_post"]))
+    ref = {k: v[pc].clone() for k, v in ref_post.items()}
+    cfg, wm, beh = Hh.build_models(name)
     noise = dict(q_prior=n["q_prior"][:, pc].contiguous(), q_post=n["q_post"][:, pc].contiguous())
-    cfg, wm, beh = Hh.build_models(NAME)
     post, _, _ = wm._train(data, noise=noise)
-    ref = {k: v[pc] for k, v in run["post"].items()}
     assert torch.equal(post["stoch"], ref["stoch"]), "permuted rows sampled differently"
     close(post["logit"], ref["logit"], 1e-6, "permuted logit")
     close(post["deter"], ref["deter"], 1e-6, "permuted deter")
 
 
-def test_graph_replay_matches_eager_and_is_deterministic():
-    """hipGraph replay computes what the eager launch sequence computes; two replays of the same inputs
-    from the same state give the same posterior (sampling uses the device Philox stream)."""
+@pytest.mark.parametrize("name", CONFIGS)
+def test_graph_replay_matches_eager_and_trains(name):
+    """hipGraph replay computes what the eager launch sequence computes (same Philox stream), and a few updates on
+    one minibatch reduce the model loss."""
     import tools
     from dv3hip.graph import UpdateRunner
 
     outs = []
     for use_graph in (False, True):
-        cfg, wm, beh = Hh.build_models(NAME)
+        cfg, wm, beh = Hh.build_models(name)
         tools.default_rng("cuda:0", seed=7)
-        data = {k: torch.from_numpy(v).cuda() for k, v in common.make_batch(NAME).items()}
+        data = {k: torch.from_numpy(v).cuda() for k, v in common.make_batch(name).items()}
         r = UpdateRunner(wm, beh, use_graph=use_graph, warm=1)
+        losses = []
         for _ in range(4):
             r.step(data)
+            losses.append(float(r.last_metrics["model_loss"]))
         torch.cuda.synchronize()
-        outs.append((float(r.last_metrics["model_loss"]), float(r.last_metrics["actor_loss"]),
-                     float(r.last_metrics["value_loss"]), wm.dynamics.W.detach().clone()))
+        assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+        for k in ("actor_loss", "value_loss", "actor_grad_norm", "value_grad_norm", "model_grad_norm"):
+            assert np.isfinite(float(r.last_metrics[k])), k
+        outs.append((losses[-1], float(r.last_metrics["actor_loss"]), float(r.last_metrics["value_loss"]),
+                     wm.dynamics.W.detach().clone()))
     (ml0, al0, vl0, w0), (ml1, al1, vl1, w1) = outs
-    assert np.isfinite([ml0, al0, vl0]).all()
     assert abs(ml0 - ml1) <= 2e-3 * abs(ml0), (ml0, ml1)
     assert abs(vl0 - vl1) <= 2e-2 * max(1.0, abs(vl0)), (vl0, vl1)
     close(w1, w0, 1e-4, "learned initial state after 4 updates")
-
-
-@pytest.mark.parametrize("name", ["cfg1", "cfg3"])
-def test_other_baseline_configs_train(name):
-    """cfg 1 (proprio MLP encoder/decoder) and cfg 3 (deter 1024, 18 discrete actions, reinforce) run full
-    updates with finite, decreasing model loss."""
-    import tools
-    from dv3hip.graph import UpdateRunner
-
-    cfg, wm, beh = Hh.build_models(name)
-    tools.default_rng("cuda:0", seed=3)
-    data = {k: torch.from_numpy(v).cuda() for k, v in common.make_batch(name).items()}
-    r = UpdateRunner(wm, beh, use_graph=False)
-    losses = []
-    for _ in range(6):
-        r.step(data)
-        losses.append(float(r.last_metrics["model_loss"]))
-    assert np.isfinite(losses).all(), losses
-    assert losses[-1] < losses[0], losses
-    for k in ("actor_loss", "value_loss", "actor_grad_norm", "value_grad_norm", "model_grad_norm"):
-        assert np.isfinite(float(r.last_metrics[k])), k

@@ -200,28 +200,49 @@ def test_full_update_matches_reference_train(name):
         close(p[k], g["after/" + k], tol=1e-6, what="after/" + k)
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg1"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg1", "cfg3"])
 def test_full_size_slices_and_checksums(name):
-    """Full-size configs: stored row slices + whole-tensor checksums of the reference's outputs."""
+    """Full-size configs: stored row slices + whole-tensor checksums of the reference's outputs, world model and
+    behaviour (imagination rows, lambda-returns, losses) -- this is what pins the oracle the GPU tests use at
+    BASELINE sizes (cfg 3: deter 1024, 18-way one-hot actor, reinforce, batch 32)."""
     g = load(name)
     torch.set_num_threads(max(1, os.cpu_count() or 1))
-    cfg, p, n, data, out = wm_out(name)
+    with torch.no_grad():
+        cfg, p, n, data, out = wm_out(name)
     sel = slice(0, 2)
     close(out["embed"][sel], g["embed"], tol=1e-4, what="embed")
-    # free-running 64-step sampled rollout: identical noise, allow (and count) sample flips
-    same = np.array_equal(out["post"]["stoch"][sel].numpy(), g["post/stoch"])
-    if same:
-        for k in ("deter", "logit"):
-            close(out["post"][k][sel], g["post/" + k], tol=1e-4, what="post/" + k)
-            close(out["prior"][k][sel], g["prior/" + k], tol=1e-4, what="prior/" + k)
-        close(out["model_loss"], g["model_loss"], tol=1e-5, what="model_loss")
-        check_sum(g, "post/logit", out["post"]["logit"].numpy())
-        if cfg.encoder == "cnn":
-            check_sum(g, "recon", out["recon"].numpy())
-    else:  # pragma: no cover - host-dependent
-        # a flip changes the row's future; teacher-forced comparison covers this in the GPU tests
-        flips = (out["post"]["stoch"][sel].numpy() != g["post/stoch"]).any(-1).any(-1).mean()
-        assert flips < 0.05, f"too many sample flips vs reference: {flips}"
+    # free-running 64-step sampled rollout on identical noise: the oracle's draws must be the reference's (same
+    # host, same torch ops); a host on which an ulp flips a draw reports it here
+    assert np.array_equal(out["post"]["stoch"][sel].numpy(), g["post/stoch"]), "oracle draws differ from the reference"
+    for k in ("deter", "logit"):
+        close(out["post"][k][sel], g["post/" + k], tol=1e-4, what="post/" + k)
+        close(out["prior"][k][sel], g["prior/" + k], tol=1e-4, what="prior/" + k)
+    close(out["model_loss"], g["model_loss"], tol=1e-5, what="model_loss")
+    check_sum(g, "post/logit", out["post"]["logit"].numpy())
+    for k, v in out["losses"].items():
+        close(v, g["loss/" + k], tol=1e-4, what="loss/" + k)
+    if cfg.encoder == "cnn":
+        check_sum(g, "recon", out["recon"].numpy())
+    # behaviour on the (not yet updated) world model: the golden file's imag/* pieces
+    start = {k: v.detach() for k, v in out["post"].items()}
+    ema = torch.zeros(2)
+    with torch.no_grad():
+        b = O.behavior_forward(cfg, p, start, n["act"], n["q_img"], ema)
+    r8 = (slice(None), slice(0, 8))
+    assert np.array_equal(b["states"]["stoch"][r8].numpy(), g["imag/stoch"]), "imagined draws differ from the reference"
+    close(b["states"]["deter"][r8], g["imag/deter"], tol=1e-4, what="imag/deter")
+    close(b["actions"][r8], g["imag/action"], tol=1e-4, what="imag/action")
+    close(b["reward"][r8], g["imag/reward"], tol=1e-4, what="imag/reward")
+    close(b["value"][r8], g["imag/value"], tol=1e-4, what="imag/value")
+    close(b["target"][r8], g["imag/target"], tol=1e-4, what="imag/target")
+    close(b["weights"][r8], g["imag/weights"], tol=1e-4, what="imag/weights")
+    close(b["actor_ent"][r8], g["imag/actor_ent"], tol=1e-4, what="imag/actor_ent")
+    check_sum(g, "imag/target", b["target"].numpy())
+    check_sum(g, "imag/deter", b["states"]["deter"].numpy())
+    close(b["actor_loss"], g["actor_loss"], tol=1e-5, what="actor_loss")
+    close(b["value_loss"], g["value_loss"], tol=1e-5, what="value_loss")
+    # (the file's ema_vals_after belongs to the full _train update that make_golden.py runs afterwards: the stored
+    # array aliases the module buffer; it is compared in the full-update tests)
 
 
 @pytest.mark.parametrize("name", ["tiny", "cfg2"])

@@ -58,6 +58,8 @@ def test_world_model_forward(tiny_run):
     close(torch.tensor(float(m["post_ent"])), exp["post_ent"].mean(), what="post_ent")
     close(torch.tensor(float(m["reward_loss"])), exp["losses"]["reward"].mean(), what="reward_loss")
     close(torch.tensor(float(m["cont_loss"])), exp["losses"]["cont"].mean(), what="cont_loss")
+    for k in exp["losses"]:  # every decoder key logs its OWN -log_prob mean (models.py:150)
+        close(torch.tensor(float(m[k + "_loss"])), exp["losses"][k].mean(), what=k + "_loss")
 
 
 def test_world_model_gradients_and_adam_step(tiny_run):
