@@ -1,0 +1,432 @@
+// Row-fused kernels of the imagination step (models.ImagBehavior._imagine, models.py:448-548, and the layers
+// it drives: networks.RSSM.img_step networks.py:208-233, networks.MLP.forward networks.py:657-681).
+//
+// 1. onehot_linear_ln: a Linear whose input is [stoch | dense tail] (the reference's
+//    torch.cat([stoch.flat, action]) at networks.py:216, get_feat at networks.py:154-159) with the stoch part an
+//    EXACT one-hot per categorical group (tools.py:452-460: the forward value of OneHotDist.sample is
+//    one_hot(argmax) + (p - p.detach()) = a one-hot).  x @ W^T over the stoch columns is therefore the sum of S
+//    columns of W -- S rows of the transposed weight -- picked by the class indices: S*N adds per row instead of
+//    S*D*N multiply-adds (1/32 of the GEMM at D = 32), an L2-resident gather instead of an MFMA launch.  A wave owns
+//    a whole output row, so the LayerNorm + SiLU that follows the Linear (networks.py:55-56, 631-633) is fused:
+//    one launch replaces GEMM + LN.  The dense part of a wider input (deter for the MLP heads, whose first layer
+//    reads feat = [stoch | deter]) comes in as `base` from a K = deter GEMM.
+// 2. actor_head: LayerNorm + SiLU of the actor trunk's last layer, its mean/std (or logit) heads, the action
+//    sample and the entropy in one row-wise launch (networks.py:672-681, 693-700, 713-714, tools.py:594-598)
+//    instead of LN, two narrow GEMMs, the noise fill and the sampling kernel.
+// 3. helpers: 2-D transpose (weights -> [K][N] for the gather), one-hot -> class index.
+//
+// HBM/L2-bound row kernels: wave per row, 16 B per lane, statistics two-pass in registers (as rowops.hip).
+#include "dv3_common.h"
+
+namespace dv3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct OLParams {
+  const int* idx;  // [M][S] class index of every categorical group
+  int S, D;
+  const float* x2;  // dense tail inputs [M][A2] (action) or null
+  long ldx2;
+  int A2;
+  const float* WT;  // transposed weight [S*D + A2][N]
+  long ldw;
+  const float* base;  // optional [M][N] added first (product of the remaining input columns)
+  long ldbase;
+  float* pre;  // pre-activation out [M][N] (may alias base)
+  long ldpre;
+  const float* gamma;
+  const float* beta;
+  float* y;  // SiLU(LN(pre)) out, or null: only pre is produced
+  long ldy;
+  float* mean;
+  float* rstd;
+  long M;
+  int N;
+  int act;
+};
+
+// N == 256 * NV4: lane l owns columns 4*(l + 64 v) .. +3
+template <int NV4>
+__global__ __launch_bounds__(256) void onehot_linear_ln_vec_kernel(OLParams p) {
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const float inv_n = 1.f / (float)p.N;
+  f32x4 g[NV4], b[NV4];
+  if (p.y) {
+#pragma unroll
+    for (int v = 0; v < NV4; ++v) {
+      g[v] = *reinterpret_cast<const f32x4u*>(p.gamma + 4 * (l + 64 * v));
+      b[v] = *reinterpret_cast<const f32x4u*>(p.beta + 4 * (l + 64 * v));
+    }
+  }
+  for (long r = (long)blockIdx.x * 4 + wave; r < p.M; r += (long)gridDim.x * 4) {
+    const int my = (l < p.S) ? p.idx[r * p.S + l] : 0;
+    f32x4 acc[NV4];
+#pragma unroll
+    for (int v = 0; v < NV4; ++v) {
+      if (p.base) acc[v] = *reinterpret_cast<const f32x4u*>(p.base + r * p.ldbase + 4 * (l + 64 * v));
+      else acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 8
+    for (int s = 0; s < p.S; ++s) {
+      const int id = __shfl(my, s, 64);
+      const float* w = p.WT + (long)(s * p.D + id) * p.ldw + 4 * l;
+#pragma unroll
+      for (int v = 0; v < NV4; ++v) acc[v] += *reinterpret_cast<const f32x4u*>(w + 256 * v);
+    }
+    for (int a = 0; a < p.A2; ++a) {
+      const float xa = p.x2[r * p.ldx2 + a];
+      const float* w = p.WT + (long)(p.S * p.D + a) * p.ldw + 4 * l;
+#pragma unroll
+      for (int v = 0; v < NV4; ++v) acc[v] += xa * *reinterpret_cast<const f32x4u*>(w + 256 * v);
+    }
+#pragma unroll
+    for (int v = 0; v < NV4; ++v) *reinterpret_cast<f32x4u*>(p.pre + r * p.ldpre + 4 * (l + 64 * v)) = acc[v];
+    if (!p.y) continue;
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV4; ++v) s += (acc[v][0] + acc[v][1]) + (acc[v][2] + acc[v][3]);
+    const float mean = group_sum<64>(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV4; ++v)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = acc[v][e] - mean;
+        q += d * d;
+      }
+    const float rstd = rsqrtf(group_sum<64>(q) * inv_n + kLnEps);
+#pragma unroll
+    for (int v = 0; v < NV4; ++v) {
+      f32x4 z;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = (acc[v][e] - mean) * rstd * g[v][e] + b[v][e];
+        z[e] = p.act ? siluf_(t) : t;
+      }
+      *reinterpret_cast<f32x4u*>(p.y + r * p.ldy + 4 * (l + 64 * v)) = z;
+    }
+    if (l == 0) {
+      if (p.mean) p.mean[r] = mean;
+      if (p.rstd) p.rstd[r] = rstd;
+    }
+  }
+}
+
+// any N (the tiny test configs, odd widths): a workgroup per row, columns strided over its 256 threads; the
+// pre-activation makes its passes through global memory (every thread re-reads only what it wrote)
+__global__ __launch_bounds__(256) void onehot_linear_ln_generic_kernel(OLParams p) {
+  __shared__ float red[4];
+  __shared__ int sidx[64];
+  const int tid = threadIdx.x;
+  const float inv_n = 1.f / (float)p.N;
+  for (long r = blockIdx.x; r < p.M; r += gridDim.x) {
+    __syncthreads();
+    if (tid < p.S) sidx[tid] = p.idx[r * p.S + tid];
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid; c < p.N; c += 256) {
+      float v = p.base ? p.base[r * p.ldbase + c] : 0.f;
+      for (int k = 0; k < p.S; ++k) v += p.WT[(long)(k * p.D + sidx[k]) * p.ldw + c];
+      for (int a = 0; a < p.A2; ++a) v += p.x2[r * p.ldx2 + a] * p.WT[(long)(p.S * p.D + a) * p.ldw + c];
+      p.pre[r * p.ldpre + c] = v;
+      s += v;
+    }
+    if (!p.y) continue;  // uniform
+    const float mean = block_sum_256(s, red) * inv_n;
+    float q = 0.f;
+    for (int c = tid; c < p.N; c += 256) {
+      const float d = p.pre[r * p.ldpre + c] - mean;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(block_sum_256(q, red) * inv_n + kLnEps);
+    for (int c = tid; c < p.N; c += 256) {
+      const float t = (p.pre[r * p.ldpre + c] - mean) * rstd * p.gamma[c] + p.beta[c];
+      p.y[r * p.ldy + c] = p.act ? siluf_(t) : t;
+    }
+    if (tid == 0) {
+      if (p.mean) p.mean[r] = mean;
+      if (p.rstd) p.rstd[r] = rstd;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+struct AHParams {
+  const float* pre;  // [M][U] pre-activation of the trunk's last Linear
+  long ldpre;
+  const float* gamma;
+  const float* beta;
+  float* y;  // SiLU(LN(pre)) out [M][U] (saved: the heads' weight gradients read it)
+  long ldy;
+  float* mean;
+  float* rstd;
+  const float* Wm;  // [A][U]
+  const float* bm;
+  const float* Ws;  // [A][U] std head (continuous actor) or null
+  const float* bs;
+  float* out_m;  // raw head outputs [M][A] (saved for the backward)
+  float* out_s;
+  const float* noise;  // [M][A]: N(0,1) (continuous) / Exp(1) (one-hot); null -> Philox
+  const unsigned long long* rng;
+  unsigned long long rng_off;
+  float* eps_out;  // continuous: the noise used [M][A] (saved for the backward); may alias noise
+  float* action;   // [M][A]
+  float* ent;      // [M]
+  int* act_idx;    // one-hot actor: chosen class [M] (optional)
+  const int* forced;
+  unsigned int* flips;
+  long M;
+  int U, A;
+  float min_std, max_std, unimix;
+  int onehot;
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void actor_head_kernel(AHParams p) {
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const float inv_n = 1.f / (float)p.U;
+  float g[NV], b[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = l + 64 * v;
+    g[v] = c < p.U ? p.gamma[c] : 0.f;
+    b[v] = c < p.U ? p.beta[c] : 0.f;
+  }
+  unsigned long long seed = 0, offset = 0;
+  if (!p.noise) {
+    seed = p.rng[0];
+    offset = p.rng[1] + p.rng_off;
+  }
+  for (long r = (long)blockIdx.x * 4 + wave; r < p.M; r += (long)gridDim.x * 4) {
+    float x[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = l + 64 * v;
+      x[v] = c < p.U ? p.pre[r * p.ldpre + c] : 0.f;
+      s += x[v];
+    }
+    const float mean = group_sum<64>(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const float d = (l + 64 * v < p.U) ? x[v] - mean : 0.f;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(group_sum<64>(q) * inv_n + kLnEps);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = l + 64 * v;
+      x[v] = c < p.U ? siluf_((x[v] - mean) * rstd * g[v] + b[v]) : 0.f;
+      if (c < p.U) p.y[r * p.ldy + c] = x[v];
+    }
+    if (l == 0) {
+      if (p.mean) p.mean[r] = mean;
+      if (p.rstd) p.rstd[r] = rstd;
+    }
+    // heads: lane a keeps output a
+    float mr = 0.f, sr = 0.f;
+    for (int a = 0; a < p.A; ++a) {
+      float dm = 0.f, ds = 0.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = l + 64 * v;
+        if (c < p.U) {
+          dm += x[v] * p.Wm[(long)a * p.U + c];
+          if (p.Ws) ds += x[v] * p.Ws[(long)a * p.U + c];
+        }
+      }
+      dm = group_sum<64>(dm);
+      if (p.Ws) ds = group_sum<64>(ds);
+      if (l == a) {
+        mr = dm + p.bm[a];
+        if (p.Ws) sr = ds + p.bs[a];
+      }
+    }
+    const bool valid = l < p.A;
+    const long e = r * p.A + l;
+    if (valid) {
+      p.out_m[e] = mr;
+      if (p.out_s) p.out_s[e] = sr;
+    }
+    if (!p.onehot) {
+      // Normal(tanh(mean), (max-min)*sigmoid(std+2)+min), rsample, absmax-1 rescale (tools.py:594-598)
+      float en = 0.f;
+      if (valid) {
+        float eps;
+        if (p.noise) {
+          eps = p.noise[e];
+        } else {  // the element fill_normal_kernel would have produced: Box-Muller over Philox counter e >> 2
+          uint32_t o[4];
+          Philox ph(seed);
+          ph(offset + ((unsigned long long)e >> 2), 0x6e6f726dULL, o);
+          const int j = (int)(e & 3);
+          const float rad = sqrtf(-2.f * logf(u01(o[j & 2])));
+          const float ang = 6.283185307179586f * u01(o[(j & 2) + 1]);
+          eps = (j & 1) ? rad * sinf(ang) : rad * cosf(ang);
+        }
+        if (p.eps_out) p.eps_out[e] = eps;
+        const float mu = tanhf(mr);
+        const float sd = (p.max_std - p.min_std) * sigmoidf_(sr + 2.f) + p.min_std;
+        const float pre = mu + sd * eps;
+        p.action[e] = pre * (1.f / fmaxf(fabsf(pre), 1.f));
+        en = 0.5f + 0.9189385332046727f + logf(sd);
+      }
+      en = group_sum<64>(en);
+      if (l == 0 && p.ent) p.ent[r] = en;
+    } else {
+      // OneHotDist(logits, unimix): sample = onehot(argmax p_hat / q), entropy of p_hat (tools.py:436-460)
+      const float m = group_max<64>(valid ? mr : -INFINITY);
+      const float ex = valid ? expf(mr - m) : 0.f;
+      const float sm = ex / group_sum<64>(ex);
+      const float ph = valid ? sm * (1.f - p.unimix) + p.unimix / (float)p.A : 0.f;
+      float qv = 1.f;
+      if (valid) {
+        if (p.noise) {
+          qv = p.noise[e];
+        } else {
+          uint32_t o[4];
+          Philox ph4(seed);
+          ph4(offset + ((unsigned long long)e >> 2), 0x5eedULL, o);
+          qv = fmaxf(-logf(u01(o[e & 3])), 1e-30f);
+        }
+      }
+      float best = valid ? ph / qv : -INFINITY;
+      int bi = l;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+          best = ob;
+          bi = oi;
+        }
+      }
+      if (p.forced) {
+        const int f = p.forced[r];
+        if (l == 0 && p.flips && f != bi) atomicAdd(p.flips, 1u);
+        bi = f;
+      }
+      if (valid) p.action[e] = (l == bi) ? 1.f : 0.f;
+      if (l == 0 && p.act_idx) p.act_idx[r] = bi;
+      const float en = group_sum<64>(valid ? -ph * logf(ph) : 0.f);
+      if (l == 0 && p.ent) p.ent[r] = en;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// dst[c][r] = src[r][c]   (weights [N][K] -> [K][N] for the gather; 32x32 tiles through LDS)
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, long lds_, int R, int C,
+                                                          float* __restrict__ dst, long ldd) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int r = r0 + ty + j, c = c0 + tx;
+    tile[ty + j][tx] = (r < R && c < C) ? src[(long)r * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int c = c0 + ty + j, r = r0 + tx;
+    if (c < C && r < R) dst[(long)c * ldd + r] = tile[tx][ty + j];
+  }
+}
+
+// class index of every one-hot group: idx[g] = argmax_d x[g][d] (lowest index on ties)
+__global__ __launch_bounds__(256) void onehot_to_idx_kernel(const float* __restrict__ x, int* __restrict__ idx, long R,
+                                                            int D) {
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < R; g += (long)gridDim.x * 256) {
+    const float* row = x + g * D;
+    int bi = 0;
+    float best = row[0];
+    for (int d = 1; d < D; ++d)
+      if (row[d] > best) {
+        best = row[d];
+        bi = d;
+      }
+    idx[g] = bi;
+  }
+}
+
+static unsigned cap_grid(long n, long per_block, long cap) {
+  long b = (n + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace dv3
+
+using namespace dv3;
+
+extern "C" int dv3_onehot_linear_ln_fwd(const int* idx, int S, int D, const float* x2, long ldx2, int A2,
+                                        const float* WT, long ldw, const float* base, long ldbase, float* pre,
+                                        long ldpre, const float* gamma, const float* beta, float* y, long ldy,
+                                        float* mean, float* rstd, long M, int N, int act, void* stream) {
+  if (M <= 0) return 0;
+  if (!idx || !WT || !pre || S <= 0 || S > 64 || D <= 0 || N <= 0 || A2 < 0 || (A2 > 0 && !x2) || ldw < N ||
+      ldpre < N || (base && ldbase < N))
+    return DV3_ERR_ARG;
+  if (y && (!gamma || !beta || ldy < N)) return DV3_ERR_ARG;
+  OLParams p{idx, S, D, x2, ldx2, A2, WT, ldw, base, ldbase, pre, ldpre, gamma, beta, y, ldy, mean, rstd, M, N, act};
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (N % 256 == 0) && N <= 1024 && (ldw % 4 == 0) && (ldpre % 4 == 0) && (!base || ldbase % 4 == 0) &&
+                   (!y || ldy % 4 == 0);
+  if (vec) {
+    const dim3 grid(cap_grid(M, 4, 16384)), block(256);
+    switch (N / 256) {
+      case 1: hipLaunchKernelGGL((onehot_linear_ln_vec_kernel<1>), grid, block, 0, s, p); break;
+      case 2: hipLaunchKernelGGL((onehot_linear_ln_vec_kernel<2>), grid, block, 0, s, p); break;
+      case 3: hipLaunchKernelGGL((onehot_linear_ln_vec_kernel<3>), grid, block, 0, s, p); break;
+      default: hipLaunchKernelGGL((onehot_linear_ln_vec_kernel<4>), grid, block, 0, s, p); break;
+    }
+  } else {
+    hipLaunchKernelGGL(onehot_linear_ln_generic_kernel, dim3(cap_grid(M, 1, 16384)), dim3(256), 0, s, p);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_actor_head_fwd(const float* pre, long ldpre, const float* gamma, const float* beta, float* y,
+                                  long ldy, float* mean, float* rstd, const float* Wm, const float* bm,
+                                  const float* Ws, const float* bs, float* out_m, float* out_s, const float* noise,
+                                  const unsigned long long* rng_state, unsigned long long rng_offset, float* eps_out,
+                                  float* action, float* entropy, int* act_idx, const int* forced,
+                                  unsigned int* flips, long M, int U, int A, float min_std, float max_std,
+                                  float unimix, int onehot, void* stream) {
+  if (M <= 0) return 0;
+  if (!pre || !gamma || !beta || !y || !Wm || !bm || !out_m || !action || U <= 0 || U > 1024 || A <= 0 || A > 64 ||
+      ldpre < U || ldy < U)
+    return DV3_ERR_ARG;
+  if (!onehot && (!Ws || !bs || !out_s)) return DV3_ERR_ARG;
+  if (onehot && Ws) return DV3_ERR_ARG;
+  if (!noise && !rng_state) return DV3_ERR_ARG;
+  AHParams p{pre, ldpre, gamma, beta, y, ldy, mean, rstd, Wm, bm, Ws, bs, out_m, out_s, noise, rng_state, rng_offset,
+             eps_out, action, entropy, act_idx, forced, flips, M, U, A, min_std, max_std, unimix, onehot};
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(cap_grid(M, 4, 16384)), block(256);
+  if (U <= 64) hipLaunchKernelGGL((actor_head_kernel<1>), grid, block, 0, s, p);
+  else if (U <= 256) hipLaunchKernelGGL((actor_head_kernel<4>), grid, block, 0, s, p);
+  else if (U <= 512) hipLaunchKernelGGL((actor_head_kernel<8>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((actor_head_kernel<16>), grid, block, 0, s, p);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_transpose2d(const float* src, long lds, int R, int C, float* dst, long ldd, void* stream) {
+  if (R <= 0 || C <= 0) return 0;
+  if (!src || !dst || lds < C || ldd < R) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(transpose2d_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
+                     lds, R, C, dst, ldd);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_onehot_to_idx(const float* onehot, int* idx, long R, int D, void* stream) {
+  if (R <= 0) return 0;
+  if (!onehot || !idx || D <= 0) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(onehot_to_idx_kernel, dim3(cap_grid(R, 256, 4096)), dim3(256), 0, (hipStream_t)stream, onehot,
+                     idx, R, D);
+  return (int)hipGetLastError();
+}

@@ -618,7 +618,7 @@ class ImagBehavior(nn.Module):
         # ---- metrics + optimizers
         ops.dot_accumulate(ent.view(HN), acc[2:3], scale=1.0 / HN)
         metrics = {}
-        metrics.update(tools.tensorstats(value, "value"))
+        metrics.update(tools.tensorstats(value[:-1], "value"))  # the critic on feat[:-1] (models.py:419, 431)
         metrics.update(tools.tensorstats(target, "target"))
         metrics.update(tools.tensorstats(reward, "imag_reward"))
         if normal:

@@ -28,7 +28,8 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CONFIGS = ["cfg2", "cfg1", "cfg3"]
 # fp32 tolerances (north_star: outputs within 1e-4), relative to max(1, max|ref|) of the tensor compared
 TOL_OUT = 1e-4  # logits, deter, pixels, returns, values, rewards, actions
-TOL_LOSS = 2e-5  # scalar losses (means over >= 1024 rows)
+TOL_LOSS = 2e-5  # scalar losses (means over >= 1024 rows) against the live oracle
+TOL_LOSS_REF = 5e-5  # ... against the reference's own float32 scalar (its CPU summation order differs again)
 TOL_GRAD = 1e-3  # gradients, relative to the gradient tensor's own max (sums over 1024..15360 rows / 4M pixels)
 MAX_FLIP_RATE = 1e-5  # per categorical draw
 
@@ -102,7 +103,7 @@ def full(request):
     TB = s["B"] * s["T"]
     A["lp_r"], A["lp_c"] = ws.get("wm.lp_r", (TB,)).clone(), ws.get("wm.lp_c", (TB,)).clone()
     if s["encoder"] == "cnn":
-        A["recon"] = ws.get("dec.recon", (TB, 64, 64, 3)).clone()
+        A["recon"] = wm.heads["decoder"]._cnn.engine.ws.get("dec.recon", (TB, 64, 64, 3)).clone()
         A["loss_img"] = ws.get("wm.loss_img", (TB,)).clone()
     else:
         A["loss_vec"] = {k: ws.get(f"wm.loss.{k}", (TB,)).clone() for k, _ in common.PROPRIO_KEYS}
@@ -221,8 +222,8 @@ def test_imagination_and_returns_vs_oracle_and_reference(full):
     close(r8(A["last"]["target"])[..., None], g["imag/target"], TOL_OUT, "lambda-return vs reference")
     close(r8(A["weights"]), g["imag/weights"], TOL_OUT, "weights vs reference")
     close(r8(A["ent"]), g["imag/actor_ent"], TOL_OUT, "actor entropy vs reference")
-    close(A["actor_loss"], g["actor_loss"], TOL_LOSS, "actor_loss vs reference")
-    close(A["value_loss"], g["value_loss"], TOL_LOSS, "value_loss vs reference")
+    close(A["actor_loss"], g["actor_loss"], TOL_LOSS_REF, "actor_loss vs reference")
+    close(A["value_loss"], g["value_loss"], TOL_LOSS_REF, "value_loss vs reference")
     # whole-tensor pins of the reference (sum, abs-sum, max over all 15 x N rows)
     checksum_close(un(A["last"]["target"]), g["sum/imag/target"], 2e-4, "lambda-return checksum vs reference")
     checksum_close(un(A["last"]["reward"]), g["sum/imag/reward"], 2e-4, "reward checksum vs reference")
@@ -264,7 +265,7 @@ def test_full_update_vs_oracle_and_reference(full):
     for k in ("model_loss", "kl", "prior_ent", "post_ent"):
         close(f(mw, k), g["train/" + k], TOL_LOSS if k == "model_loss" else TOL_OUT, k + " vs reference")
     close(f(mw, "model_grad_norm"), g["train/model_grad_norm"], 2e-4, "model_grad_norm vs reference")
-    for k, tol in (("actor_loss", TOL_LOSS), ("value_loss", TOL_LOSS), ("actor_grad_norm", 3e-4),
+    for k, tol in (("actor_loss", TOL_LOSS_REF), ("value_loss", TOL_LOSS_REF), ("actor_grad_norm", 3e-4),
                    ("value_grad_norm", 3e-4), ("actor_entropy", TOL_OUT), ("EMA_005", TOL_OUT), ("EMA_095", TOL_OUT),
                    ("target_mean", TOL_OUT), ("target_std", TOL_OUT), ("imag_reward_mean", TOL_OUT),
                    ("value_mean", TOL_OUT)):
