@@ -9,16 +9,6 @@
 
 namespace dv3 {
 
-// p_hat = (1-u) softmax(l) + u/D for the lane's class; also returns the plain softmax value
-template <int G>
-__device__ __forceinline__ void unimix_probs(float l, bool valid, int D, float unimix, float& sm, float& ph) {
-  const float m = group_max<G>(valid ? l : -INFINITY);
-  const float e = valid ? expf(l - m) : 0.f;
-  const float s = group_sum<G>(e);
-  sm = e / s;
-  ph = valid ? sm * (1.f - unimix) + unimix / (float)D : 0.f;
-}
-
 // sample: idx = argmax_d p_hat[d] / q[d], q ~ Exp(1) (the single-draw path of torch.multinomial);
 // mode: idx = argmax_d p_hat[d].  Ties resolve to the lowest class index, as torch.argmax does.
 // forced (optional, [R]): the class to emit instead of the kernel's own draw; flips counts the disagreements.

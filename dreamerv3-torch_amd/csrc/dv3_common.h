@@ -32,6 +32,17 @@ __device__ __forceinline__ float group_max(float v) {
   return v;
 }
 
+// One-hot categorical with uniform mixing (tools.py:436-442), one class per lane in a group of G lanes:
+// p_hat = (1-u) softmax(l) + u/D for the lane's class; also returns the plain softmax value
+template <int G>
+__device__ __forceinline__ void unimix_probs(float l, bool valid, int D, float unimix, float& sm, float& ph) {
+  const float m = group_max<G>(valid ? l : -INFINITY);
+  const float e = valid ? expf(l - m) : 0.f;
+  const float s = group_sum<G>(e);
+  sm = e / s;
+  ph = valid ? sm * (1.f - unimix) + unimix / (float)D : 0.f;
+}
+
 // block-wide sum for 256-thread workgroups (4 waves); `red` is >= 4 floats of LDS
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   v = group_sum<64>(v);

@@ -46,42 +46,64 @@ struct OLParams {
   int act;
 };
 
-// N == 256 * NV4: lane l owns columns 4*(l + 64 v) .. +3
+// N == 256 * NV4.  One workgroup (4 waves) per output row: wave w gathers the rows s = w, w+4, ... of its share in
+// ONE batch of independent 16-byte loads (lane l owns columns 4*(l + 64 v) .. +3), the four partial rows meet in
+// LDS, and every wave then sums them in the same fixed order and normalises -- one memory round trip and one
+// barrier per row (a wave per row needed S / 8 dependent round trips at one wave per SIMD).
 template <int NV4>
 __global__ __launch_bounds__(256) void onehot_linear_ln_vec_kernel(OLParams p) {
+  __shared__ __attribute__((aligned(16))) float part[4][256 * NV4];
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const float inv_n = 1.f / (float)p.N;
-  f32x4 g[NV4], b[NV4];
-  if (p.y) {
-#pragma unroll
-    for (int v = 0; v < NV4; ++v) {
-      g[v] = *reinterpret_cast<const f32x4u*>(p.gamma + 4 * (l + 64 * v));
-      b[v] = *reinterpret_cast<const f32x4u*>(p.beta + 4 * (l + 64 * v));
-    }
-  }
-  for (long r = (long)blockIdx.x * 4 + wave; r < p.M; r += (long)gridDim.x * 4) {
+  constexpr int MAXB = 8;  // gathered rows per wave and batch (S <= 32: one batch)
+  for (long r = blockIdx.x; r < p.M; r += gridDim.x) {
     const int my = (l < p.S) ? p.idx[r * p.S + l] : 0;
     f32x4 acc[NV4];
 #pragma unroll
-    for (int v = 0; v < NV4; ++v) {
-      if (p.base) acc[v] = *reinterpret_cast<const f32x4u*>(p.base + r * p.ldbase + 4 * (l + 64 * v));
-      else acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll 8
-    for (int s = 0; s < p.S; ++s) {
-      const int id = __shfl(my, s, 64);
-      const float* w = p.WT + (long)(s * p.D + id) * p.ldw + 4 * l;
+    for (int v = 0; v < NV4; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (wave == 0 && p.base) {
 #pragma unroll
-      for (int v = 0; v < NV4; ++v) acc[v] += *reinterpret_cast<const f32x4u*>(w + 256 * v);
+      for (int v = 0; v < NV4; ++v) acc[v] = *reinterpret_cast<const f32x4u*>(p.base + r * p.ldbase + 4 * (l + 64 * v));
     }
-    for (int a = 0; a < p.A2; ++a) {
+    for (int s0 = wave; s0 < p.S; s0 += 4 * MAXB) {
+      f32x4 t[MAXB][NV4];
+#pragma unroll
+      for (int u = 0; u < MAXB; ++u) {
+        const int s = s0 + 4 * u;
+        if (s < p.S) {  // wave-uniform
+          const int id = __builtin_amdgcn_readlane(my, s);
+          const float* w = p.WT + (long)(s * p.D + id) * p.ldw + 4 * l;
+#pragma unroll
+          for (int v = 0; v < NV4; ++v) t[u][v] = *reinterpret_cast<const f32x4u*>(w + 256 * v);
+        } else {
+#pragma unroll
+          for (int v = 0; v < NV4; ++v) t[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < MAXB; ++u)
+#pragma unroll
+        for (int v = 0; v < NV4; ++v) acc[v] += t[u][v];
+    }
+    for (int a = wave; a < p.A2; a += 4) {
       const float xa = p.x2[r * p.ldx2 + a];
       const float* w = p.WT + (long)(p.S * p.D + a) * p.ldw + 4 * l;
 #pragma unroll
       for (int v = 0; v < NV4; ++v) acc[v] += xa * *reinterpret_cast<const f32x4u*>(w + 256 * v);
     }
+    __syncthreads();  // the previous row's readers are done with `part`
 #pragma unroll
-    for (int v = 0; v < NV4; ++v) *reinterpret_cast<f32x4u*>(p.pre + r * p.ldpre + 4 * (l + 64 * v)) = acc[v];
+    for (int v = 0; v < NV4; ++v) *reinterpret_cast<f32x4*>(&part[wave][4 * (l + 64 * v)]) = acc[v];
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV4; ++v) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&part[0][4 * (l + 64 * v)]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&part[1][4 * (l + 64 * v)]);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(&part[2][4 * (l + 64 * v)]);
+      const f32x4 a3 = *reinterpret_cast<const f32x4*>(&part[3][4 * (l + 64 * v)]);
+      acc[v] = (a0 + a1) + (a2 + a3);
+      if ((v & 3) == wave) *reinterpret_cast<f32x4u*>(p.pre + r * p.ldpre + 4 * (l + 64 * v)) = acc[v];
+    }
     if (!p.y) continue;
     float s = 0.f;
 #pragma unroll
@@ -98,15 +120,18 @@ __global__ __launch_bounds__(256) void onehot_linear_ln_vec_kernel(OLParams p) {
     const float rstd = rsqrtf(group_sum<64>(q) * inv_n + kLnEps);
 #pragma unroll
     for (int v = 0; v < NV4; ++v) {
+      if ((v & 3) != wave) continue;  // wave-uniform
+      const f32x4 g = *reinterpret_cast<const f32x4u*>(p.gamma + 4 * (l + 64 * v));
+      const f32x4 b = *reinterpret_cast<const f32x4u*>(p.beta + 4 * (l + 64 * v));
       f32x4 z;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float t = (acc[v][e] - mean) * rstd * g[v][e] + b[v][e];
+        const float t = (acc[v][e] - mean) * rstd * g[e] + b[e];
         z[e] = p.act ? siluf_(t) : t;
       }
       *reinterpret_cast<f32x4u*>(p.y + r * p.ldy + 4 * (l + 64 * v)) = z;
     }
-    if (l == 0) {
+    if (threadIdx.x == 0) {
       if (p.mean) p.mean[r] = mean;
       if (p.rstd) p.rstd[r] = rstd;
     }
@@ -182,9 +207,23 @@ struct AHParams {
   int onehot;
 };
 
+// wlds != 0: the head weights ([A][U] mean rows, then [A][U] std rows) are first copied into dynamic LDS by the whole
+// workgroup: every wave of the chip walks the same 2A weight rows in step, and from global memory that is 2A
+// dependent round trips onto the same few cache lines (measured 26-36 us for 1024 rows; the L2 channels holding
+// those lines serialise the 256 CUs).
 template <int NV>
-__global__ __launch_bounds__(256) void actor_head_kernel(AHParams p) {
+__global__ __launch_bounds__(256) void actor_head_kernel(AHParams p, int wlds) {
+  extern __shared__ __attribute__((aligned(16))) float wsh[];
+  __shared__ float hsh[4 * 16 * 65];
+  __shared__ float hres[4 * 128];
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (wlds) {
+    const int nm = p.A * p.U;
+    for (int i = threadIdx.x; i < nm; i += 256) wsh[i] = p.Wm[i];
+    if (p.Ws)
+      for (int i = threadIdx.x; i < nm; i += 256) wsh[nm + i] = p.Ws[i];
+    __syncthreads();
+  }
   const float inv_n = 1.f / (float)p.U;
   float g[NV], b[NV];
 #pragma unroll
@@ -225,24 +264,42 @@ __global__ __launch_bounds__(256) void actor_head_kernel(AHParams p) {
       if (p.mean) p.mean[r] = mean;
       if (p.rstd) p.rstd[r] = rstd;
     }
-    // heads: lane a keeps output a
+    // heads: 2A (or A) dot products of length U.  Every lane writes its partial of each output to LDS and lane j
+    // then sums the 64 partials of output j: two LDS passes instead of 2A dependent wave reductions.  Outputs go
+    // through in chunks of 16; `res` collects them so that lane a ends up with mean[a] and std[a].
     float mr = 0.f, sr = 0.f;
-    for (int a = 0; a < p.A; ++a) {
-      float dm = 0.f, ds = 0.f;
+    {
+      float* sh = hsh + wave * (16 * 65);
+      float* res = hres + wave * 128;
+      const int nout = p.Ws ? 2 * p.A : p.A;
+      for (int o0 = 0; o0 < nout; o0 += 16) {
+        const int no = min(16, nout - o0);
+        for (int j = 0; j < no; ++j) {
+          const int o = o0 + j;
+          const float* w = wlds ? wsh + (long)o * p.U
+                                : ((o < p.A) ? p.Wm + (long)o * p.U : p.Ws + (long)(o - p.A) * p.U);
+          float d = 0.f;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        const int c = l + 64 * v;
-        if (c < p.U) {
-          dm += x[v] * p.Wm[(long)a * p.U + c];
-          if (p.Ws) ds += x[v] * p.Ws[(long)a * p.U + c];
+          for (int v = 0; v < NV; ++v) {
+            const int c = l + 64 * v;
+            if (c < p.U) d += x[v] * w[c];
+          }
+          sh[j * 65 + l] = d;
         }
+        __builtin_amdgcn_wave_barrier();
+        if (l < no) {
+          float t = 0.f;
+#pragma unroll 16
+          for (int k = 0; k < 64; ++k) t += sh[l * 65 + k];
+          res[o0 + l] = t;
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      dm = group_sum<64>(dm);
-      if (p.Ws) ds = group_sum<64>(ds);
-      if (l == a) {
-        mr = dm + p.bm[a];
-        if (p.Ws) sr = ds + p.bs[a];
+      if (l < p.A) {
+        mr = res[l] + p.bm[l];
+        if (p.Ws) sr = res[p.A + l] + p.bs[l];
       }
+      __builtin_amdgcn_wave_barrier();
     }
     const bool valid = l < p.A;
     const long e = r * p.A + l;
@@ -336,19 +393,27 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
   }
 }
 
-// class index of every one-hot group: idx[g] = argmax_d x[g][d] (lowest index on ties)
+// class index of every one-hot group: idx[g] = argmax_d x[g][d] (lowest index on ties).  G = pow2 >= D lanes per
+// group, one class per lane (coalesced), shuffle argmax.
+template <int G>
 __global__ __launch_bounds__(256) void onehot_to_idx_kernel(const float* __restrict__ x, int* __restrict__ idx, long R,
                                                             int D) {
-  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < R; g += (long)gridDim.x * 256) {
-    const float* row = x + g * D;
-    int bi = 0;
-    float best = row[0];
-    for (int d = 1; d < D; ++d)
-      if (row[d] > best) {
-        best = row[d];
-        bi = d;
+  constexpr int GPB = 256 / G;
+  const int sub = threadIdx.x / G, d = threadIdx.x % G;
+  for (long g0 = (long)blockIdx.x * GPB; g0 < R; g0 += (long)gridDim.x * GPB) {
+    const long g = g0 + sub;
+    float best = (g < R && d < D) ? x[g * D + d] : -INFINITY;
+    int bi = d;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
       }
-    idx[g] = bi;
+    }
+    if (g < R && d == 0) idx[g] = bi;
   }
 }
 
@@ -377,7 +442,7 @@ extern "C" int dv3_onehot_linear_ln_fwd(const int* idx, int S, int D, const floa
   const bool vec = (N % 256 == 0) && N <= 1024 && (ldw % 4 == 0) && (ldpre % 4 == 0) && (!base || ldbase % 4 == 0) &&
                    (!y || ldy % 4 == 0);
   if (vec) {
-    const dim3 grid(cap_grid(M, 4, 16384)), block(256);
+    const dim3 grid(cap_grid(M, 1, 32768)), block(256);
     switch (N / 256) {
       case 1: hipLaunchKernelGGL((onehot_linear_ln_vec_kernel<1>), grid, block, 0, s, p); break;
       case 2: hipLaunchKernelGGL((onehot_linear_ln_vec_kernel<2>), grid, block, 0, s, p); break;
@@ -407,11 +472,22 @@ extern "C" int dv3_actor_head_fwd(const float* pre, long ldpre, const float* gam
   AHParams p{pre, ldpre, gamma, beta, y, ldy, mean, rstd, Wm, bm, Ws, bs, out_m, out_s, noise, rng_state, rng_offset,
              eps_out, action, entropy, act_idx, forced, flips, M, U, A, min_std, max_std, unimix, onehot};
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(cap_grid(M, 4, 16384)), block(256);
-  if (U <= 64) hipLaunchKernelGGL((actor_head_kernel<1>), grid, block, 0, s, p);
-  else if (U <= 256) hipLaunchKernelGGL((actor_head_kernel<4>), grid, block, 0, s, p);
-  else if (U <= 512) hipLaunchKernelGGL((actor_head_kernel<8>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((actor_head_kernel<16>), grid, block, 0, s, p);
+  const dim3 grid(cap_grid(M, 4, 2048)), block(256);
+  const size_t wbytes = (size_t)(onehot ? 1 : 2) * A * U * sizeof(float);
+  const int wlds = wbytes <= 96 * 1024;
+  const size_t sh = wlds ? wbytes : 0;
+#define DV3_AH(NV_)                                                                                              \
+  do {                                                                                                           \
+    if (sh > 32 * 1024)                                                                                          \
+      (void)hipFuncSetAttribute((const void*)actor_head_kernel<NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)sh);                                                                        \
+    hipLaunchKernelGGL((actor_head_kernel<NV_>), grid, block, sh, s, p, wlds);                                   \
+  } while (0)
+  if (U <= 64) DV3_AH(1);
+  else if (U <= 256) DV3_AH(4);
+  else if (U <= 512) DV3_AH(8);
+  else DV3_AH(16);
+#undef DV3_AH
   return (int)hipGetLastError();
 }
 
@@ -426,7 +502,16 @@ extern "C" int dv3_transpose2d(const float* src, long lds, int R, int C, float* 
 extern "C" int dv3_onehot_to_idx(const float* onehot, int* idx, long R, int D, void* stream) {
   if (R <= 0) return 0;
   if (!onehot || !idx || D <= 0) return DV3_ERR_ARG;
-  hipLaunchKernelGGL(onehot_to_idx_kernel, dim3(cap_grid(R, 256, 4096)), dim3(256), 0, (hipStream_t)stream, onehot,
-                     idx, R, D);
+  if (D > 64) return DV3_ERR_ARG;
+  int G = 4;
+  while (G < 64 && G < D) G <<= 1;
+  hipStream_t s = (hipStream_t)stream;
+  switch (G) {
+    case 4: hipLaunchKernelGGL((onehot_to_idx_kernel<4>), dim3(cap_grid(R, 64, 8192)), dim3(256), 0, s, onehot, idx, R, D); break;
+    case 8: hipLaunchKernelGGL((onehot_to_idx_kernel<8>), dim3(cap_grid(R, 32, 8192)), dim3(256), 0, s, onehot, idx, R, D); break;
+    case 16: hipLaunchKernelGGL((onehot_to_idx_kernel<16>), dim3(cap_grid(R, 16, 8192)), dim3(256), 0, s, onehot, idx, R, D); break;
+    case 32: hipLaunchKernelGGL((onehot_to_idx_kernel<32>), dim3(cap_grid(R, 8, 8192)), dim3(256), 0, s, onehot, idx, R, D); break;
+    default: hipLaunchKernelGGL((onehot_to_idx_kernel<64>), dim3(cap_grid(R, 4, 8192)), dim3(256), 0, s, onehot, idx, R, D); break;
+  }
   return (int)hipGetLastError();
 }

@@ -31,6 +31,17 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int splits, kchunk;  // split-K over workgroups (accumulating GEMMs only: partial sums land with atomics)
   int transC;          // skinny kernel only: store C[col*ldc + row] and index bias by row
+  // direct kernel, EPI = 1: C holds the logits of N/32 categorical groups of 32 classes per row; each group is
+  // sampled in the epilogue (tools.OneHotDist.sample, tools.py:452-460; same draws as dv3_onehot_sample_fwd)
+  const float* smp_noise;
+  const unsigned long long* smp_rng;
+  unsigned long long smp_off;
+  float* smp_onehot;
+  int* smp_idx;
+  const int* smp_forced;
+  unsigned int* smp_flips;
+  float smp_unimix;
+  int smp_mode;
 };
 
 template <class TS, bool TA, bool TB>
@@ -223,9 +234,13 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
 // without its LDS write+read of every element and its barriers.  TB: B is [N][K] (else [K][N], scalar loads).
 // grid = ceil(N / (16*RN)) * ceil(M / 32) workgroups (XCD-aware order, see below); blockDim = 64 * waves (4 or 8).
 // ------------------------------------------------------------------------------------------------
-template <bool TB, int RN, int BATCH>
+// PIPE = 1: the loads of batch t+1 are issued before the MFMAs of batch t (two register sets).  PIPE = 0: one register
+// set, a batch is loaded then consumed; latency is hidden by the other resident waves only -- with BATCH = 2 a wave
+// then consumes whole 128-byte lines of its 16 operand rows per batch (two adjacent 16-k chunks) at ~110 VGPRs.
+template <bool TB, int RN, int BATCH, int EPI = 0, int PIPE = 1>
 __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float dred[];  // [waves][2][RN][256]
+  __shared__ float ctile[EPI == 1 ? 32 * (16 * RN + 1) : 1];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nwaves = blockDim.x >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -341,12 +356,19 @@ __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
           }
       }
   };
-  load(a0, b0, cb);
-  for (int c0 = cb; c0 < ce; c0 += 2 * BATCH) {
-    load(a1, b1, c0 + BATCH);
-    compute(a0, b0, c0);
-    load(a0, b0, c0 + 2 * BATCH);
-    compute(a1, b1, c0 + BATCH);
+  if constexpr (PIPE) {
+    load(a0, b0, cb);
+    for (int c0 = cb; c0 < ce; c0 += 2 * BATCH) {
+      load(a1, b1, c0 + BATCH);
+      compute(a0, b0, c0);
+      load(a0, b0, c0 + 2 * BATCH);
+      compute(a1, b1, c0 + BATCH);
+    }
+  } else {
+    for (int c0 = cb; c0 < ce; c0 += BATCH) {
+      load(a0, b0, c0);
+      compute(a0, b0, c0);
+    }
   }
   float* red = dred + (long)wave * (2 * RN * 256);
 #pragma unroll
@@ -369,6 +391,62 @@ __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
       float* o = p.C + (long)row * p.ldc + col;
       if (p.accumulate) v += *o;
       *o = v;
+      if constexpr (EPI == 1) ctile[(16 * t + 4 * (l >> 4) + r) * (16 * RN + 1) + 16 * c + (l & 15)] = v;
+    }
+  }
+  if constexpr (EPI == 1) {
+    // the finished 32 x (16 RN) logit tile holds RN/2 whole categorical groups per row: 32 lanes per group
+    constexpr int GT = 16 * RN / 32;
+    __syncthreads();
+    const int S = p.N >> 5;
+    const int d = tid & 31;
+    unsigned long long seed = 0, offset = 0;
+    if (!p.smp_mode && !p.smp_noise) {
+      seed = p.smp_rng[0];
+      offset = p.smp_rng[1] + p.smp_off;
+    }
+    for (int pr = tid >> 5; pr < 32 * GT; pr += blockDim.x >> 5) {
+      const int row_l = pr / GT, gl = pr % GT;
+      const int row = m0 + row_l, col0 = n0 + 32 * gl;
+      const bool rv = row < p.M && col0 < p.N;
+      const float lg = ctile[row_l * (16 * RN + 1) + 32 * gl + d];
+      float sm, ph;
+      unimix_probs<32>(lg, true, 32, p.smp_unimix, sm, ph);
+      const long g = (long)row * S + (col0 >> 5);
+      float score = ph;
+      if (!p.smp_mode) {
+        float q;
+        if (p.smp_noise) {
+          q = rv ? p.smp_noise[g * 32 + d] : 1.f;
+        } else {
+          uint32_t o4[4];
+          const unsigned long long e = (unsigned long long)g * 32 + d;
+          Philox ph4(seed);
+          ph4(offset + (e >> 2), 0x5eedULL, o4);
+          q = fmaxf(-logf(u01(o4[e & 3])), 1e-30f);
+        }
+        score = ph / q;
+      }
+      float best = score;
+      int bi = d;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+          best = ob;
+          bi = oi;
+        }
+      }
+      if (p.smp_forced) {
+        const int f = rv ? p.smp_forced[g] : 0;
+        if (rv && d == 0 && p.smp_flips && f != bi) atomicAdd(p.smp_flips, 1u);
+        bi = f;
+      }
+      if (rv) {
+        p.smp_onehot[g * 32 + d] = (d == bi) ? 1.f : 0.f;
+        if (d == 0 && p.smp_idx) p.smp_idx[g] = bi;
+      }
     }
   }
 }
@@ -383,6 +461,19 @@ static void launch_direct_rn(const GemmParams& p0, int waves, hipStream_t s) {
   // one chunk of lookahead (BATCH 1) measured best: ~100 VGPRs keep 4 waves per SIMD resident, which hides more
   // latency than deeper register prefetch at 170-230 VGPRs (DV3_DIRECT_BATCH: development switch)
   static const int env_batch = getenv("DV3_DIRECT_BATCH") ? atoi(getenv("DV3_DIRECT_BATCH")) : 0;
+  if constexpr (TB && RN == 4) {
+    if (p.smp_onehot) {
+      hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 1, 1>), grid, block, sh, s, p);
+      return;
+    }
+  }
+  static const int env_pipe = getenv("DV3_DIRECT_PIPE") ? atoi(getenv("DV3_DIRECT_PIPE")) : 1;
+  if (env_pipe == 0) {
+    if (env_batch == 4) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 4, 0, 0>), grid, block, sh, s, p);
+    else if (env_batch == 1) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 1, 0, 0>), grid, block, sh, s, p);
+    else hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 2, 0, 0>), grid, block, sh, s, p);
+    return;
+  }
   if (env_batch == 2) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 2>), grid, block, sh, s, p);
   else if (env_batch == 3) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 3>), grid, block, sh, s, p);
   else hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 1>), grid, block, sh, s, p);
@@ -778,4 +869,30 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   else if (t == 1) e = launch_ts<T64>(p, transA, transB, s);
   else e = launch_ts<T32x128>(p, transA, transB, s);
   return (int)e;
+}
+
+// y = [A|A2] W^T + bias as dv3_gemm_f32 (transA = 0, transB = 1, register-direct kernel) with the categorical
+// sampling of the result fused into the epilogue: C [M, N] holds the logits of N/32 groups of 32 classes per row
+// (RSSM._suff_stats_layer + get_dist + OneHotDist.sample, networks.py:241-250, 161-166, tools.py:452-460).
+// Same draws, outputs and options as dv3_onehot_sample_fwd_ex on C.  N % 64 == 0.
+extern "C" int dv3_gemm_sample_f32(int M, int N, int K, const float* A, long lda, const float* A2, long lda2, int K1,
+                                   const float* B, long ldb, float* C, long ldc, const float* bias,
+                                   const float* noise, const unsigned long long* rng_state,
+                                   unsigned long long rng_offset, float* onehot, int* idx, const int* forced,
+                                   unsigned int* flips, float unimix, int mode, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (K <= 0 || !A || !B || !C || !onehot || (N % 64) != 0) return DV3_ERR_ARG;
+  if (!mode && !noise && !rng_state) return DV3_ERR_ARG;
+  if (A2 && (K1 <= 0 || K1 >= K || (K1 % 16) != 0)) return DV3_ERR_ARG;
+  GemmParams p{};
+  p.A = A; p.A2 = A2; p.B = B; p.C = C; p.bias = bias;
+  p.M = M; p.N = N; p.K = K; p.K1 = (A2 ? K1 : K);
+  p.lda = lda; p.lda2 = lda2; p.ldb = ldb; p.ldc = ldc;
+  p.accumulate = 0;
+  p.vecA = 1; p.vecB = 1;
+  p.smp_noise = noise; p.smp_rng = rng_state; p.smp_off = rng_offset; p.smp_onehot = onehot; p.smp_idx = idx;
+  p.smp_forced = forced; p.smp_flips = flips; p.smp_unimix = unimix; p.smp_mode = mode;
+  const int chunks = (K + 15) / 16;
+  launch_direct_rn<true, 4>(p, chunks >= 32 ? 8 : 4, (hipStream_t)stream);
+  return (int)hipGetLastError();
 }

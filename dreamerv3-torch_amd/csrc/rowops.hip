@@ -734,6 +734,166 @@ __global__ __launch_bounds__(256) void gru_bwd_vec_kernel(const float* __restric
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Wide GRU cells (De = 1024 * NK > 1024: the crafter-size models, dyn_deter 2048..4096, i.e. LayerNorm rows of
+// 6144..12288): a workgroup per row, thread t owns columns 4*(t + 256 k) .. +3 of each gate (k < NK), the row's
+// 3*De pre-activations stay in registers, statistics by two block reductions.  Same math as gru_fwd_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int NK>
+__global__ __launch_bounds__(256) void gru_fwd_wide_kernel(const float* __restrict__ p, long ldp,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ h,
+                                                           long ldh, float* __restrict__ hn, long ldhn,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           int M, int De, NextBlend nb) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int N = 3 * De;
+  const float inv_n = 1.f / (float)N;
+  for (int r = blockIdx.x; r < M; r += gridDim.x) {
+    const float* pr = p + (long)r * ldp;
+    f4 x[3][NK];
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        x[g][k] = *reinterpret_cast<const f4u*>(pr + (long)g * De + 4 * (tid + 256 * k));
+        s += hsum(x[g][k]);
+      }
+    const float mean = block_sum_256(s, red) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const f4 d = x[g][k] - mean;
+        q += hsum(d * d);
+      }
+    const float rstd = rsqrtf(block_sum_256(q, red) * inv_n + kLnEps);
+    const float nf = nb.out ? nb.first[r] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int j = 4 * (tid + 256 * k);
+      const f4 gr = *reinterpret_cast<const f4u*>(gamma + j), br = *reinterpret_cast<const f4u*>(beta + j);
+      const f4 gc = *reinterpret_cast<const f4u*>(gamma + De + j), bc = *reinterpret_cast<const f4u*>(beta + De + j);
+      const f4 gu = *reinterpret_cast<const f4u*>(gamma + 2 * De + j), bu = *reinterpret_cast<const f4u*>(beta + 2 * De + j);
+      const f4 hp = *reinterpret_cast<const f4u*>(h + (long)r * ldh + j);
+      f4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float yr = (x[0][k][e] - mean) * rstd * gr[e] + br[e];
+        const float yc = (x[1][k][e] - mean) * rstd * gc[e] + bc[e];
+        const float yu = (x[2][k][e] - mean) * rstd * gu[e] + bu[e];
+        const float rg = sigmoidf_(yr);
+        const float cg = tanhf(rg * yc);
+        const float ug = sigmoidf_(yu - 1.f);
+        o[e] = ug * cg + (1.f - ug) * hp[e];
+      }
+      *reinterpret_cast<f4u*>(hn + (long)r * ldhn + j) = o;
+      if (nb.out) {
+        const f4 in = *reinterpret_cast<const f4u*>(nb.init + j);
+        *reinterpret_cast<f4u*>(nb.out + (long)r * nb.ld + j) = o * (1.f - nf) + in * nf;
+      }
+    }
+    if (tid == 0) {
+      mean_out[r] = mean;
+      rstd_out[r] = rstd;
+    }
+  }
+}
+
+// Backward of the wide cell.  dgamma/dbeta partial sums stay in registers over the workgroup's rows (a thread owns
+// the same columns in every row) and leave with one atomic per column per workgroup.
+template <int NK>
+__global__ __launch_bounds__(256) void gru_bwd_wide_kernel(const float* __restrict__ dhn, long lddhn,
+                                                           const float* __restrict__ p, long ldp,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ h,
+                                                           long ldh, const float* __restrict__ mean_in,
+                                                           const float* __restrict__ rstd_in, float* __restrict__ dp,
+                                                           long lddp, float* __restrict__ dh, long lddh,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                           int De, int accumulate_dh) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int N = 3 * De;
+  const float inv_n = 1.f / (float)N;
+  f4 ag[3][NK], ab[3][NK];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      ag[g][k] = (f4){0.f, 0.f, 0.f, 0.f};
+      ab[g][k] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+  for (int r = blockIdx.x; r < M; r += gridDim.x) {
+    const float* pr = p + (long)r * ldp;
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    f4 xh[3][NK], dy[3][NK];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int j = 4 * (tid + 256 * k);
+      const f4 gr = *reinterpret_cast<const f4u*>(gamma + j), br = *reinterpret_cast<const f4u*>(beta + j);
+      const f4 gc = *reinterpret_cast<const f4u*>(gamma + De + j), bc = *reinterpret_cast<const f4u*>(beta + De + j);
+      const f4 gu = *reinterpret_cast<const f4u*>(gamma + 2 * De + j), bu = *reinterpret_cast<const f4u*>(beta + 2 * De + j);
+      xh[0][k] = (*reinterpret_cast<const f4u*>(pr + j) - mean) * rstd;
+      xh[1][k] = (*reinterpret_cast<const f4u*>(pr + De + j) - mean) * rstd;
+      xh[2][k] = (*reinterpret_cast<const f4u*>(pr + 2 * De + j) - mean) * rstd;
+      const f4 hp = *reinterpret_cast<const f4u*>(h + (long)r * ldh + j);
+      const f4 gg = *reinterpret_cast<const f4u*>(dhn + (long)r * lddhn + j);
+      f4 dhd;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float yr = xh[0][k][e] * gr[e] + br[e], yc = xh[1][k][e] * gc[e] + bc[e], yu = xh[2][k][e] * gu[e] + bu[e];
+        const float rg = sigmoidf_(yr);
+        const float cg = tanhf(rg * yc);
+        const float ug = sigmoidf_(yu - 1.f);
+        const float g = gg[e];
+        const float du = g * (cg - hp[e]) * ug * (1.f - ug);
+        const float drc = g * ug * (1.f - cg * cg);
+        const float dr = drc * yc * rg * (1.f - rg);
+        const float dc = drc * rg;
+        dhd[e] = g * (1.f - ug);
+        dy[0][k][e] = dr;
+        dy[1][k][e] = dc;
+        dy[2][k][e] = du;
+        s1 += dr * gr[e] + dc * gc[e] + du * gu[e];
+        s2 += dr * gr[e] * xh[0][k][e] + dc * gc[e] * xh[1][k][e] + du * gu[e] * xh[2][k][e];
+      }
+      f4u* o = reinterpret_cast<f4u*>(dh + (long)r * lddh + j);
+      if (accumulate_dh) dhd += *o;
+      *o = dhd;
+    }
+    s1 = block_sum_256(s1, red) * inv_n;
+    s2 = block_sum_256(s2, red) * inv_n;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int c = g * De + 4 * (tid + 256 * k);
+        const f4 gm = *reinterpret_cast<const f4u*>(gamma + c);
+        *reinterpret_cast<f4u*>(dp + (long)r * lddp + c) = (dy[g][k] * gm - s1 - xh[g][k] * s2) * rstd;
+        ag[g][k] += dy[g][k] * xh[g][k];
+        ab[g][k] += dy[g][k];
+      }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int c = g * De + 4 * (tid + 256 * k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(dgamma + c + e, ag[g][k][e]);
+          atomicAdd(dbeta + c + e, ab[g][k][e]);
+        }
+      }
+  }
+}
+
 template <int LPR, int NV>
 static void launch_ln_fwd(const float* x, long ldx, const float* g, const float* b, float* y, long ldy, float* mean,
                           float* rstd, long R, int N, int act, int G, hipStream_t s) {
@@ -869,7 +1029,8 @@ extern "C" int dv3_gru_fwd_blend(const float* p, long ldp, const float* gamma, c
                                  long ldh, float* h_new, long ldhn, float* mean, float* rstd, int M, int De,
                                  const float* next_first, const float* init, float* next_out, long ld_next,
                                  void* stream) {
-  if (!next_first || !init || !next_out || ld_next < De || De % 256 != 0 || De > 1024) return DV3_ERR_ARG;
+  if (!next_first || !init || !next_out || ld_next < De || ld_next % 4 != 0) return DV3_ERR_ARG;
+  if (!((De % 256 == 0 && De <= 1024) || (De % 1024 == 0 && De <= 4096))) return DV3_ERR_ARG;
   return gru_fwd_impl(p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De,
                       NextBlend{next_first, init, next_out, ld_next}, stream);
 }
@@ -888,6 +1049,15 @@ static int gru_fwd_impl(const float* p, long ldp, const float* gamma, const floa
     else hipLaunchKernelGGL((gru_fwd_vec_kernel<4>), dim3(blocks), dim3(256), 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De, nb);
     return (int)hipGetLastError();
   }
+  if (De % 1024 == 0 && De <= 4096 && ldp % 4 == 0 && ldh % 4 == 0 && ldhn % 4 == 0) {
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(M < 8192 ? M : 8192), block(256);
+    if (De == 2048) hipLaunchKernelGGL((gru_fwd_wide_kernel<2>), grid, block, 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De, nb);
+    else if (De == 3072) hipLaunchKernelGGL((gru_fwd_wide_kernel<3>), grid, block, 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De, nb);
+    else hipLaunchKernelGGL((gru_fwd_wide_kernel<4>), grid, block, 0, s, p, ldp, gamma, beta, h, ldh, h_new, ldhn, mean, rstd, M, De, nb);
+    return (int)hipGetLastError();
+  }
+  if (nb.out) return DV3_ERR_ARG;
   hipLaunchKernelGGL(gru_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, ldp, gamma, beta, h, ldh,
                      h_new, ldhn, mean, rstd, M, De);
   return (int)hipGetLastError();
@@ -900,8 +1070,22 @@ extern "C" int dv3_gru_bwd(const float* dh_new, long lddhn, const float* p, long
   if (M <= 0) return 0;
   if (De <= 0 || !dh_new || !p || !gamma || !beta || !h || !mean || !rstd || !dp || !dh) return DV3_ERR_ARG;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return DV3_ERR_ARG;
+  if (De > 1024 && De % 1024 == 0 && De <= 4096 && ldp % 4 == 0 && lddp % 4 == 0 && ldh % 4 == 0 && lddh % 4 == 0 &&
+      lddhn % 4 == 0) {
+    hipStream_t s = (hipStream_t)stream;
+    // with parameter gradients few fat workgroups (their 2 * 3 De atomics each are the tail); without, the whole chip
+    const int cap = dgamma ? 256 : 4096;
+    const dim3 grid(M < cap ? M : cap), block(256);
+#define DV3_GRUBW(NK_) hipLaunchKernelGGL((gru_bwd_wide_kernel<NK_>), grid, block, 0, s, dh_new, lddhn, p, ldp, gamma, beta, h, \
+                                          ldh, mean, rstd, dp, lddp, dh, lddh, dgamma, dbeta, M, De, accumulate_dh)
+    if (De == 2048) DV3_GRUBW(2);
+    else if (De == 3072) DV3_GRUBW(3);
+    else DV3_GRUBW(4);
+#undef DV3_GRUBW
+    return (int)hipGetLastError();
+  }
   const size_t shmem = (size_t)6 * 3 * De * sizeof(float);
-  if (shmem > 150 * 1024) return DV3_ERR_ARG;  // De <= 2048; larger cells need the block-per-row variant
+  if (shmem > 150 * 1024) return DV3_ERR_ARG;  // generic kernel: De <= 2133 (wider cells: De % 1024 == 0 above)
   int blocks = (M + 3) / 4;
   if (blocks > 256) blocks = 256;
   if (De % 256 == 0 && De <= 1024) {

@@ -37,6 +37,8 @@ class Dreamer(nn.Module):
         if config.expl_behavior != "greedy":
             raise NotImplementedError("only expl_behavior='greedy' is on the accelerated path")
         self._expl_behavior = self._task_behavior
+        self._runner, self._stager = None, None
+        self._metric_keys, self._metric_sum, self._metric_n = [], None, 0
 
     def __call__(self, obs, reset, state=None, training=True):
         step = self._step
@@ -47,6 +49,7 @@ class Dreamer(nn.Module):
                 self._update_count += 1
                 self._metrics["update_count"] = self._update_count
             if self._should_log(step) and self._logger is not None:
+                self._flush_metrics()
                 for name, values in self._metrics.items():
                     self._logger.scalar(name, float(np.mean(values)))
                     self._metrics[name] = []
@@ -84,10 +87,39 @@ class Dreamer(nn.Module):
         return {"action": action, "logprob": logprob}, (latent, action)
 
     def _train(self, data):
-        metrics = {}
-        post, context, mets = self._wm._train(data)
-        metrics.update(mets)
-        reward = lambda f, s, a: self._wm.heads["reward"](self._wm.dynamics.get_feat(s)).mode()
-        metrics.update(self._task_behavior._train(post, reward)[-1])
-        for name, value in metrics.items():
-            self._metrics.setdefault(name, []).append(value)
+        """dreamer.py:192-208.  One update = WorldModel._train + ImagBehavior._train on the updated world model; the
+        launch sequence is replayed from hipGraphs (dv3hip.graph.UpdateRunner, ~3000 launches per update) once it has
+        been captured, with the host batch staged through pinned buffers (dv3hip.staging.BatchStager).  Metrics stay
+        on the device: one running sum per key, read back once per log interval (see _flush_metrics)."""
+        if self._runner is None:
+            from dv3hip.graph import UpdateRunner
+            from dv3hip.staging import BatchStager
+
+            self._runner = UpdateRunner(self._wm, self._task_behavior,
+                                        use_graph=bool(getattr(self._config, "hip_graph", True)))
+            self._stager = BatchStager(self._config.device)
+        host = all(not isinstance(v, torch.Tensor) for v in data.values())
+        self._runner.step(self._stager.stage(data) if host else
+                          {k: (v if k == "image" else v.to(torch.float32)) for k, v in data.items()})
+        mets = self._runner.last_metrics
+        dev = [(k, v._t) for k, v in mets.items() if isinstance(v, models.DeviceScalar)]
+        if self._metric_keys != [k for k, _ in dev]:
+            self._flush_metrics()
+            self._metric_keys = [k for k, _ in dev]
+            self._metric_sum = torch.zeros(len(dev), device=dev[0][1].device, dtype=torch.float32)
+            self._metric_n = 0
+        self._metric_sum.add_(torch.stack([t.reshape(()).to(torch.float32) for _, t in dev]))
+        self._metric_n += 1
+        for k, v in mets.items():
+            if not isinstance(v, models.DeviceScalar):
+                self._metrics.setdefault(k, []).append(v)
+
+    def _flush_metrics(self):
+        """Device-side running sums -> self._metrics[name] = [mean] (what the reference's logging loop, which takes
+        np.mean of each list, then reports): a single device-to-host copy per log interval."""
+        if self._metric_n:
+            mean = (self._metric_sum / self._metric_n).cpu().numpy()
+            for k, v in zip(self._metric_keys, mean):
+                self._metrics.setdefault(k, []).append(float(v))
+            self._metric_sum.zero_()
+            self._metric_n = 0

@@ -33,6 +33,7 @@ F32 = torch.float32
 
 
 _FUSE_BLEND = os.environ.get("DV3_FUSE_BLEND", "1") != "0"  # development switch (A/B runs)
+_FUSE_SAMPLE = os.environ.get("DV3_FUSE_SAMPLE", "1") != "0"  # sampling in the epilogue of the prior-logit GEMM
 
 
 class SideStream:
@@ -185,18 +186,62 @@ class MLPEngine:
         out2 = ws.get(f"{nm}.out2", (total, P.out2.W.shape[0])) if P.out2 is not None else None
         return acts, out, out2
 
-    def forward(self, x1, x2=None, *, row0=0, total=None):
+    def pack_onehot(self, SD: int):
+        """Transposed copy of the first layer's stoch columns, W0[:, :SD] -> [SD, U], for the one-hot gather
+        (ops.onehot_linear_ln).  Call once per update, after the optimizer step that changed W0."""
+        W0 = self.P.layers[0].W
+        wt = self.ws.get(f"{self.name}.wt0", (SD, W0.shape[0]))
+        ops.transpose2d(W0[:, :SD], wt)
+        return wt
+
+    def forward(self, x1, x2=None, *, row0=0, total=None, idx=None, D=0, head=None, base0=None):
         """x = [x1|x2] (R rows) -> (trunk output, mean_layer output, std_layer output) for rows
-        [row0, row0+R) of the engine's buffers."""
+        [row0, row0+R) of the engine's buffers.
+
+        idx (int32 [R,S]) + D: x1 is the exact one-hot expansion of idx ([R, S*D], the flattened stoch of
+        get_feat, networks.py:154-159).  The first layer then multiplies only x2 on the MFMA path and gathers the S
+        weight columns of every row (pack_onehot must have run), fused with its LayerNorm + SiLU.
+        head (dict, actor only): run the last layer's LayerNorm + SiLU, both head Linears, the action sample and
+        the entropy as ONE launch (ops.actor_head); keys: action, ent, noise, rng, eps_out, onehot, min_std,
+        max_std, unimix, act_idx, forced, flips.
+        base0 ([R, U], with idx): x2 @ W0[:, SD:]^T computed elsewhere (RSSMEngine.img_step_fwd's stacked GEMM)."""
         P = self.P
         R = x1.shape[0]
         total = R if total is None else total
         acts, out, out2 = self._bufs(total)
         rs = slice(row0, row0 + R)
         h1, h2 = x1, x2
-        for (pre, mean, rstd, y), L in zip(acts, P.layers):
-            dense_ln_fwd(L, h1, h2, pre[rs], mean[rs], rstd[rs], y[rs])
+        n_layers = len(P.layers)
+        for i, ((pre, mean, rstd, y), L) in enumerate(zip(acts, P.layers)):
+            last_fused = head is not None and i == n_layers - 1
+            if i == 0 and idx is not None:
+                SD = idx.shape[1] * D
+                wt = self.ws.get(f"{self.name}.wt0", (SD, L.W.shape[0]))
+                base = base0
+                if base is None and x2 is not None:
+                    ops.gemm(x2, L.W[:, SD:], pre[rs])
+                    base = pre[rs]
+                if last_fused:
+                    ops.onehot_linear_ln(idx, D, wt, pre[rs], base=base)
+                else:
+                    ops.onehot_linear_ln(idx, D, wt, pre[rs], base=base, gamma=L.g, beta=L.b, y=y[rs], mean=mean[rs],
+                                         rstd=rstd[rs])
+            elif last_fused:
+                ops.gemm(h1, L.W, pre[rs], A2=h2)
+            else:
+                dense_ln_fwd(L, h1, h2, pre[rs], mean[rs], rstd[rs], y[rs])
             h1, h2 = y[rs], None
+        if head is not None:
+            pre, mean, rstd, y = acts[-1]
+            L = P.layers[-1]
+            onehot = bool(head.get("onehot", False))
+            ops.actor_head(pre[rs], L.g, L.b, y[rs], mean[rs], rstd[rs], P.out.W, P.out.b,
+                           None if onehot else P.out2.W, None if onehot else P.out2.b, out[rs],
+                           None if onehot else out2[rs], head["action"], head["ent"], noise=head.get("noise"),
+                           rng=head.get("rng"), eps_out=head.get("eps_out"), act_idx=head.get("act_idx"),
+                           forced=head.get("forced"), flips=head.get("flips"), min_std=head.get("min_std", 0.1),
+                           max_std=head.get("max_std", 1.0), unimix=head.get("unimix", 0.01), onehot=onehot)
+            return h1, out[rs], None if onehot else out2[rs]
         o = o2 = None
         if out is not None:
             o = out[rs]
@@ -305,11 +350,14 @@ class RSSMEngine:
         ops.tanh_bwd(d0, dd, _g(P.W0), accumulate=True)
 
     # -- observe ------------------------------------------------------------------------------------
-    def observe_fwd(self, embed_tm, action_tm, first_tm, *, q_prior=None, q_post=None, rng=None, force=None):
+    def observe_fwd(self, embed_tm, action_tm, first_tm, *, q_prior=None, q_post=None, rng=None, force=None,
+                    state0=None):
         """embed_tm [T,B,E], action_tm [T,B,A], first_tm [T,B] (float 0/1; row 0 is forced to 1, as
         prev_state=None does in networks.py:176-180).  Noise [T,B,S,D] ~ Exp(1) or rng state.
         force (parity tests): dict(post=[T,B,S] int32, prior=[T,B,S] int32, flips=int32[1]) teacher-forces the
-        sampled classes and counts the draws that differ.  Returns dict of time-major buffers."""
+        sampled classes and counts the draws that differ.  state0 = (stoch [B,SD], deter [B,De]): the carried
+        state of RSSM.observe(..., state) (networks.py:127-143): step 0 then blends it with is_first[:, 0] as given
+        instead of starting every row from the initial state.  Returns dict of time-major buffers."""
         P, ws = self.P, self.ws
         T, B = embed_tm.shape[0], embed_tm.shape[1]
         S, D, SD, De, Hd, A, E = self.S, self.D, self.SD, self.De, self.Hd, self.A, self.E
@@ -320,7 +368,8 @@ class RSSMEngine:
         s0, d0 = self.init_state_fwd()
         first = ws.get("obs.first", (T, B))
         first.copy_(first_tm)
-        first[0].fill_(1.0)
+        if state0 is None:
+            first[0].fill_(1.0)
         g = ws.get
         sin, din, ain = g("obs.sin", (T, B, SD)), g("obs.din", (T, B, De)), g("obs.ain", (T, B, A))
         x1pre, x1 = g("obs.x1pre", (T, B, Hd)), g("obs.x1", (T, B, Hd))
@@ -336,11 +385,11 @@ class RSSMEngine:
         # launch for all T), step 0 starts from the initial state, and the blend of step t+1's stoch / deter is a
         # second output of the kernels that produce them at step t (fused when the vector GRU kernel applies).
         ops.reset_blend(v2(action_tm, A), None, first.view(TB), v2(ain, A))
-        fuse = De % 256 == 0 and De <= 1024 and _FUSE_BLEND
+        fuse = ((De % 256 == 0 and De <= 1024) or (De % 1024 == 0 and De <= 4096)) and _FUSE_BLEND
         for t in range(T):
             if t == 0 or not fuse:
-                prev_s = post_stoch[t - 1].view(B, SD) if t > 0 else None
-                prev_d = deter[t - 1] if t > 0 else None
+                prev_s = post_stoch[t - 1].view(B, SD) if t > 0 else (None if state0 is None else state0[0])
+                prev_d = deter[t - 1] if t > 0 else (None if state0 is None else state0[1])
                 ops.obs_blend(prev_s, s0.view(SD), prev_d, d0.view(De), action_tm[t], first[t], sin[t], din[t], ain[t])
             nxt = fuse and t + 1 < T
             dense_ln_fwd(P.img_in, sin[t], ain[t], x1pre[t], m1[t], r1[t], x1[t])
@@ -448,18 +497,46 @@ class RSSMEngine:
         return side
 
     # -- one img_step on a row block (networks.py:208-233), used by the policy path and imagine ---------
+    def pack_img_in(self):
+        """Transposed copy of the img_in weight, [Hd, SD+A] -> [SD+A, Hd], for the one-hot gather path of img_step
+        (once per update: the world model's weights are frozen during imagination, models.py:335)."""
+        W = self.P.img_in.W
+        wt = self.ws.get("rssm.img_in_wt", (W.shape[1], W.shape[0]))
+        ops.transpose2d(W, wt)
+        return wt
+
     def img_step_fwd(self, stoch, deter, action, bufs, *, noise=None, rng=None, sample=True, forced=None,
-                     flips=None):
-        """stoch [M,SD], deter [M,De], action [M,A]; bufs: dict of per-step buffers (see imagine_fwd)."""
+                     flips=None, idx=None, idx_out=None, wcat=None):
+        """stoch [M,SD], deter [M,De], action [M,A]; bufs: dict of per-step buffers (see imagine_fwd).
+        idx (int32 [M,S]): the class indices of stoch (an exact one-hot): img_in then runs as gather + LayerNorm +
+        SiLU in one launch (pack_img_in must have run) instead of GEMM + LN.  idx_out (int32 [M,S]) receives the
+        class indices of the sampled successor.  wcat ([Hd + X, De] = img_out weight stacked on other Linears that
+        read the new deter, e.g. the actor's first layer): ONE GEMM writes bufs["cat"] [M, Hd + X] whose first Hd
+        columns are bufs["x2pre"] (a view of it) -- the consumers of deter' share its launch."""
         P = self.P
         M = stoch.shape[0]
-        dense_ln_fwd(P.img_in, stoch, action, bufs["x1pre"], bufs["m1"], bufs["r1"], bufs["x1"])
+        if idx is not None:
+            wt = self.ws.get("rssm.img_in_wt", (P.img_in.W.shape[1], P.img_in.W.shape[0]))
+            ops.onehot_linear_ln(idx, self.D, wt, bufs["x1pre"], x2=action, gamma=P.img_in.g, beta=P.img_in.b,
+                                 y=bufs["x1"], mean=bufs["m1"], rstd=bufs["r1"])
+        else:
+            dense_ln_fwd(P.img_in, stoch, action, bufs["x1pre"], bufs["m1"], bufs["r1"], bufs["x1"])
         ops.gemm(bufs["x1"], P.gru.W, bufs["gpre"], A2=deter)
         ops.gru_fwd(bufs["gpre"], P.gru.g, P.gru.b, deter, bufs["deter"], bufs["mg"], bufs["rg"])
-        dense_ln_fwd(P.img_out, bufs["deter"], None, bufs["x2pre"], bufs["m2"], bufs["r2"], bufs["x2"])
-        ops.gemm(bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD), bias=P.ims.b)
-        ops.onehot_sample(bufs["logit"], bufs["stoch"], noise=noise, rng=rng, unimix=self.unimix, mode=not sample,
-                          forced=forced, flips=flips)
+        if wcat is not None:
+            ops.gemm(bufs["deter"], wcat, bufs["cat"])
+            ops.ln_act_fwd(bufs["x2pre"], P.img_out.g, P.img_out.b, bufs["x2"], bufs["m2"], bufs["r2"], act=True)
+        else:
+            dense_ln_fwd(P.img_out, bufs["deter"], None, bufs["x2pre"], bufs["m2"], bufs["r2"], bufs["x2"])
+        io = None if idx_out is None else idx_out.view(-1)
+        if _FUSE_SAMPLE and ops.gemm_sample_ok(M, self.SD, self.D):
+            ops.gemm_sample(bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD), bufs["stoch"], bias=P.ims.b,
+                            noise=noise, rng=rng, idx=io, forced=forced, flips=flips, unimix=self.unimix,
+                            mode=not sample)
+        else:
+            ops.gemm(bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD), bias=P.ims.b)
+            ops.onehot_sample(bufs["logit"], bufs["stoch"], noise=noise, rng=rng, unimix=self.unimix, mode=not sample,
+                              forced=forced, flips=flips, idx=io)
 
     def img_step_bwd(self, dstoch, ddeter, prev_deter, bufs, scratch, dprev_stoch, dprev_deter, daction,
                      accumulate_prev=False):

@@ -916,3 +916,154 @@ def convT_s2_c3_fwd(x, w, y, *, CW, bias=None, out_add=0.0, accumulate=False):
     _call("dv3_convT_s2_c3_fwd", _ptr(x), _ptr(w), _ptr(bias), float(out_add), _ptr(y), N, IH, IW, CW,
           int(accumulate), _stream(), key="convT_s2_c3_kernel", nbytes=4.0 * (x.numel() + y.numel()))
     return y
+
+
+# ---------------------------------------------------------------------------------------------
+# row-fused layers of the imagination step (csrc/fusedops.hip)
+# ---------------------------------------------------------------------------------------------
+def transpose2d(src, dst):
+    """dst [C,R] = src [R,C]^T (src may be a column slice of a wider matrix)."""
+    R, C, lds = _rows2d(src, "src")
+    Rd, Cd, ldd = _rows2d(dst, "dst")
+    if (Rd, Cd) != (C, R):
+        raise ValueError(f"transpose2d: src {tuple(src.shape)} dst {tuple(dst.shape)}")
+    _call("dv3_transpose2d", _ptr(src), lds, R, C, _ptr(dst), ldd, _stream())
+    return dst
+
+
+def onehot_to_idx(onehot, idx):
+    D = onehot.shape[-1]
+    R = _groups(onehot, "onehot", D)
+    _contig(idx, "idx", torch.int32)
+    if idx.numel() != R:
+        raise ValueError("idx size mismatch")
+    _call("dv3_onehot_to_idx", _ptr(onehot), _ptr(idx), R, D, _stream())
+    return idx
+
+
+def onehot_linear_ln(idx, D, WT, pre, *, x2=None, base=None, gamma=None, beta=None, y=None, mean=None, rstd=None,
+                     act=True):
+    """pre [M,N] = base + gather of WT rows by idx [M,S] (+ x2 [M,A2] @ WT[S*D:]); y = act(LN(pre)) when y is given.
+    WT [S*D + A2, N] is the transposed Linear weight."""
+    _contig(idx, "idx", torch.int32)
+    if idx.dim() != 2:
+        raise ValueError("idx must be [M,S]")
+    M, S = idx.shape
+    Kw, N, ldw = _rows2d(WT, "WT")
+    Mp, Np, ldpre = _rows2d(pre, "pre")
+    A2, ldx2 = 0, 0
+    if x2 is not None:
+        Mx, A2, ldx2 = _rows2d(x2, "x2")
+        if Mx != M:
+            raise ValueError("x2 rows mismatch")
+    if (Mp, Np) != (M, N) or Kw != S * D + A2 or S > 64:
+        raise ValueError(f"onehot_linear_ln: idx {tuple(idx.shape)} D {D} A2 {A2} WT {tuple(WT.shape)} pre {tuple(pre.shape)}")
+    ldbase = 0
+    if base is not None:
+        Mb, Nb, ldbase = _rows2d(base, "base")
+        if (Mb, Nb) != (M, N):
+            raise ValueError("base shape mismatch")
+    ldy = 0
+    if y is not None:
+        My, Ny, ldy = _rows2d(y, "y")
+        _contig(gamma, "gamma"), _contig(beta, "beta")
+        if (My, Ny) != (M, N) or gamma.numel() != N or beta.numel() != N:
+            raise ValueError("y / LN affine shape mismatch")
+        for t, nm in ((mean, "mean"), (rstd, "rstd")):
+            if t is not None:
+                _contig(t, nm)
+                if t.numel() != M:
+                    raise ValueError(nm + " size mismatch")
+    _call("dv3_onehot_linear_ln_fwd", _ptr(idx), S, int(D), _ptr(x2), ldx2, A2, _ptr(WT), ldw, _ptr(base), ldbase,
+          _ptr(pre), ldpre, _ptr(gamma), _ptr(beta), _ptr(y), ldy, _ptr(mean), _ptr(rstd), M, N, int(act), _stream(),
+          key="dv3_onehot_linear_ln_fwd" + (f"[{M}x{N},S={S}]" if PROFILE.by_shape else ""),
+          flops=2.0 * M * N * (S * D + A2), nbytes=4.0 * M * N * (S + 2))
+    return y if y is not None else pre
+
+
+def actor_head(pre, gamma, beta, y, mean, rstd, Wm, bm, Ws, bs, out_m, out_s, action, entropy, *, noise=None,
+               rng=None, eps_out=None, act_idx=None, forced=None, flips=None, min_std=0.1, max_std=1.0, unimix=0.01,
+               onehot=False):
+    """Last trunk LayerNorm+SiLU, the heads, the action sample and the entropy of the actor in one launch."""
+    M, U, ldpre = _rows2d(pre, "pre")
+    My, Uy, ldy = _rows2d(y, "y")
+    A = Wm.shape[0]
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (Wm, "Wm"), (bm, "bm"), (out_m, "out_m"), (action, "action")):
+        _contig(t, nm)
+    if (My, Uy) != (M, U) or gamma.numel() != U or tuple(Wm.shape) != (A, U) or bm.numel() != A \
+            or out_m.numel() != M * A or action.numel() != M * A or U > 1024 or A > 64:
+        raise ValueError("actor_head shapes mismatch")
+    if not onehot:
+        for t, nm in ((Ws, "Ws"), (bs, "bs"), (out_s, "out_s")):
+            _contig(t, nm)
+        if tuple(Ws.shape) != (A, U) or bs.numel() != A or out_s.numel() != M * A:
+            raise ValueError("actor_head std head shapes mismatch")
+    else:
+        Ws = bs = out_s = None
+    for t, nm, n in ((mean, "mean", M), (rstd, "rstd", M), (entropy, "entropy", M), (noise, "noise", M * A),
+                     (eps_out, "eps_out", M * A)):
+        if t is not None:
+            _contig(t, nm)
+            if t.numel() != n:
+                raise ValueError(nm + " size mismatch")
+    for t, nm in ((act_idx, "act_idx"), (forced, "forced")):
+        if t is not None:
+            _contig(t, nm, torch.int32)
+            if t.numel() != M:
+                raise ValueError(nm + " size mismatch")
+    if flips is not None:
+        _contig(flips, "flips", torch.int32)
+    rng_state, rng_off = None, 0
+    if noise is None:
+        if rng is None:
+            raise ValueError("actor_head needs noise or an RngStream")
+        rng_state, rng_off = rng.state, rng.take(M * A)
+    _call("dv3_actor_head_fwd", _ptr(pre), ldpre, _ptr(gamma), _ptr(beta), _ptr(y), ldy, _ptr(mean), _ptr(rstd), _ptr(Wm),
+          _ptr(bm), _ptr(Ws), _ptr(bs), _ptr(out_m), _ptr(out_s), _ptr(noise), _ptr(rng_state), int(rng_off),
+          _ptr(eps_out), _ptr(action), _ptr(entropy), _ptr(act_idx), _ptr(forced), _ptr(flips), M, U, A,
+          float(min_std), float(max_std), float(unimix), int(onehot), _stream(),
+          flops=2.0 * M * U * A * (1 if onehot else 2))
+
+
+def gemm_sample_ok(M, N, D, A=None) -> bool:
+    """True when ops.gemm_sample applies: groups of 32 classes, whole groups per 64-column tile, and an output
+    size for which dv3_gemm_f32 would pick the register-direct kernel anyway."""
+    return D == 32 and N % 64 == 0 and M > 32 and pick_gemm_tile(M, N) == 9
+
+
+def gemm_sample(A, B, logit, onehot, *, bias=None, noise=None, rng=None, idx=None, forced=None, flips=None,
+                unimix=0.01, mode=False):
+    """logit [M,N] = A @ B^T + bias and, in the same launch, the one-hot sample of every group of 32 logits
+    (onehot [M,N]; idx/forced int32 [M*N/32]) -- ops.gemm followed by ops.onehot_sample, fused."""
+    M, K, lda = _rows2d(A, "A")
+    N, Kb, ldb = _rows2d(B, "B")
+    Mc, Nc, ldc = _rows2d(logit, "logit")
+    _contig(onehot, "onehot")
+    if Kb != K or (Mc, Nc) != (M, N) or onehot.numel() != M * N or N % 64:
+        raise ValueError("gemm_sample shapes mismatch")
+    R = M * N // 32
+    if bias is not None:
+        _contig(bias, "bias")
+        if bias.numel() != N:
+            raise ValueError("bias size mismatch")
+    if noise is not None:
+        _contig(noise, "noise")
+        if noise.numel() != M * N:
+            raise ValueError("noise size mismatch")
+    for t, nm in ((idx, "idx"), (forced, "forced")):
+        if t is not None:
+            _contig(t, nm, torch.int32)
+            if t.numel() != R:
+                raise ValueError(nm + " size mismatch")
+    if flips is not None:
+        _contig(flips, "flips", torch.int32)
+    rng_state, rng_off = None, 0
+    if not mode and noise is None:
+        if rng is None:
+            raise ValueError("sampling needs noise or an RngStream")
+        rng_state, rng_off = rng.state, rng.take(M * N)
+    _call("dv3_gemm_sample_f32", M, N, K, _ptr(A), lda, 0, 0, 0, _ptr(B), ldb, _ptr(logit), ldc, _ptr(bias), _ptr(noise),
+          _ptr(rng_state), int(rng_off), _ptr(onehot), _ptr(idx), _ptr(forced), _ptr(flips), float(unimix), int(mode),
+          _stream(), key="gemm_kernel<direct32x64+sample,tA=0,tB=1>" + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else ""),
+          flops=2.0 * M * N * K, nbytes=4.0 * (M * K + N * K + 2 * M * N))
+    return onehot

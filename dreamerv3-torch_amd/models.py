@@ -12,6 +12,7 @@ Row order: activations are time-major inside (row t*B+b); dict entries handed ba
 from __future__ import annotations
 
 import copy
+import os
 
 import numpy as np
 import torch
@@ -24,6 +25,17 @@ from dv3hip import ops
 from dv3hip.params import ParamBucket
 
 to_np = lambda x: x.detach().cpu().numpy()
+_FUSED_IMAG = os.environ.get("DV3_FUSED_IMAG", "1") != "0"  # development switch (A/B runs), see _imagine_fwd
+_IMAG_CHAINS = int(os.environ.get("DV3_IMAG_CHAINS", "1"))  # row-split imagination rollout on parallel streams
+_STACK_DETER = os.environ.get("DV3_STACK_DETER", "1") != "0"  # img_out + actor layer-0 dense half as one GEMM
+_SIDE = {}
+
+
+def _side_streams(device, n):
+    key = str(device)
+    while len(_SIDE.setdefault(key, [])) < n:
+        _SIDE[key].append(torch.cuda.Stream(device=device))
+    return _SIDE[key][:n]
 
 
 class DeviceScalar:
@@ -421,6 +433,8 @@ class ImagBehavior(nn.Module):
     def _imagine(self, start, policy, horizon, first_action=None, noise=None):
         """models.py:448-548 (forward only): returns feats [H,N,F], states {[H,N,...]}, actions [H,N,A].
         Row order follows the memory order of `start` (time-major when it comes from WorldModel._train)."""
+        if policy is not None and policy is not self.actor:
+            raise NotImplementedError("_imagine: only the behaviour's own actor is a policy on the accelerated path")
         self._imagine_fwd(start, horizon, noise)
         st = self._im
         S, D = self._world_model.dynamics._stoch, self._world_model.dynamics._discrete
@@ -446,44 +460,118 @@ class ImagBehavior(nn.Module):
         stoch[0].copy_(s0), deter[0].copy_(d0), logit[0].copy_(l0)
         action, ent = g("im.action", (H, N, A)), g("im.ent", (H, N))
         eps = g("im.eps", (H, N, A))
+        actor_eng = self.actor.engine_for(".imag")
+        U0 = actor_eng.P.layers[0].W.shape[0]
+        # img_out and the dense half of the actor's first layer both read the new deter: one stacked GEMM per step
+        # writes [x2pre | actor pre0 of the NEXT step] (engine.RSSMEngine.img_step_fwd, wcat)
+        stack = _FUSED_IMAG and _STACK_DETER
+        cat = g("im.cat", (H, N, Hd + U0)) if stack else None
         step = dict(x1pre=g("im.x1pre", (H, N, Hd)), m1=g("im.m1", (H, N)), r1=g("im.r1", (H, N)),
                     x1=g("im.x1", (H, N, Hd)), gpre=g("im.gpre", (H, N, 3 * De)), mg=g("im.mg", (H, N)),
-                    rg=g("im.rg", (H, N)), x2pre=g("im.x2pre", (H, N, Hd)), m2=g("im.m2", (H, N)),
-                    r2=g("im.r2", (H, N)), x2=g("im.x2", (H, N, Hd)))
-        actor_eng = self.actor.engine_for(".imag")
+                    rg=g("im.rg", (H, N)), x2pre=cat[..., :Hd] if stack else g("im.x2pre", (H, N, Hd)),
+                    m2=g("im.m2", (H, N)), r2=g("im.r2", (H, N)), x2=g("im.x2", (H, N, Hd)))
+        if stack:
+            step["cat"] = cat
+            wcat = g("im.wcat", (Hd + U0, De))
+            wcat[:Hd].copy_(rssm.P.img_out.W)
+            wcat[Hd:].copy_(actor_eng.P.layers[0].W[:, SD:])
+        else:
+            wcat = None
         normal = cfg.actor["dist"] == "normal"
         q_img, act_noise = nz.get("q_img"), nz.get("act")
         f_img, f_act, flips = nz.get("force_img"), nz.get("force_act"), nz.get("flips")  # parity tests
-        for t in range(H):
-            _, mean_raw, std_raw = actor_eng.forward(stoch[t], deter[t], row0=t * N, total=H * N)
-            if normal:
-                if act_noise is not None:
-                    eps[t].copy_(act_noise[t])
-                else:
-                    ops.fill_normal(eps[t], rng)
-                ops.actor_normal_fwd(mean_raw, std_raw, eps[t], action[t], ent[t], min_std=cfg.actor["min_std"],
-                                     max_std=cfg.actor["max_std"])
-            else:
-                ops.onehot_sample(mean_raw, action[t], noise=None if act_noise is None else act_noise[t], rng=rng,
-                                  unimix=cfg.actor["unimix_ratio"], forced=None if f_act is None else f_act[t],
-                                  flips=flips)
-                ops.onehot_ent_logp_fwd(mean_raw, None, ent[t], None, unimix=cfg.actor["unimix_ratio"])
-            if t < H - 1:
-                b = {k: v[t] for k, v in step.items()}
-                b.update(deter=deter[t + 1], logit=logit[t + 1].view(N, S, D), stoch=stoch[t + 1].view(N, S, D))
-                rssm.img_step_fwd(stoch[t], deter[t], action[t], b, noise=None if q_img is None else q_img[t], rng=rng,
-                                  forced=None if f_img is None else f_img[t], flips=flips)
+        # The stochastic state is an exact one-hot (tools.py:452-460): carry its class indices and let every Linear
+        # that reads it (actor layer 0, img_in) gather weight columns instead of multiplying zeros (engine.py).
+        idx = g("im.idx", (H, N, S), torch.int32)
+        ops.onehot_to_idx(stoch[0].view(N, S, D), idx[0].view(-1))
+        if _FUSED_IMAG:
+            actor_eng.pack_onehot(SD)
+            rssm.pack_img_in()
+
+        def run_chain(rc):
+            """The H-step rollout of the row range rc (rows are independent: models.py:450-451 flattens [B,T])."""
+            n, r0 = rc.stop - rc.start, rc.start
+            for t in range(H):
+                nz_act = None if act_noise is None else act_noise[t][rc]
+                if _FUSED_IMAG:
+                    head = dict(action=action[t][rc], ent=ent[t][rc], rng=rng, onehot=not normal, flips=flips,
+                                noise=nz_act)
+                    if normal:
+                        head.update(eps_out=eps[t][rc], min_std=cfg.actor["min_std"], max_std=cfg.actor["max_std"])
+                    else:
+                        head.update(unimix=cfg.actor["unimix_ratio"], forced=None if f_act is None else f_act[t][rc])
+                    actor_eng.forward(stoch[t][rc], deter[t][rc], row0=t * N + r0, total=H * N, idx=idx[t][rc], D=D,
+                                      head=head, base0=cat[t - 1][rc][:, Hd:] if (stack and t > 0) else None)
+                else:  # one launch per op (development switch DV3_FUSED_IMAG=0: the r01 launch sequence, for A/B)
+                    _, mean_raw, std_raw = actor_eng.forward(stoch[t][rc], deter[t][rc], row0=t * N + r0, total=H * N)
+                    if normal:
+                        if nz_act is not None:
+                            eps[t][rc].copy_(nz_act)
+                        else:
+                            ops.fill_normal(eps[t][rc], rng)
+                        ops.actor_normal_fwd(mean_raw, std_raw, eps[t][rc], action[t][rc], ent[t][rc],
+                                             min_std=cfg.actor["min_std"], max_std=cfg.actor["max_std"])
+                    else:
+                        ops.onehot_sample(mean_raw, action[t][rc], noise=nz_act, rng=rng,
+                                          unimix=cfg.actor["unimix_ratio"],
+                                          forced=None if f_act is None else f_act[t][rc], flips=flips)
+                        ops.onehot_ent_logp_fwd(mean_raw, None, ent[t][rc], None, unimix=cfg.actor["unimix_ratio"])
+                if t < H - 1:
+                    b = {k: v[t][rc] for k, v in step.items()}
+                    b.update(deter=deter[t + 1][rc], logit=logit[t + 1][rc].view(n, S, D),
+                             stoch=stoch[t + 1][rc].view(n, S, D))
+                    rssm.img_step_fwd(stoch[t][rc], deter[t][rc], action[t][rc], b,
+                                      noise=None if q_img is None else q_img[t][rc], rng=rng,
+                                      forced=None if f_img is None else f_img[t][rc], flips=flips,
+                                      idx=idx[t][rc] if _FUSED_IMAG else None, idx_out=idx[t + 1][rc], wcat=wcat)
+
+        chains = _IMAG_CHAINS if N % (32 * _IMAG_CHAINS) == 0 else 1
+        if chains == 1:
+            run_chain(slice(0, N))
+        else:
+            # Row-split rollout on parallel streams (graph branches under capture): at 1024 rows every launch of the
+            # chain is latency- rather than throughput-bound, so one half's MFMA work fills the other half's launch
+            # and memory latencies.  Rows are independent; only the Philox counter ranges differ from one chain.
+            main = torch.cuda.current_stream()
+            sides = _side_streams(stoch.device, chains - 1)
+            per = N // chains
+            for st in sides:
+                st.wait_stream(main)
+            run_chain(slice(0, per))
+            for c, st in enumerate(sides):
+                with torch.cuda.stream(st):
+                    run_chain(slice((c + 1) * per, (c + 2) * per))
+            for st in sides:
+                main.wait_stream(st)
         rng.commit()
         self._im = dict(H=H, N=N, stoch=stoch, deter=deter, logit=logit, action=action, ent=ent, eps=eps, step=step,
-                        actor=actor_eng)
+                        actor=actor_eng, idx=idx)
 
     # ------------------------------------------------------------------------------------------
     def _train(self, start, objective=None, noise=None):
-        """One actor + critic update (models.py:327-446).  `objective` is accepted for signature
-        compatibility; the reward is the world model's reward head on the imagined states, which is what
-        dreamer.py passes (dreamer.py:196-199)."""
+        """One actor + critic update (models.py:327-446).  The reward is the world model's reward head on the
+        imagined states, which is the `objective` dreamer.py passes (dreamer.py:196-199); a given `objective` is
+        checked against it once (see _check_objective), None skips the check."""
         self.train_fwd_bwd(start, noise)
+        if objective is not None and not getattr(self, "_objective_checked", False):
+            self._check_objective(objective)
         return self.train_opt()
+
+    def _check_objective(self, objective):
+        """The backward through the reward is hand-derived for the reward HEAD on the imagined states, which is the
+        objective dreamer.py:196-199 passes.  Any other callable would silently train on the wrong signal, so the
+        first update evaluates the caller's objective (forward only, through the public modules) on the imagined
+        trajectory and compares it with the reward the kernels used; a different objective is refused."""
+        (_, imag_state, action, _), _, _ = self._pending
+        feat = self._world_model.dynamics.get_feat(imag_state)
+        got = objective(feat, imag_state, action)
+        want = self._last["reward"]
+        if tuple(got.shape[:2]) != tuple(want.shape) or not torch.allclose(got.reshape(want.shape).to(want.dtype), want,
+                                                                            rtol=1e-4, atol=1e-4):
+            raise NotImplementedError("ImagBehavior._train: `objective` is not the world model's reward head on the "
+                                      "imagined states (dreamer.py:196-199); only that objective has a backward on "
+                                      "the accelerated path")
+        object.__setattr__(self, "_objective_checked", True)
 
     def train_opt(self, allreduce=True):
         ret, metrics, losses = self._pending
@@ -511,17 +599,22 @@ class ImagBehavior(nn.Module):
         fs, fd = stoch.view(HN, SD), deter.view(HN, De)
         g = ws.get
         # ---- heads over all H*N imagined states
+        # first layers read feat = [stoch | deter]: deter through the MFMA GEMM, the one-hot stoch as a gather
+        fidx = im["idx"].view(HN, S) if _FUSED_IMAG else None
         reng = wm.heads["reward"].engine_for(".imag")
-        _, r_logits, _ = reng.forward(fs, fd)
-        reward = ops.disc_mode_fwd(r_logits, g("bh.reward", (H, N)))
         ceng = wm.heads["cont"].engine_for(".imag")
-        _, c_logit, _ = ceng.forward(fs, fd)
         veng = self.value.engine_for(".imag")
-        _, v_logits, _ = veng.forward(fs, fd)
-        value = ops.disc_mode_fwd(v_logits, g("bh.value", (H, N)))
         seng = networks.MLP.engine_for(self._slow_value, ".imag")
         self._slow_bucket()
-        _, s_logits, _ = seng.forward(fs[:H1N], fd[:H1N])
+        if _FUSED_IMAG:
+            for e in (reng, ceng, veng, seng):
+                e.pack_onehot(SD)
+        _, r_logits, _ = reng.forward(fs, fd, idx=fidx, D=D)
+        reward = ops.disc_mode_fwd(r_logits, g("bh.reward", (H, N)))
+        _, c_logit, _ = ceng.forward(fs, fd, idx=fidx, D=D)
+        _, v_logits, _ = veng.forward(fs, fd, idx=fidx, D=D)
+        value = ops.disc_mode_fwd(v_logits, g("bh.value", (H, N)))
+        _, s_logits, _ = seng.forward(fs[:H1N], fd[:H1N], idx=None if fidx is None else fidx[:H1N], D=D)
         slow = ops.disc_mode_fwd(s_logits, g("bh.slow", (H - 1, N)))
         target, weights, disc = g("bh.target", (H - 1, N)), g("bh.weights", (H, N)), g("bh.disc", (H, N))
         ops.lambda_return_fwd(reward, value, c_logit.view(H, N), target, weights, disc, gamma=cfg.discount,

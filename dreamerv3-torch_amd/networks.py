@@ -143,6 +143,17 @@ class RSSM(nn.Module):
         ops.gemm(x, p.ims.W, logit.view(M, -1), bias=p.ims.b)
         return tools.OneHotDist(logit, unimix_ratio=self._unimix_ratio).mode()
 
+    def _suff_stats_layer(self, name, x):
+        """networks.py:241-250 (discrete latents): x [..., hidden] -> {"logit": [..., stoch, discrete]}."""
+        lin = {"ims": self._imgs_stat_layer, "obs": self._obs_stat_layer}.get(name)
+        if lin is None:
+            raise NotImplementedError(name)
+        lead = x.shape[:-1]
+        x2 = x.to(torch.float32).reshape(-1, x.shape[-1]).contiguous()
+        out = torch.empty(x2.shape[0], self._stoch * self._discrete, device=x.device)
+        ops.gemm(x2, lin.weight, out, bias=lin.bias)
+        return {"logit": out.reshape(tuple(lead) + (self._stoch, self._discrete))}
+
     def _step_bufs(self, M, dev):
         S, D, De, Hd = self._stoch, self._discrete, self._deter, self._hidden
         mk = lambda *s: torch.empty(*s, device=dev)
@@ -200,15 +211,17 @@ class RSSM(nn.Module):
 
     def observe(self, embed, action, is_first, state=None, noise=None):
         """networks.py:127-143: embed [B,T,E], action [B,T,A], is_first [B,T] -> (post, prior) of [B,T,...]."""
-        if state is not None:
-            raise NotImplementedError("observe() with a carried state: use obs_step per step")
         B, T = embed.shape[0], embed.shape[1]
         dev = embed.device
         tm = lambda x: ops.transpose01(x.to(torch.float32).contiguous(),
                                        torch.empty((T, B) + tuple(x.shape[2:]), device=dev))
         nz = noise or {}
+        state0 = None
+        if state is not None:  # carried state {stoch [B,S,D], deter [B,De], logit}: step 0 does not reset
+            state0 = (state["stoch"].to(torch.float32).reshape(B, -1).contiguous(),
+                      state["deter"].to(torch.float32).contiguous())
         out = self.engine.observe_fwd(tm(embed), tm(action), tm(is_first), q_prior=nz.get("q_prior"),
-                                      q_post=nz.get("q_post"), rng=self._rng())
+                                      q_post=nz.get("q_post"), rng=self._rng(), state0=state0)
         self._rng().commit()
         bt = lambda x: x.transpose(0, 1).clone()
         post = {"stoch": bt(out["post_stoch"]), "deter": bt(out["deter"]), "logit": bt(out["post_logit"])}

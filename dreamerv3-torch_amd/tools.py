@@ -3,8 +3,11 @@
 Same names, argument meaning and return shapes as the reference (tools.py) for everything the
 world-model training path touches: the distribution wrappers returned by heads / RSSM.get_dist,
 `lambda_return`, `Optimizer`, `RequiresGrad`, `static_scan`, initialisers and schedules.  The
-reference's host-side I/O helpers (Logger, simulate, replay loading) are out of scope (SURVEY.md
-§2 #11) and are not provided here.
+reference's host-side I/O helpers (Logger, simulate, load_episodes, save_episodes, enable_deterministic_run,
+...) are out of scope and are not re-implemented: names this module does not define resolve,
+lazily, to the integrator's OWN reference `tools.py` (module-level __getattr__ below; its path comes from the
+environment variable DV3_REFERENCE_TOOLS or from a `tools.py` found further down sys.path), so the reference's
+`dreamer.py` runs against this module with no import edits.
 
 Distribution objects are forward-only views over kernel outputs: training never differentiates
 through them (models.WorldModel._train / ImagBehavior._train run the hand-derived backward in
@@ -12,8 +15,11 @@ dv3hip.engine); acting and logging only need values.
 """
 from __future__ import annotations
 
+import importlib.util
 import math
+import os
 import re
+import sys
 
 import numpy as np
 import torch
@@ -352,9 +358,9 @@ class _BucketAdam(torch.optim.Optimizer):
 
 
 class Optimizer:
-    """tools.py:731-783 surface over a flat bucket: zero_grad / (caller runs backward into .grad) /
-    all-reduce / clip / Adam.  `__call__(loss, params)` of the reference is split in two because the
-    backward here is explicit: `begin()` before it, `finish(loss)` after it."""
+    """tools.py:731-783 surface over a flat bucket: zero_grad / backward into .grad / all-reduce / clip / Adam.
+    The hot path's backward is explicit, so it uses the two halves `begin()` ... `finish(loss)`; the reference's
+    `__call__(loss, params)` is kept for autograd-built losses."""
 
     def __init__(self, name, parameters, lr, eps=1e-4, clip=None, wd=None, wd_pattern=r".*", opt="adam",
                  use_amp=False):
@@ -384,6 +390,22 @@ class Optimizer:
 
     def begin(self):
         self.bucket.ensure().zero_grad()
+
+    def __call__(self, loss, params, retain_graph=True):
+        """tools.py:760-776 for callers that built `loss` with torch autograd over parameters of this optimizer
+        (exploration.py:104): zero_grad -> loss.backward() into the bucket's .grad views -> all-reduce -> clip ->
+        Adam.  The hot path (WorldModel / ImagBehavior._train) does not come through here: its backward is explicit
+        (begin() ... finish())."""
+        if not isinstance(loss, torch.Tensor) or not loss.requires_grad:
+            raise RuntimeError(f"{self._name}_opt(loss, params): loss carries no autograd graph; the accelerated "
+                               "modules run an explicit backward -- use begin() / finish(loss)")
+        assert len(loss.shape) == 0, loss.shape
+        mine = {id(p) for p in self.bucket.params}
+        if any(id(p) not in mine for p in params):
+            raise ValueError("params are not the parameters this Optimizer was built over")
+        self.begin()
+        loss.backward(retain_graph=retain_graph)
+        return self.finish(loss.detach())
 
     def finish(self, loss, allreduce=True):
         """loss: 0-d device tensor (metric only).  Returns the reference's metric dict with device scalars.
@@ -647,3 +669,61 @@ def load_config(path, blocks):
     for name in ["defaults"] + list(blocks):
         merge(cfg, coerce(raw[name]))
     return cfg
+
+
+# ---------------------------------------------------------------------------------------------
+# delegation of the host-side helpers to the integrator's reference tools.py
+# ---------------------------------------------------------------------------------------------
+# Names of the reference's tools.py that the drivers (dreamer.py:356-567, main_with_causal.py, eval scripts) use and
+# that are NOT part of the accelerated path: resolved from the reference file at the integrator's site.  Nothing of
+# that file is copied here.
+PASSTHROUGH = ("Logger", "simulate", "load_episodes", "save_episodes", "add_to_cache", "erase_over_episodes",
+               "convert", "enable_deterministic_run", "schedule", "static_scan_for_lambda_return", "SampleDist",
+               "SafeTruncatedNormal", "TanhBijector", "UnnormalizedHuber")
+_REFERENCE_TOOLS = None
+
+
+def _find_reference_tools():
+    cand = os.environ.get("DV3_REFERENCE_TOOLS")
+    if cand:
+        if os.path.isdir(cand):
+            cand = os.path.join(cand, "tools.py")
+        if not os.path.isfile(cand):
+            raise ImportError(f"DV3_REFERENCE_TOOLS={cand}: no such file")
+        return cand
+    here = os.path.abspath(__file__)
+    for d in sys.path:
+        f = os.path.abspath(os.path.join(d or ".", "tools.py"))
+        if f != here and os.path.isfile(f):
+            return f
+    return None
+
+
+def _reference_tools():
+    global _REFERENCE_TOOLS
+    if _REFERENCE_TOOLS is None:
+        path = _find_reference_tools()
+        if path is None:
+            raise ImportError("the reference's tools.py was not found: set DV3_REFERENCE_TOOLS=/path/to/reference "
+                              "(or keep the reference directory on sys.path behind this package)")
+        spec = importlib.util.spec_from_file_location("_dv3_reference_tools", path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["_dv3_reference_tools"] = mod
+        spec.loader.exec_module(mod)
+        _REFERENCE_TOOLS = mod
+    return _REFERENCE_TOOLS
+
+
+def __getattr__(name):
+    """PEP 562: attributes this module does not define come from the integrator's reference tools.py."""
+    if name.startswith("__"):
+        raise AttributeError(name)
+    try:
+        ref = _reference_tools()
+    except ImportError as e:
+        raise AttributeError(f"tools.{name} is a host-side helper of the reference that this drop-in does not "
+                             f"re-implement, and {e}") from None
+    try:
+        return getattr(ref, name)
+    except AttributeError:
+        raise AttributeError(f"neither the MI355X tools module nor {ref.__file__} defines {name!r}") from None

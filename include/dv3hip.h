@@ -52,6 +52,15 @@ int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, lo
                  long lda2, int K1, const float* B, long ldb, float* C, long ldc, const float* bias,
                  int accumulate, int tile, void* stream);
 
+/* dv3_gemm_f32 (transA=0, transB=1, register-direct kernel) with the one-hot categorical sampling of its output fused
+ * into the epilogue: C [M,N] = the logits of N/32 groups of 32 classes per row (N % 64 == 0), sampled exactly as
+ * dv3_onehot_sample_fwd_ex would (same noise layout [M*N/32, 32], same Philox counters).  Replaces
+ * RSSM._suff_stats_layer + get_dist(...).sample() in img_step / obs_step (networks.py:226-229, 241-250). */
+int dv3_gemm_sample_f32(int M, int N, int K, const float* A, long lda, const float* A2, long lda2, int K1,
+                        const float* B, long ldb, float* C, long ldc, const float* bias, const float* noise,
+                        const unsigned long long* rng_state, unsigned long long rng_offset, float* onehot, int* idx,
+                        const int* forced, unsigned int* flips, float unimix, int mode, void* stream);
+
 /* ---- LayerNorm(eps 1e-3) [+ SiLU] ----------------------------------------------------------------
  * y = act(LN(x) * gamma + beta), rows of length N <= 2048; mean/rstd [R] are saved for the backward
  * (may be NULL in fwd).  act: 0 none, 1 SiLU.  chw_group G > 0 addresses y (fwd) / dy (bwd) as the
@@ -66,11 +75,13 @@ int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const f
 
 /* ---- LayerNorm-GRU gates -- GRUCell.forward (networks.py:760-768) ---------------------------------
  * p [M,3*De] is the output of the fused Linear on cat[x,h]; LN over all 3*De, then
- * r=sigmoid, c=tanh(r*c), u=sigmoid(u-1), h' = u*c + (1-u)*h.   De <= 2048 for the backward. */
+ * r=sigmoid, c=tanh(r*c), u=sigmoid(u-1), h' = u*c + (1-u)*h.  Any De forward; backward De <= 2133 or
+ * De in {2048, 3072, 4096} (wide cells: a workgroup per row, LayerNorm rows up to 12288). */
 int dv3_gru_fwd(const float* p, long ldp, const float* gamma, const float* beta, const float* h, long ldh,
                 float* h_new, long ldhn, float* mean, float* rstd, int M, int De, void* stream);
 /* dv3_gru_fwd plus the NEXT observe step's reset blend of the new state (networks.py:183-191), fused:
- * next_out[r] = h_new[r]*(1 - next_first[r]) + init*next_first[r].  De % 256 == 0, De <= 1024. */
+ * next_out[r] = h_new[r]*(1 - next_first[r]) + init*next_first[r].  De % 256 == 0 and De <= 1024, or
+ * De in {2048, 3072, 4096}. */
 int dv3_gru_fwd_blend(const float* p, long ldp, const float* gamma, const float* beta, const float* h, long ldh,
                       float* h_new, long ldhn, float* mean, float* rstd, int M, int De, const float* next_first,
                       const float* init, float* next_out, long ld_next, void* stream);
@@ -259,6 +270,35 @@ int dv3_rng_advance(unsigned long long* rng_state, unsigned long long increment,
  * (torch.distributions.utils._standard_normal behind networks.py:697-699); consumes ceil(n/4) counters. */
 int dv3_fill_normal(float* out, long n, const unsigned long long* rng_state, unsigned long long rng_offset,
                     void* stream);
+
+/* ---- row-fused layers of the imagination step (csrc/fusedops.hip) -----------------------------------
+ * dv3_onehot_linear_ln_fwd: pre[M,N] = base + sum_s WT[s*D + idx[m][s]] + sum_a x2[m][a] * WT[S*D + a], then
+ * y = act(LN(pre)) (y == NULL: pre only).  The Linear + LayerNorm + SiLU whose input is cat[stoch.flat, tail]
+ * (RSSM._img_in_layers on cat[stoch, action], networks.py:216-218; the first layer of every MLP head on
+ * get_feat = cat[stoch, deter], networks.py:154-159, 657-668) with the stoch columns an exact one-hot per group
+ * (tools.py:452-460): S rows of the TRANSPOSED weight WT [S*D + A2][N] are gathered by class index instead of
+ * multiplying the one-hot through an MFMA GEMM.  base [M,N] (optional, may alias pre): the product of the other
+ * input columns (deter) from dv3_gemm_f32.  idx int32 [M,S], S <= 64.  mean/rstd [M] saved for dv3_ln_act_bwd.
+ * dv3_actor_head_fwd: y = SiLU(LN(pre)) of the actor trunk's last layer [M,U<=1024], its heads
+ * out_m = y Wm^T + bm (and out_s = y Ws^T + bs for the continuous actor), the action sample and the entropy:
+ * MLP.forward tail + dist 'normal' / 'onehot' (networks.py:672-681, 693-700, 713-714), ContDist.sample with
+ * absmax 1 (tools.py:594-598) / OneHotDist.sample (tools.py:452-460).  noise [M,A] (N(0,1) / Exp(1)) or, when
+ * NULL, the Philox draws dv3_fill_normal / dv3_onehot_sample_fwd would make at rng_offset; eps_out receives the
+ * N(0,1) draws used.  onehot=1: Ws/bs/out_s NULL, act_idx/forced/flips as in dv3_onehot_sample_fwd_ex.
+ * dv3_transpose2d: dst[c*ldd + r] = src[r*lds + c] (weights [N][K] -> WT [K][N]).
+ * dv3_onehot_to_idx: idx[g] = argmax_d onehot[g][d] for R groups of D. */
+int dv3_onehot_linear_ln_fwd(const int* idx, int S, int D, const float* x2, long ldx2, int A2, const float* WT,
+                             long ldw, const float* base, long ldbase, float* pre, long ldpre, const float* gamma,
+                             const float* beta, float* y, long ldy, float* mean, float* rstd, long M, int N, int act,
+                             void* stream);
+int dv3_actor_head_fwd(const float* pre, long ldpre, const float* gamma, const float* beta, float* y, long ldy,
+                       float* mean, float* rstd, const float* Wm, const float* bm, const float* Ws, const float* bs,
+                       float* out_m, float* out_s, const float* noise, const unsigned long long* rng_state,
+                       unsigned long long rng_offset, float* eps_out, float* action, float* entropy, int* act_idx,
+                       const int* forced, unsigned int* flips, long M, int U, int A, float min_std, float max_std,
+                       float unimix, int onehot, void* stream);
+int dv3_transpose2d(const float* src, long lds, int R, int C, float* dst, long ldd, void* stream);
+int dv3_onehot_to_idx(const float* onehot, int* idx, long R, int D, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,25 +14,13 @@ import numpy as np
 # ---------------------------------------------------------------------------------------
 # shape configs
 # ---------------------------------------------------------------------------------------
-SHAPES = {
-    # name: dict(stoch, discrete, deter, hidden, units, A, cnn_depth, B, T, H, actor_dist, imag_gradient)
-    "tiny": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
-                 actor_dist="normal", imag_gradient="dynamics", encoder="cnn"),
-    "tiny_onehot": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=5, cnn_depth=2, B=3, T=6, H=4,
-                        actor_dist="onehot", imag_gradient="reinforce", encoder="cnn"),
-    "tiny_proprio": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
-                         actor_dist="normal", imag_gradient="dynamics", encoder="mlp",
-                         enc_mlp_units=32, enc_mlp_layers=2),
-    "cfg1": dict(stoch=32, discrete=32, deter=512, hidden=512, units=512, A=6, cnn_depth=32, B=16, T=64, H=15,
-                 actor_dist="normal", imag_gradient="dynamics", encoder="mlp",
-                 enc_mlp_units=1024, enc_mlp_layers=5),
-    "cfg2": dict(stoch=32, discrete=32, deter=512, hidden=512, units=512, A=6, cnn_depth=32, B=16, T=64, H=15,
-                 actor_dist="normal", imag_gradient="dynamics", encoder="cnn"),
-    "cfg3": dict(stoch=32, discrete=32, deter=1024, hidden=512, units=512, A=18, cnn_depth=32, B=32, T=64, H=15,
-                 actor_dist="onehot", imag_gradient="reinforce", encoder="cnn"),
-}
-# walker_walk proprio keys, in the order the reference's obs_space dict would list them
-PROPRIO_KEYS: Tuple[Tuple[str, int], ...] = (("orientations", 14), ("height", 1), ("velocity", 9))
+import os as _os
+import sys as _sys
+
+_PKG = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))), "dreamerv3-torch_amd")
+if _PKG not in _sys.path:
+    _sys.path.insert(0, _PKG)
+from dv3hip.shapes import PROPRIO_KEYS, SHAPES  # noqa: E402,F401  (one table for the product, the fixtures and the tests)
 
 
 def path_config(name: str):
@@ -44,6 +32,8 @@ def path_config(name: str):
         stoch=s["stoch"], discrete=s["discrete"], deter=s["deter"], hidden=s["hidden"], units=s["units"],
         num_actions=s["A"], cnn_depth=s["cnn_depth"], actor_dist=s["actor_dist"],
         imag_gradient=s["imag_gradient"], horizon=s["H"], encoder=s["encoder"],
+        actor_layers=s.get("actor_layers", 2), reward_layers=s.get("reward_layers", 2),
+        cont_layers=s.get("cont_layers", 2), critic_layers=s.get("critic_layers", 2),
     )
     if s["encoder"] == "mlp":
         kw.update(mlp_keys=PROPRIO_KEYS, enc_mlp_units=s["enc_mlp_units"], enc_mlp_layers=s["enc_mlp_layers"])
@@ -108,17 +98,17 @@ def param_shapes(name: str) -> Dict[str, Tuple[int, ...]]:
             sh[f"heads.decoder._mlp.mean_layer.{k}.weight"] = (w, E)
             sh[f"heads.decoder._mlp.mean_layer.{k}.bias"] = (w,)
     for pre, nm, out in (("heads.reward.", "Reward", 255), ("heads.cont.", "Cont", 1)):
-        mlp(pre, nm, 2, F, U)
+        mlp(pre, nm, s.get(nm.lower() + "_layers", 2), F, U)
         sh[pre + "mean_layer.weight"] = (out, U)
         sh[pre + "mean_layer.bias"] = (out,)
-    mlp("actor.", "Actor", 2, F, U)
+    mlp("actor.", "Actor", s.get("actor_layers", 2), F, U)
     sh["actor.mean_layer.weight"] = (A, U)
     sh["actor.mean_layer.bias"] = (A,)
     if s["actor_dist"] == "normal":
         sh["actor.std_layer.weight"] = (A, U)
         sh["actor.std_layer.bias"] = (A,)
     for pre in ("value.", "_slow_value."):
-        mlp(pre, "Value", 2, F, U)
+        mlp(pre, "Value", s.get("critic_layers", 2), F, U)
         sh[pre + "mean_layer.weight"] = (255, U)
         sh[pre + "mean_layer.bias"] = (255,)
     return sh

@@ -15,45 +15,7 @@ PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 WM_PREFIXES = ("encoder", "dynamics", "heads")
 
 
-class _Space:
-    def __init__(self, shape):
-        self.shape = shape
-
-
-class _ObsSpace:
-    def __init__(self, spaces):
-        self.spaces = spaces
-
-
-def make_config(name, device="cuda:0"):
-    import tools
-
-    s = common.SHAPES[name]
-    blocks = ["dmc_proprio"] if s["encoder"] == "mlp" else ["dmc_vision"]
-    cfg = tools.load_config(os.path.join(PKG, "configs.yaml"), blocks)
-    cfg.update(device=device, num_actions=s["A"], dyn_stoch=s["stoch"], dyn_discrete=s["discrete"],
-               dyn_deter=s["deter"], dyn_hidden=s["hidden"], units=s["units"], batch_size=s["B"],
-               batch_length=s["T"], imag_horizon=s["H"], imag_gradient=s["imag_gradient"])
-    cfg["encoder"]["cnn_depth"] = s["cnn_depth"]
-    cfg["decoder"]["cnn_depth"] = s["cnn_depth"]
-    if s["actor_dist"] == "onehot":
-        cfg["actor"].update(dist="onehot", std="none")
-    if s["encoder"] == "mlp":
-        for d in (cfg["encoder"], cfg["decoder"]):
-            d.update(mlp_units=s["enc_mlp_units"], mlp_layers=s["enc_mlp_layers"])
-    return argparse.Namespace(**cfg)
-
-
-def obs_space(name):
-    s = common.SHAPES[name]
-    spaces = {}
-    if s["encoder"] == "mlp":
-        for k, w in common.PROPRIO_KEYS:
-            spaces[k] = _Space((w,))
-    spaces["image"] = _Space((64, 64, 3))
-    spaces["is_first"] = _Space((1,))
-    spaces["is_terminal"] = _Space((1,))
-    return _ObsSpace(spaces)
+from dv3hip.shapes import make_config, obs_space  # noqa: E402,F401  (moved into the package: bench.py needs no tests/)
 
 
 def build_models(name, device="cuda:0", weights=None):

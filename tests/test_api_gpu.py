@@ -1,0 +1,112 @@
+"""Public (reference-surface) methods around the hot path that the training kernels do not go through themselves:
+tools.lambda_return, RSSM.observe with a carried state, tools.Optimizer.__call__, the `objective` argument of
+ImagBehavior._train.  Each against the CPU oracle / torch on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dv3_oracle as O
+from tests import helpers as Hh
+from tests.golden import common
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_lambda_return_public_api_matches_oracle_and_reference():
+    """tools.lambda_return(reward[1:], value[:-1], disc[1:], bootstrap=value[-1], lambda_, axis=0) as
+    models.py:627-634 calls it, on the imagined trajectory of the tiny config."""
+    import tools
+
+    name = "tiny"
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    exp = Hh.oracle_update(name, piecewise=True)
+    b = exp["beh0"]
+    r, v, d = b["reward"].cuda(), b["value"].cuda(), b["discount"].cuda()
+    got = tools.lambda_return(r[1:], v[:-1], d[1:], bootstrap=v[-1], lambda_=0.95, axis=0)
+    assert got.shape == b["target"].shape
+    assert torch.allclose(got.cpu(), b["target"], atol=1e-5)
+    assert np.allclose(got.cpu().numpy(), g["imag/target"], atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg2"])
+def test_observe_with_carried_state_matches_oracle(name):
+    """RSSM.observe(embed, action, is_first, state) (networks.py:127-143): step 0 continues from `state` on rows
+    whose is_first is 0 and resets the others."""
+    cfg, wm, _ = Hh.build_models(name)
+    s = common.SHAPES[name]
+    pc = common.path_config(name)
+    p = {k: torch.from_numpy(v) for k, v in common.make_weights(name).items()}
+    rs = np.random.RandomState(3)
+    B, T, E = min(s["B"], 5), 4, wm.embed_size
+    embed = torch.from_numpy(rs.randn(B, T, E).astype(np.float32))
+    action = torch.from_numpy(rs.uniform(-1, 1, (B, T, s["A"])).astype(np.float32))
+    first = torch.zeros(B, T)
+    first[1, 0] = 1.0  # one row resets at step 0, one mid-sequence
+    first[2, 2] = 1.0
+    S, D = s["stoch"], s["discrete"]
+    idx = rs.randint(0, D, (B, S))
+    state = {"stoch": torch.nn.functional.one_hot(torch.from_numpy(idx), D).float(),
+             "deter": torch.from_numpy(rs.randn(B, s["deter"]).astype(np.float32)) * 0.5,
+             "logit": torch.from_numpy(rs.randn(B, S, D).astype(np.float32))}
+    q1 = torch.from_numpy(np.maximum(rs.exponential(size=(T, B, S, D)), 1e-20).astype(np.float32))
+    q2 = torch.from_numpy(np.maximum(rs.exponential(size=(T, B, S, D)), 1e-20).astype(np.float32))
+    post, prior = wm.dynamics.observe(embed.cuda(), action.cuda(), first.cuda(), {k: v.cuda() for k, v in state.items()},
+                                      noise=dict(q_prior=q1.cuda(), q_post=q2.cuda()))
+    with torch.no_grad():
+        epost, eprior = O.observe(pc, p, embed, action, first, q1, q2, state=state)
+    assert torch.equal(post["stoch"].cpu(), epost["stoch"]), "posterior draws"
+    for k in ("deter", "logit"):
+        assert torch.allclose(post[k].cpu(), epost[k], atol=1e-4), "post " + k
+        assert torch.allclose(prior[k].cpu(), eprior[k], atol=1e-4), "prior " + k
+    # and without a state the call still starts every row from the initial state
+    post0, _ = wm.dynamics.observe(embed.cuda(), action.cuda(), first.cuda(), noise=dict(q_prior=q1.cuda(), q_post=q2.cuda()))
+    with torch.no_grad():
+        e0, _ = O.observe(pc, p, embed, action, first, q1, q2)
+    assert torch.allclose(post0["deter"].cpu(), e0["deter"], atol=1e-4)
+
+
+def test_optimizer_call_with_an_autograd_loss_is_clip_plus_adam():
+    """The reference's Optimizer.__call__(loss, params) (tools.py:760-776) for a loss built with torch autograd."""
+    import tools
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).cuda()
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).cuda()
+    ref.load_state_dict(net.state_dict())
+    opt = tools.Optimizer("test", list(net.parameters()), lr=1e-2, eps=1e-5, clip=0.5)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2, eps=1e-5)
+    x = torch.randn(11, 7, device="cuda")
+    for _ in range(3):
+        loss = (net(x) ** 2).sum()
+        mets = opt(loss, net.parameters())
+        rloss = (ref(x) ** 2).sum()
+        ropt.zero_grad()
+        rloss.backward()
+        norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        ropt.step()
+        assert float(mets["test_grad_norm"]) == pytest.approx(float(norm), rel=1e-4)
+        assert float(mets["test_loss"]) == pytest.approx(float(rloss), rel=1e-5)
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, atol=2e-6), (a - b).abs().max()
+    with pytest.raises(RuntimeError, match="no autograd graph"):
+        opt(torch.zeros((), device="cuda"), net.parameters())
+
+
+def test_objective_argument_is_checked_against_the_reward_head():
+    name = "tiny"
+    cfg, wm, beh = Hh.build_models(name)
+    n = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(name).items()}
+    post, _, _ = wm._train(common.make_batch(name), noise=dict(q_prior=n["q_prior"], q_post=n["q_post"]))
+    post = {k: v.clone() for k, v in post.items()}
+    reward = lambda f, s, a: wm.heads["reward"](wm.dynamics.get_feat(s)).mode()  # dreamer.py:196-198
+    out = beh._train(post, reward)
+    assert np.isfinite(float(out[-1]["actor_loss"])) and beh._objective_checked
+    cfg, wm2, beh2 = Hh.build_models(name)
+    post2, _, _ = wm2._train(common.make_batch(name), noise=dict(q_prior=n["q_prior"], q_post=n["q_post"]))
+    with pytest.raises(NotImplementedError, match="objective"):
+        beh2._train({k: v.clone() for k, v in post2.items()}, lambda f, s, a: torch.ones_like(f[..., :1]))
+    with pytest.raises(NotImplementedError, match="policy"):
+        beh2._imagine(post2, lambda feat: None, 3)

@@ -225,7 +225,8 @@ def test_ln_chw_flatten_matches_reference_order(ops):
     assert_close(y, ref, what="chw flatten")
 
 
-@pytest.mark.parametrize("M,De", [(1024, 512), (16, 512), (5, 16), (33, 1024), (3, 40)])
+@pytest.mark.parametrize("M,De", [(1024, 512), (16, 512), (5, 16), (33, 1024), (3, 40), (64, 4096), (16, 2048),
+                                  (130, 3072), (7, 1280)])
 def test_gru_fwd_bwd(ops, M, De):
     g = torch.Generator().manual_seed(M + De)
     p_pre = (torch.randn(M, 3 * De, generator=g)).requires_grad_(True)
@@ -714,3 +715,152 @@ def test_fused_next_step_reset_blend_outputs(ops):
     assert torch.equal(st, st2)
     want = st.cpu() * (1 - first[:, None, None]) + init_s.view(1, S, D) * first[:, None, None]
     assert_close(nxt_s, want, what="sample next blend")
+
+
+# ----------------------------------------------------------------------------- row-fused imagination layers
+@pytest.mark.parametrize("M,N,S,D,A2,with_base", [(1024, 512, 32, 32, 6, False), (1024, 512, 32, 32, 0, True),
+                                                   (16, 512, 32, 32, 6, False), (33, 1024, 32, 32, 17, True),
+                                                   (7, 16, 4, 4, 3, False), (5, 40, 3, 5, 0, True),
+                                                   (300, 256, 32, 32, 18, False), (64, 768, 32, 32, 6, True)])
+def test_onehot_linear_ln_matches_dense_linear(ops, M, N, S, D, A2, with_base):
+    """Gather of S weight columns per row == the dense Linear on the one-hot expansion (networks.py:216-218,
+    657-668), with the LayerNorm + SiLU behind it; also the pre-activation-only form."""
+    g = torch.Generator().manual_seed(M * 31 + N)
+    K = S * D + A2
+    W = torch.randn(N, K, generator=g) / math.sqrt(S + A2 + 1)  # the Linear's [out, in] weight
+    idx = torch.randint(0, D, (M, S), generator=g, dtype=torch.int32)
+    x2 = torch.randn(M, A2, generator=g) if A2 else None
+    base = torch.randn(M, N, generator=g) if with_base else None
+    gamma, beta = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    onehot = F.one_hot(idx.long(), D).float().reshape(M, S * D)
+    x = onehot if x2 is None else torch.cat([onehot, x2], -1)
+    pre_ref = x @ W.t() + (base if base is not None else 0.0)
+    y_ref = F.silu(O.layer_norm(pre_ref, gamma, beta))
+    WT = torch.empty(K, N, device="cuda")
+    ops.transpose2d(dev(W), WT)
+    assert torch.equal(WT.cpu(), W.t().contiguous())
+    pre = dev(base.clone()) if base is not None else torch.empty(M, N, device="cuda")
+    y, mean, rstd = torch.empty(M, N, device="cuda"), torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.onehot_linear_ln(dev(idx), D, WT, pre, x2=None if x2 is None else dev(x2), base=pre if base is not None else None,
+                         gamma=dev(gamma), beta=dev(beta), y=y, mean=mean, rstd=rstd)
+    assert_close(pre, pre_ref, what="pre")
+    assert_close(y, y_ref, what="y")
+    assert_close(mean, pre_ref.mean(-1), what="mean")
+    assert_close(rstd, 1.0 / torch.sqrt(pre_ref.var(-1, unbiased=False) + 1e-3), what="rstd")
+    pre2 = torch.empty(M, N, device="cuda")
+    ops.onehot_linear_ln(dev(idx), D, WT, pre2, x2=None if x2 is None else dev(x2),
+                         base=dev(base) if base is not None else None)
+    assert_close(pre2, pre_ref, what="pre only")
+    # the class indices of a one-hot tensor
+    back = torch.empty(M * S, dtype=torch.int32, device="cuda")
+    ops.onehot_to_idx(dev(F.one_hot(idx.long(), D).float()), back)
+    assert torch.equal(back.cpu().view(M, S), idx)
+
+
+@pytest.mark.parametrize("M,U,A", [(1024, 512, 6), (16, 512, 6), (37, 16, 3), (100, 1024, 17), (9, 200, 1)])
+def test_actor_head_continuous(ops, M, U, A):
+    """LN + SiLU + mean/std heads + rsample + absmax rescale + entropy in one launch == the separate steps
+    (networks.py:672-681, 693-700, tools.py:594-598)."""
+    g = torch.Generator().manual_seed(U + A)
+    pre = torch.randn(M, U, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(U, generator=g), 0.1 * torch.randn(U, generator=g)
+    Wm, Ws = torch.randn(A, U, generator=g) / math.sqrt(U), torch.randn(A, U, generator=g) / math.sqrt(U)
+    bm, bs = 0.1 * torch.randn(A, generator=g), 0.1 * torch.randn(A, generator=g)
+    eps = torch.randn(M, A, generator=g)
+    y_ref = F.silu(O.layer_norm(pre, gamma, beta))
+    mr, sr = y_ref @ Wm.t() + bm, y_ref @ Ws.t() + bs
+    mu, sd = torch.tanh(mr), 0.9 * torch.sigmoid(sr + 2.0) + 0.1
+    a = mu + sd * eps
+    a_ref = a / torch.clip(a.abs(), min=1.0)
+    ent_ref = (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(sd)).sum(-1)
+    mk = lambda *s: torch.empty(*s, device="cuda")
+    y, mean, rstd, om, os_, act, ent, eps_out = mk(M, U), mk(M), mk(M), mk(M, A), mk(M, A), mk(M, A), mk(M), mk(M, A)
+    ops.actor_head(dev(pre), dev(gamma), dev(beta), y, mean, rstd, dev(Wm), dev(bm), dev(Ws), dev(bs), om, os_, act, ent,
+                   noise=dev(eps), eps_out=eps_out, min_std=0.1, max_std=1.0)
+    assert_close(y, y_ref, what="y")
+    assert_close(om, mr, what="mean head"), assert_close(os_, sr, what="std head")
+    assert_close(act, a_ref, what="action"), assert_close(ent, ent_ref, what="entropy")
+    assert torch.equal(eps_out.cpu(), eps)
+    # without injected noise: the N(0,1) draws are those of dv3_fill_normal at the same stream position
+    r1, r2 = ops.RngStream("cuda", seed=11), ops.RngStream("cuda", seed=11)
+    ops.actor_head(dev(pre), dev(gamma), dev(beta), y, mean, rstd, dev(Wm), dev(bm), dev(Ws), dev(bs), om, os_, act, ent,
+                   rng=r1, eps_out=eps_out, min_std=0.1, max_std=1.0)
+    want = ops.fill_normal(mk(M, A), r2)
+    assert torch.allclose(eps_out, want, rtol=1e-5, atol=1e-6) and r1.cursor == r2.cursor
+    a2 = mu.cuda() + sd.cuda() * eps_out
+    assert_close(act, a2 / torch.clip(a2.abs(), min=1.0), what="action (philox)")
+
+
+@pytest.mark.parametrize("M,U,A", [(2048, 512, 18), (16, 512, 18), (21, 16, 5), (50, 1024, 64)])
+def test_actor_head_onehot(ops, M, U, A):
+    """One-hot actor (networks.py:713-714): logits head + OneHotDist sample / entropy; teacher forcing counts flips."""
+    g = torch.Generator().manual_seed(U * 3 + A)
+    pre = torch.randn(M, U, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(U, generator=g), 0.1 * torch.randn(U, generator=g)
+    Wm, bm = torch.randn(A, U, generator=g) / math.sqrt(U) * 3, 0.1 * torch.randn(A, generator=g)
+    q = torch.empty(M, A).exponential_(1.0, generator=g).clamp_min(1e-20)
+    y_ref = F.silu(O.layer_norm(pre, gamma, beta))
+    lg = y_ref @ Wm.t() + bm
+    samp_ref = O.onehot_sample(lg, q, 0.01)
+    ent_ref = O.onehot_entropy(lg[:, None, :], 0.01)
+    mk = lambda *s: torch.empty(*s, device="cuda")
+    y, mean, rstd, om, act, ent = mk(M, U), mk(M), mk(M), mk(M, A), mk(M, A), mk(M)
+    ai = torch.empty(M, dtype=torch.int32, device="cuda")
+    ops.actor_head(dev(pre), dev(gamma), dev(beta), y, mean, rstd, dev(Wm), dev(bm), None, None, om, None, act, ent,
+                   noise=dev(q), act_idx=ai, unimix=0.01, onehot=True)
+    assert_close(om, lg, what="logits"), assert_close(ent, ent_ref, what="entropy")
+    same = (act.cpu() == samp_ref).all(-1)
+    assert same.float().mean() >= 1 - 2e-3, f"{(~same).sum()} of {M} draws differ"
+    assert torch.equal(ai.cpu().long(), act.cpu().argmax(-1)) and act.sum(-1).eq(1).all()
+    # teacher forcing: emit the given classes, count the rows whose own draw differs
+    forced = torch.randint(0, A, (M,), generator=g, dtype=torch.int32)
+    flips = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.actor_head(dev(pre), dev(gamma), dev(beta), y, mean, rstd, dev(Wm), dev(bm), None, None, om, None, act, ent,
+                   noise=dev(q), act_idx=ai, forced=dev(forced), flips=flips, unimix=0.01, onehot=True)
+    assert torch.equal(act.cpu().argmax(-1).int(), forced)
+    assert abs(int(flips.item()) - int((samp_ref.argmax(-1).int() != forced).sum())) <= int((~same).sum())
+
+
+def test_onehot_sample_teacher_forcing_counts_flips(ops):
+    R, D = 4096, 32
+    g = torch.Generator().manual_seed(3)
+    logit = torch.randn(R, D, generator=g)
+    q = torch.empty(R, D).exponential_(1.0, generator=g).clamp_min(1e-20)
+    own = O.onehot_sample(logit, q, 0.01).argmax(-1).int()
+    forced = own.clone()
+    forced[::7] = (forced[::7] + 1) % D
+    out, idx = torch.empty(R, D, device="cuda"), torch.empty(R, dtype=torch.int32, device="cuda")
+    flips = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.onehot_sample(dev(logit), out, noise=dev(q), idx=idx, forced=dev(forced), flips=flips, unimix=0.01)
+    assert torch.equal(idx.cpu(), forced) and torch.equal(out.cpu().argmax(-1).int(), forced)
+    assert abs(int(flips.item()) - len(range(0, R, 7))) <= 2  # + the rare ulp-level disagreement with the oracle
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 512), (100, 128, 48), (33, 64, 512), (2048, 1024, 512)])
+@pytest.mark.parametrize("mode", [False, True])
+def test_gemm_with_sampling_epilogue_equals_gemm_then_sample(ops, M, N, K, mode):
+    """dv3_gemm_sample_f32 == dv3_gemm_f32 (direct kernel) followed by dv3_onehot_sample_fwd: bit-equal logits and
+    samples, with injected noise, with the Philox stream, and teacher-forced."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K) * 3, torch.randn(N, generator=g)
+    q = torch.empty(M, N // 32, 32).exponential_(1.0, generator=g).clamp_min(1e-20)
+    A, W, b, q = dev(A), dev(W), dev(b), dev(q)
+    lg0, st0 = torch.empty(M, N, device="cuda"), torch.empty(M, N // 32, 32, device="cuda")
+    i0 = torch.empty(M * N // 32, dtype=torch.int32, device="cuda")
+    ops.gemm(A, W, lg0, bias=b, tile=9)
+    ops.onehot_sample(lg0.view(M, N // 32, 32), st0, noise=None if mode else q, idx=i0, mode=mode)
+    lg1, st1 = torch.empty_like(lg0), torch.empty_like(st0)
+    i1 = torch.empty_like(i0)
+    ops.gemm_sample(A, W, lg1, st1, bias=b, noise=None if mode else q, idx=i1, mode=mode)
+    assert torch.equal(lg0, lg1) and torch.equal(st0, st1) and torch.equal(i0, i1)
+    assert_close(lg1, A.cpu() @ W.cpu().t() + b.cpu(), tol=2e-4, what="logits")
+    if not mode:
+        r0, r1 = ops.RngStream("cuda", seed=5), ops.RngStream("cuda", seed=5)
+        ops.onehot_sample(lg0.view(M, N // 32, 32), st0, rng=r0)
+        ops.gemm_sample(A, W, lg1, st1, bias=b, rng=r1)
+        assert torch.equal(st0, st1) and r0.cursor == r1.cursor
+        forced = torch.randint(0, 32, (M * N // 32,), dtype=torch.int32, generator=g).cuda()
+        flips = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ops.gemm_sample(A, W, lg1, st1, bias=b, noise=q, idx=i1, forced=forced, flips=flips)
+        assert torch.equal(i1, forced) and torch.equal(st1.argmax(-1).int().view(-1), forced)
+        assert int(flips.item()) == int((i0 != forced).sum())
