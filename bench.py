@@ -34,32 +34,20 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix = 256 CU x 256 flop/clk x 2.4 GHz
 METRIC = "imagination-steps/sec"
+WORKLOADS = {  # BASELINE.json configs
+    "cfg1": "dmc_proprio walker_walk (MLP encoder/decoder) synthetic replay",
+    "cfg2": "dmc_vision 64x64x3 synthetic replay",
+    "cfg3": "atari100k 64x64 discrete-action synthetic replay",
+    "cfg4": "dmc_vision XL (crafter-size model, cnn_depth 96) 64x64x3 synthetic replay",
+    "cfg5": "crafter 64x64 synthetic replay, long sequences (per-GPU shard of the 128-sequence batch at DP=8)",
+}
 
 
-def synthetic_batch(shape, seed, device):
-    """RandomState(seed); image u8, continuous action uniform(-1,1) / one-hot, reward randn,
-    is_first[:,0] plus one extra reset on every other row, staged on the device before timing."""
-    from tests.golden import common
+def synthetic_batch(name, seed, device):
+    """SURVEY.md 8(d) synthetic replay minibatch (dv3hip.shapes.synthetic_batch), staged on the device before timing."""
+    from dv3hip import shapes
 
-    rs = np.random.RandomState(seed)
-    B, T, A = shape["B"], shape["T"], shape["A"]
-    data = {"image": rs.randint(0, 256, size=(B, T, 64, 64, 3)).astype(np.uint8)}
-    if shape["actor_dist"] == "onehot":
-        data["action"] = np.eye(A, dtype=np.float32)[rs.randint(0, A, size=(B, T))]
-    else:
-        data["action"] = rs.uniform(-1, 1, size=(B, T, A)).astype(np.float32)
-    data["reward"] = rs.randn(B, T).astype(np.float32)
-    data["discount"] = np.ones((B, T), np.float32)
-    first = np.zeros((B, T), np.float32)
-    first[:, 0] = 1.0
-    for b in range(0, B, 2):
-        first[b, rs.randint(1, T)] = 1.0
-    data["is_first"] = first
-    data["is_terminal"] = np.zeros((B, T), np.float32)
-    if shape["encoder"] == "mlp":
-        for k, w in common.PROPRIO_KEYS:
-            data[k] = rs.randn(B, T, w).astype(np.float32)
-    return {k: torch.from_numpy(v).to(device) for k, v in data.items()}
+    return {k: torch.from_numpy(v).to(device) for k, v in shapes.synthetic_batch(name, seed).items()}
 
 
 def host_cores() -> int:
@@ -98,10 +86,20 @@ def cpu_baseline(name, updates=2):
         print(f"[bench] cpu_baseline update {i}: {t_all[-1]:.2f} s", file=sys.stderr, flush=True)
     t = float(np.median(t_all))
     units = s["B"] * s["T"] * s["H"]
-    return {"value": units / t, "unit": "imagination-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{updates} full updates of {name} (after 1 warm-up), torch CPU fp32, {cores} threads; "
-                      f"median {t:.2f} s/update (includes building the noise/batch arrays, < 2 %)",
-            "sec_per_update": t}
+    out = {"value": units / t, "unit": "imagination-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{updates} full updates of {name} (after 1 warm-up), torch CPU fp32, {cores} threads; "
+                     f"median {t:.2f} s/update (includes building the noise/batch arrays, < 2 %)",
+           "sec_per_update": t}
+    try:  # reference-CPU figure DERIVED from the port: ratio measured where both run
+        r = json.load(open(os.path.join(REPO, "profiles", "r02_cpu_ratio.json")))
+        ratio = float(r["ratio_reference_over_oracle"])
+        out["reference_cpu_derived"] = {
+            "value": units / (t * ratio), "unit": "imagination-steps/s", "ratio_reference_over_port": ratio,
+            "source": "profiles/r02_cpu_ratio.json (tools/cpu_ratio.py in the build container, cfg2, 8 threads); "
+                      "derived = port time x ratio, not measured on this host"}
+    except Exception:
+        pass
+    return out
 
 
 def phase_timers(wm, beh, data, H, t_upd_ms, reps=10):
@@ -175,23 +173,21 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from dv3hip import ops
-    from tests import helpers as Hh
-    from tests.golden import common
+    from dv3hip import ops, shapes
     import tools
 
     name = args.config
-    shape = common.SHAPES[name]
+    shape = shapes.SHAPES[name]
     B, T, H = shape["B"], shape["T"], shape["H"]
     torch.manual_seed(0)  # identical random-init replica on every rank (reference init scheme, tools.py:890-946)
     import models
 
-    cfg = Hh.make_config(name, str(device))
-    wm = models.WorldModel(Hh.obs_space(name), None, 0, cfg).to(device)
+    cfg = shapes.make_config(name, str(device))
+    wm = models.WorldModel(shapes.obs_space(name), None, 0, cfg).to(device)
     beh = models.ImagBehavior(cfg, wm).to(device)
     wm.requires_grad_(False), beh.requires_grad_(False)
     tools.default_rng(device, seed=1234 + rank)  # per-rank sampling stream
-    data = synthetic_batch(shape, seed=rank, device=device)
+    data = synthetic_batch(name, seed=rank, device=device)
 
     from dv3hip.graph import UpdateRunner
 
@@ -230,27 +226,46 @@ def main():
         mf = {k: v for k, v in prof.items() if v["flops"] > 0}
         # MFMA-bound candidates: the tile-engine kernels.  The M = batch scan GEMM ("skinny16"/"narrowN") is a
         # weight-streaming, latency-bound kernel and is reported on its own below.
-        tile_engine = {k: v for k, v in mf.items() if "skinny16" not in k and "narrowN" not in k}
+        tile_engine = {k: v for k, v in mf.items()
+                       if k.startswith(("gemm_kernel", "conv")) and "skinny16" not in k and "narrowN" not in k}
         dom = max(tile_engine, key=lambda k: tile_engine[k]["ms"])
         d = tile_engine[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         tot_fl, tot_ms = sum(v["flops"] for v in mf.values()), sum(v["ms"] for v in mf.values())
         sym = ops.kernel_symbol(dom)
-        traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        # HBM/fabric bytes and MFMA-busy come from hardware counters, which only a rocprofv3 --pmc run can read: they
+        # are looked up in the newest committed summaries of the SAME command (profiles/rNN_pmc_*.json, written by
+        # tools/pmc_traffic.py / tools/pmc_mfma.py) and are NOT measured inside this run (flagged below).
+        traffic, traffic_src, mfma_pmc = None, None, None
+        import glob
+
+        for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            try:
+                pmc = json.load(open(path))["kernels"]
+            except Exception:
+                continue
             if sym in pmc:
                 traffic = pmc[sym]["bytes_per_launch"]
-                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        except Exception:
-            pass
+                traffic_src = (f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                               "passes, gfx950 x2 read correction)")
+                break
+        for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_mfma.json")), reverse=True):
+            try:
+                pm = json.load(open(path))["kernels"]
+            except Exception:
+                continue
+            if sym in pm:
+                mfma_pmc = {"mfma_util": pm[sym]["mfma_util"], "source": f"profiles/{os.path.basename(path)} "
+                            "(SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))"}
+                break
         scan = {k: v for k, v in mf.items() if "skinny16" in k}
         scan_ms = sum(v["ms"] for v in scan.values())
         scan_n = sum(v["launches"] for v in scan.values())
         scan_bytes = sum(v["bytes"] for v in scan.values())
         roofline = {"bound": "mfma", "kernel": dom, "kernel_symbol": sym, "achieved": ach,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False,
+                    "mfma_busy_counter": mfma_pmc,
                     "launches_per_update": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                     "flops_per_launch": d["flops"] / d["launches"],
                     "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
@@ -305,8 +320,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{name}: dmc_vision 64x64x3 replay, RSSM deter={shape['deter']} stoch="
-                                   f"{shape['stoch']}x{shape['discrete']}, batch {B} x seq {T} per GPU, horizon {H}; "
+            "config": {"workload": f"{name}: {WORKLOADS.get(name, name)}, RSSM deter={shape['deter']} hidden="
+                                   f"{shape['hidden']} stoch={shape['stoch']}x{shape['discrete']}, "
+                                   f"{'one-hot' if shape['actor_dist'] == 'onehot' else 'continuous'} actor ({shape['A']}), "
+                                   f"imag_gradient {shape['imag_gradient']}, batch {B} x seq {T} per GPU, horizon {H}; "
                                    "one step = full Dreamer._train update (world model + actor + critic fwd/bwd, "
                                    "gradient all-reduce, 3x clip+Adam)",
                        "global_batch": B * world, "seq_len": T, "horizon": H, "parallelism": f"dp{world}",

@@ -23,7 +23,9 @@ __global__ __launch_bounds__(256) void onehot_sample_kernel(const float* __restr
                                                             unsigned long long offset_add,
                                                             const float* __restrict__ nb_first,
                                                             const float* __restrict__ nb_init,
-                                                            float* __restrict__ nb_out, int nb_groups) {
+                                                            float* __restrict__ nb_out, int nb_groups,
+                                                            const int* __restrict__ nb_init_idx,
+                                                            int* __restrict__ nb_idx_out) {
   constexpr int GPB = 256 / G;
   const int sub = threadIdx.x / G, d = threadIdx.x % G;
   const bool valid = d < D;
@@ -82,6 +84,8 @@ __global__ __launch_bounds__(256) void onehot_sample_kernel(const float* __restr
       }
     }
     if (rv && d == 0 && idx_out) idx_out[r] = bi;
+    // class index of the blended next-step state (a one-hot either way: the sample or the initial state's mode)
+    if (rv && d == 0 && nb_idx_out) nb_idx_out[r] = (nb_first[r / nb_groups] != 0.f) ? nb_init_idx[r % nb_groups] : bi;
   }
 }
 
@@ -284,7 +288,7 @@ extern "C" int dv3_onehot_sample_fwd(const float* logit, const float* noise, con
   DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_sample_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
                                        logit, noise, rng_state, onehot, idx, (const int*)nullptr,
                                        (unsigned int*)nullptr, R, D, unimix, mode, rng_offset, nullptr, nullptr,
-                                       nullptr, 1));
+                                       nullptr, 1, (const int*)nullptr, (int*)nullptr));
   return (int)hipGetLastError();
 }
 
@@ -295,16 +299,17 @@ extern "C" int dv3_onehot_sample_fwd_ex(const float* logit, const float* noise, 
                                         unsigned long long rng_offset, float* onehot, int* idx, const int* forced,
                                         unsigned int* flips, long R, int D, float unimix, int mode,
                                         const float* next_first, const float* init, float* next_out, int groups,
-                                        void* stream) {
+                                        const int* init_idx, int* next_idx, void* stream) {
   if (R <= 0) return 0;
   if (D <= 0 || D > 64 || !logit || !onehot) return DV3_ERR_ARG;
   if (!mode && !noise && !rng_state) return DV3_ERR_ARG;
   if (next_first && (!init || !next_out || groups <= 0 || R % groups)) return DV3_ERR_ARG;
-  if (!next_first) { init = nullptr; next_out = nullptr; groups = 1; }
+  if (next_idx && (!next_first || !init_idx)) return DV3_ERR_ARG;
+  if (!next_first) { init = nullptr; next_out = nullptr; groups = 1; next_idx = nullptr; }
   hipStream_t s = (hipStream_t)stream;
   DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_sample_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
                                        logit, noise, rng_state, onehot, idx, forced, flips, R, D, unimix, mode,
-                                       rng_offset, next_first, init, next_out, groups));
+                                       rng_offset, next_first, init, next_out, groups, init_idx, next_idx));
   return (int)hipGetLastError();
 }
 
@@ -322,7 +327,7 @@ extern "C" int dv3_onehot_sample_fwd_blend(const float* logit, const float* nois
   DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_sample_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
                                        logit, noise, rng_state, onehot, (int*)nullptr, (const int*)nullptr,
                                        (unsigned int*)nullptr, R, D, unimix, mode, rng_offset, next_first, init,
-                                       next_out, groups));
+                                       next_out, groups, (const int*)nullptr, (int*)nullptr));
   return (int)hipGetLastError();
 }
 

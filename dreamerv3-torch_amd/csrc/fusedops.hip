@@ -207,23 +207,15 @@ struct AHParams {
   int onehot;
 };
 
-// wlds != 0: the head weights ([A][U] mean rows, then [A][U] std rows) are first copied into dynamic LDS by the whole
-// workgroup: every wave of the chip walks the same 2A weight rows in step, and from global memory that is 2A
-// dependent round trips onto the same few cache lines (measured 26-36 us for 1024 rows; the L2 channels holding
-// those lines serialise the 256 CUs).
+// The heads are 2A (or A) dot products of length U per row.  Every wave of the chip walks the same weight rows, so
+// the loads of a batch of OB outputs are ALL issued before the first multiply (one memory round trip per batch, not
+// one per output), and wave w starts its batch at output w % OB so that the 1024 waves do not hit the same cache
+// lines at the same moment (from global memory in output order this took 26-36 us for 1024 rows).
 template <int NV>
-__global__ __launch_bounds__(256) void actor_head_kernel(AHParams p, int wlds) {
-  extern __shared__ __attribute__((aligned(16))) float wsh[];
+__global__ __launch_bounds__(256) void actor_head_kernel(AHParams p) {
   __shared__ float hsh[4 * 16 * 65];
   __shared__ float hres[4 * 128];
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  if (wlds) {
-    const int nm = p.A * p.U;
-    for (int i = threadIdx.x; i < nm; i += 256) wsh[i] = p.Wm[i];
-    if (p.Ws)
-      for (int i = threadIdx.x; i < nm; i += 256) wsh[nm + i] = p.Ws[i];
-    __syncthreads();
-  }
   const float inv_n = 1.f / (float)p.U;
   float g[NV], b[NV];
 #pragma unroll
@@ -237,6 +229,28 @@ __global__ __launch_bounds__(256) void actor_head_kernel(AHParams p, int wlds) {
     seed = p.rng[0];
     offset = p.rng[1] + p.rng_off;
   }
+  const int nout = p.Ws ? 2 * p.A : p.A;
+  constexpr int OB = (NV <= 8) ? 12 : 6;  // OB * NV weight registers per batch of outputs
+  const int rot = (int)((blockIdx.x * 4 + wave) % OB);
+  auto load_w = [&](float (&wv)[OB][NV], int o0) {
+    const int no = min(OB, nout - o0);
+#pragma unroll
+    for (int jj = 0; jj < OB; ++jj) {
+      const int j = (jj + rot) % OB;
+      const int o = o0 + j;
+      if (j < no) {  // wave-uniform
+        const float* w = (o < p.A) ? p.Wm + (long)o * p.U : p.Ws + (long)(o - p.A) * p.U;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int c = l + 64 * v;
+          wv[jj][v] = c < p.U ? w[c] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) wv[jj][v] = 0.f;
+      }
+    }
+  };
   for (long r = (long)blockIdx.x * 4 + wave; r < p.M; r += (long)gridDim.x * 4) {
     float x[NV];
     float s = 0.f;
@@ -271,20 +285,19 @@ __global__ __launch_bounds__(256) void actor_head_kernel(AHParams p, int wlds) {
     {
       float* sh = hsh + wave * (16 * 65);
       float* res = hres + wave * 128;
-      const int nout = p.Ws ? 2 * p.A : p.A;
-      for (int o0 = 0; o0 < nout; o0 += 16) {
-        const int no = min(16, nout - o0);
-        for (int j = 0; j < no; ++j) {
-          const int o = o0 + j;
-          const float* w = wlds ? wsh + (long)o * p.U
-                                : ((o < p.A) ? p.Wm + (long)o * p.U : p.Ws + (long)(o - p.A) * p.U);
+      for (int o0 = 0; o0 < nout; o0 += OB) {
+        const int no = min(OB, nout - o0);
+        // (hoisting the first batch above the row's own loads and LayerNorm was measured: 96 live registers across
+        // the whole kernel, 15.6 -> 33 us)
+        float wn[OB][NV];
+        load_w(wn, o0);
+#pragma unroll
+        for (int jj = 0; jj < OB; ++jj) {
+          const int j = (jj + rot) % OB;
           float d = 0.f;
 #pragma unroll
-          for (int v = 0; v < NV; ++v) {
-            const int c = l + 64 * v;
-            if (c < p.U) d += x[v] * w[c];
-          }
-          sh[j * 65 + l] = d;
+          for (int v = 0; v < NV; ++v) d += x[v] * wn[jj][v];
+          if (j < no) sh[j * 65 + l] = d;
         }
         __builtin_amdgcn_wave_barrier();
         if (l < no) {
@@ -472,22 +485,11 @@ extern "C" int dv3_actor_head_fwd(const float* pre, long ldpre, const float* gam
   AHParams p{pre, ldpre, gamma, beta, y, ldy, mean, rstd, Wm, bm, Ws, bs, out_m, out_s, noise, rng_state, rng_offset,
              eps_out, action, entropy, act_idx, forced, flips, M, U, A, min_std, max_std, unimix, onehot};
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(cap_grid(M, 4, 2048)), block(256);
-  const size_t wbytes = (size_t)(onehot ? 1 : 2) * A * U * sizeof(float);
-  const int wlds = wbytes <= 96 * 1024;
-  const size_t sh = wlds ? wbytes : 0;
-#define DV3_AH(NV_)                                                                                              \
-  do {                                                                                                           \
-    if (sh > 32 * 1024)                                                                                          \
-      (void)hipFuncSetAttribute((const void*)actor_head_kernel<NV_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)sh);                                                                        \
-    hipLaunchKernelGGL((actor_head_kernel<NV_>), grid, block, sh, s, p, wlds);                                   \
-  } while (0)
-  if (U <= 64) DV3_AH(1);
-  else if (U <= 256) DV3_AH(4);
-  else if (U <= 512) DV3_AH(8);
-  else DV3_AH(16);
-#undef DV3_AH
+  const dim3 grid(cap_grid(M, 4, 4096)), block(256);
+  if (U <= 64) hipLaunchKernelGGL((actor_head_kernel<1>), grid, block, 0, s, p);
+  else if (U <= 256) hipLaunchKernelGGL((actor_head_kernel<4>), grid, block, 0, s, p);
+  else if (U <= 512) hipLaunchKernelGGL((actor_head_kernel<8>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((actor_head_kernel<16>), grid, block, 0, s, p);
   return (int)hipGetLastError();
 }
 

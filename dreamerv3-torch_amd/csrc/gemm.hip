@@ -42,6 +42,13 @@ struct GemmParams {
   unsigned int* smp_flips;
   float smp_unimix;
   int smp_mode;
+  // direct kernel, ALN = 1: A holds PRE-activations; SiLU(LayerNorm(A) * gamma + beta) is applied as the operand is
+  // loaded (row statistics computed by the workgroup itself over its 32 rows), so the LayerNorm of the producing
+  // layer needs no launch of its own.  ln_mean / ln_rstd [M] receive the statistics (saved for the backward).
+  const float* ln_gamma;
+  const float* ln_beta;
+  float* ln_mean;
+  float* ln_rstd;
 };
 
 template <class TS, bool TA, bool TB>
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
 // PIPE = 1: the loads of batch t+1 are issued before the MFMAs of batch t (two register sets).  PIPE = 0: one register
 // set, a batch is loaded then consumed; latency is hidden by the other resident waves only -- with BATCH = 2 a wave
 // then consumes whole 128-byte lines of its 16 operand rows per batch (two adjacent 16-k chunks) at ~110 VGPRs.
-template <bool TB, int RN, int BATCH, int EPI = 0, int PIPE = 1>
+template <bool TB, int RN, int BATCH, int EPI = 0, int PIPE = 1, int ALN = 0>
 __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float dred[];  // [waves][2][RN][256]
   __shared__ float ctile[EPI == 1 ? 32 * (16 * RN + 1) : 1];
@@ -284,6 +291,46 @@ __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
     arow[t] = p.A + (long)(ok ? row : 0) * p.lda;
     arow2[t] = p.A2 ? p.A2 + (long)(ok ? row : 0) * p.lda2 : nullptr;
   }
+  float lmean[2] = {0.f, 0.f}, lrstd[2] = {1.f, 1.f};
+  f32x4 gk[BATCH], bk[BATCH];
+  if constexpr (ALN) {
+    __shared__ float lnst[32][2];
+    const float inv_k = 1.f / (float)p.K;
+    for (int rr = wave; rr < 32; rr += nwaves) {  // wave-uniform
+      const int row = m0 + rr;
+      if (row < p.M) {
+        const float* ar = p.A + (long)row * p.lda;
+        float sm = 0.f;
+        for (int k = 4 * lane; k < p.K; k += 256) {
+          const f32x4 v = *reinterpret_cast<const f32x4u*>(ar + k);
+          sm += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        const float mean = group_sum<64>(sm) * inv_k;
+        float qv = 0.f;
+        for (int k = 4 * lane; k < p.K; k += 256) {
+          const f32x4 v = *reinterpret_cast<const f32x4u*>(ar + k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qv += (v[e] - mean) * (v[e] - mean);
+        }
+        const float rstd = rsqrtf(group_sum<64>(qv) * inv_k + kLnEps);
+        if (lane == 0) {
+          lnst[rr][0] = mean;
+          lnst[rr][1] = rstd;
+          if (tn == 0) {
+            if (p.ln_mean) p.ln_mean[row] = mean;
+            if (p.ln_rstd) p.ln_rstd[row] = rstd;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (m0 + i + 16 * t < p.M) {
+        lmean[t] = lnst[i + 16 * t][0];
+        lrstd[t] = lnst[i + 16 * t][1];
+      }
+  }
   // software pipeline: the loads of batch t+1 are issued before the MFMAs of batch t (two register sets)
   f32x4 a0[BATCH][2], b0[BATCH][RN], a1[BATCH][2], b1[BATCH][RN];
   const int clast = ce - 1;
@@ -299,6 +346,10 @@ __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
           a[u][t] = *reinterpret_cast<const f32x4u*>(seg2 ? arow2[t] + (k - p.K1) : arow[t] + k);
+        if constexpr (ALN) {
+          gk[u] = *reinterpret_cast<const f32x4u*>(p.ln_gamma + k);
+          bk[u] = *reinterpret_cast<const f32x4u*>(p.ln_beta + k);
+        }
 #pragma unroll
         for (int c = 0; c < RN; ++c) {
           if (TB) {
@@ -328,6 +379,13 @@ __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
           }
           a[u][t] = v;
         }
+        if constexpr (ALN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            gk[u][e] = (cc < ce && k + e < p.K) ? p.ln_gamma[k + e] : 0.f;
+            bk[u][e] = (cc < ce && k + e < p.K) ? p.ln_beta[k + e] : 0.f;
+          }
+        }
 #pragma unroll
         for (int c = 0; c < RN; ++c) {
           f32x4 w = {0.f, 0.f, 0.f, 0.f};
@@ -349,7 +407,9 @@ __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            const float av = a[u][t][g] * amask[t];
+            float av = a[u][t][g];
+            if constexpr (ALN) av = siluf_((av - lmean[t]) * lrstd[t] * gk[u][g] + bk[u][g]);
+            av *= amask[t];
 #pragma unroll
             for (int c = 0; c < RN; ++c)
               acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u][c][g] * bmask[c], acc[t][c], 0, 0, 0);
@@ -405,47 +465,83 @@ __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
       seed = p.smp_rng[0];
       offset = p.smp_rng[1] + p.smp_off;
     }
-    for (int pr = tid >> 5; pr < 32 * GT; pr += blockDim.x >> 5) {
-      const int row_l = pr / GT, gl = pr % GT;
-      const int row = m0 + row_l, col0 = n0 + 32 * gl;
-      const bool rv = row < p.M && col0 < p.N;
-      const float lg = ctile[row_l * (16 * RN + 1) + 32 * gl + d];
-      float sm, ph;
-      unimix_probs<32>(lg, true, 32, p.smp_unimix, sm, ph);
-      const long g = (long)row * S + (col0 >> 5);
-      float score = ph;
-      if (!p.smp_mode) {
-        float q;
-        if (p.smp_noise) {
-          q = rv ? p.smp_noise[g * 32 + d] : 1.f;
-        } else {
-          uint32_t o4[4];
-          const unsigned long long e = (unsigned long long)g * 32 + d;
-          Philox ph4(seed);
-          ph4(offset + (e >> 2), 0x5eedULL, o4);
-          q = fmaxf(-logf(u01(o4[e & 3])), 1e-30f);
-        }
-        score = ph / q;
-      }
-      float best = score;
-      int bi = d;
+    // 32 * GT (row, group) pairs over blockDim / 32 lane groups: UN pairs per lane group are worked on together so
+    // that their dependent shuffle chains (softmax max / sum, argmax) overlap instead of running back to back
+    constexpr int UN = 4;
+    const int ngrp = blockDim.x >> 5;
+    for (int pr0 = tid >> 5; pr0 < 32 * GT; pr0 += UN * ngrp) {
+      float lg[UN], sc[UN];
+      long gi[UN];
+      bool rv[UN];
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) {
-          best = ob;
-          bi = oi;
+      for (int u = 0; u < UN; ++u) {
+        const int pr = min(pr0 + u * ngrp, 32 * GT - 1);
+        const int row_l = pr / GT, gl = pr % GT;
+        const int row = m0 + row_l, col0 = n0 + 32 * gl;
+        rv[u] = (pr0 + u * ngrp < 32 * GT) && row < p.M && col0 < p.N;
+        lg[u] = ctile[row_l * (16 * RN + 1) + 32 * gl + d];
+        gi[u] = (long)row * S + (col0 >> 5);
+      }
+      float mx[UN], ex[UN], sm_[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) mx[u] = lg[u];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) mx[u] = fmaxf(mx[u], __shfl_xor(mx[u], o, 64));
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        ex[u] = expf(lg[u] - mx[u]);
+        sm_[u] = ex[u];
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) sm_[u] += __shfl_xor(sm_[u], o, 64);
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const float ph = (ex[u] / sm_[u]) * (1.f - p.smp_unimix) + p.smp_unimix / 32.f;
+        float score = ph;
+        if (!p.smp_mode) {
+          float q;
+          if (p.smp_noise) {
+            q = rv[u] ? p.smp_noise[gi[u] * 32 + d] : 1.f;
+          } else {
+            uint32_t o4[4];
+            const unsigned long long e = (unsigned long long)gi[u] * 32 + d;
+            Philox ph4(seed);
+            ph4(offset + (e >> 2), 0x5eedULL, o4);
+            q = fmaxf(-logf(u01(o4[e & 3])), 1e-30f);
+          }
+          score = ph / q;
         }
+        sc[u] = score;
       }
-      if (p.smp_forced) {
-        const int f = rv ? p.smp_forced[g] : 0;
-        if (rv && d == 0 && p.smp_flips && f != bi) atomicAdd(p.smp_flips, 1u);
-        bi = f;
-      }
-      if (rv) {
-        p.smp_onehot[g * 32 + d] = (d == bi) ? 1.f : 0.f;
-        if (d == 0 && p.smp_idx) p.smp_idx[g] = bi;
+      int bi[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) bi[u] = d;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const float ob = __shfl_xor(sc[u], o, 64);
+          const int oi = __shfl_xor(bi[u], o, 64);
+          if (ob > sc[u] || (ob == sc[u] && oi < bi[u])) {
+            sc[u] = ob;
+            bi[u] = oi;
+          }
+        }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (p.smp_forced) {
+          const int f = rv[u] ? p.smp_forced[gi[u]] : 0;
+          if (rv[u] && d == 0 && p.smp_flips && f != bi[u]) atomicAdd(p.smp_flips, 1u);
+          bi[u] = f;
+        }
+        if (rv[u]) {
+          p.smp_onehot[gi[u] * 32 + d] = (d == bi[u]) ? 1.f : 0.f;
+          if (d == 0 && p.smp_idx) p.smp_idx[gi[u]] = bi[u];
+        }
       }
     }
   }
@@ -463,11 +559,14 @@ static void launch_direct_rn(const GemmParams& p0, int waves, hipStream_t s) {
   static const int env_batch = getenv("DV3_DIRECT_BATCH") ? atoi(getenv("DV3_DIRECT_BATCH")) : 0;
   if constexpr (TB && RN == 4) {
     if (p.smp_onehot) {
-      hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 1, 1>), grid, block, sh, s, p);
+      if (p.ln_gamma) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 2, 1, 0, 1>), grid, block, sh, s, p);
+      else hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 2, 1, 0>), grid, block, sh, s, p);
       return;
     }
   }
-  static const int env_pipe = getenv("DV3_DIRECT_PIPE") ? atoi(getenv("DV3_DIRECT_PIPE")) : 1;
+  // measured (r02e, hipGraph back-to-back, us): y = x W^T shapes 1024x1536x1024 46.1 -> 43.8, 1024x512x512 10.9 -> 10.1,
+  // 1024x1024x512 18.1 -> 17.0 with PIPE 0 / BATCH 2; the [K][N] (data-gradient) form is better pipelined (40.8 vs 43.9)
+  static const int env_pipe = getenv("DV3_DIRECT_PIPE") ? atoi(getenv("DV3_DIRECT_PIPE")) : (TB ? 0 : 1);
   if (env_pipe == 0) {
     if (env_batch == 4) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 4, 0, 0>), grid, block, sh, s, p);
     else if (env_batch == 1) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 1, 0, 0>), grid, block, sh, s, p);
@@ -879,9 +978,11 @@ extern "C" int dv3_gemm_sample_f32(int M, int N, int K, const float* A, long lda
                                    const float* B, long ldb, float* C, long ldc, const float* bias,
                                    const float* noise, const unsigned long long* rng_state,
                                    unsigned long long rng_offset, float* onehot, int* idx, const int* forced,
-                                   unsigned int* flips, float unimix, int mode, void* stream) {
+                                   unsigned int* flips, float unimix, int mode, const float* ln_gamma,
+                                   const float* ln_beta, float* ln_mean, float* ln_rstd, void* stream) {
   if (M <= 0 || N <= 0) return 0;
   if (K <= 0 || !A || !B || !C || !onehot || (N % 64) != 0) return DV3_ERR_ARG;
+  if (ln_gamma && (!ln_beta || A2 || (K % 4) != 0 || (lda % 4) != 0)) return DV3_ERR_ARG;
   if (!mode && !noise && !rng_state) return DV3_ERR_ARG;
   if (A2 && (K1 <= 0 || K1 >= K || (K1 % 16) != 0)) return DV3_ERR_ARG;
   GemmParams p{};
@@ -892,6 +993,7 @@ extern "C" int dv3_gemm_sample_f32(int M, int N, int K, const float* A, long lda
   p.vecA = 1; p.vecB = 1;
   p.smp_noise = noise; p.smp_rng = rng_state; p.smp_off = rng_offset; p.smp_onehot = onehot; p.smp_idx = idx;
   p.smp_forced = forced; p.smp_flips = flips; p.smp_unimix = unimix; p.smp_mode = mode;
+  p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_mean = ln_mean; p.ln_rstd = ln_rstd;
   const int chunks = (K + 15) / 16;
   launch_direct_rn<true, 4>(p, chunks >= 32 ? 8 : 4, (hipStream_t)stream);
   return (int)hipGetLastError();

@@ -417,7 +417,8 @@ __global__ void actor_normal_logp_kernel(const float* __restrict__ mean_raw, con
   }
 }
 // Backward of the three actor outputs w.r.t. (mean_raw, std_raw):
-//   daction (through the rsample; the absmax rescale factor is a constant), dent, dlogp (action held fixed).
+//   daction (through the rsample; the absmax rescale factor is a constant), dent, dlogp (log-prob of the sampled
+//   action: with eps given the action is the rsample of this very (mean, std), as in models.py:667, else held fixed).
 // Any of daction / dent / dlogp may be null.
 __global__ void actor_normal_bwd_kernel(const float* __restrict__ mean_raw, const float* __restrict__ std_raw,
                                         const float* __restrict__ eps, const float* __restrict__ action,
@@ -440,9 +441,18 @@ __global__ void actor_normal_bwd_kernel(const float* __restrict__ mean_raw, cons
       }
       if (dent) dsd += dent[r] / sd;
       if (dlogp) {
+        // log N(a; mu, sd) with a = (mu + sd eps) * c the rsampled action itself (ContDist.sample, tools.py:594-598;
+        // c = 1 / max(|mu + sd eps|, 1) is detached): the explicit dependence on (mu, sd) plus the path through a
         const float d = action[i] - mu;
-        dmu += dlogp[r] * d / (sd * sd);
-        dsd += dlogp[r] * (d * d / (sd * sd * sd) - 1.f / sd);
+        float dmu_l = d / (sd * sd), dsd_l = d * d / (sd * sd * sd) - 1.f / sd;
+        if (eps) {
+          const float c = 1.f / fmaxf(fabsf(mu + sd * eps[i]), 1.f);
+          const float dla = -d / (sd * sd);
+          dmu_l += dla * c;
+          dsd_l += dla * c * eps[i];
+        }
+        dmu += dlogp[r] * dmu_l;
+        dsd += dlogp[r] * dsd_l;
       }
       dmean_raw[i] = dmu * (1.f - mu * mu);
       dstd_raw[i] = dsd * (max_std - min_std) * sg * (1.f - sg);
@@ -543,13 +553,14 @@ __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ x, c
 //   offset = ema[0], scale = max(ema[1]-ema[0], 1)                                  (models.py:24-25)
 //   dynamics : loss_t = -w_t ((target_t-offset)/scale - (base_t-offset)/scale) - c ent_t ; dtarget = -w_t/(scale*cnt)
 //   reinforce: loss_t = -w_t logp_t (target_t - base_t) - c ent_t                ; dlogp   = -w_t (target_t-base_t)/cnt
+//   both     : loss_t = -w_t (mix target_t + (1-mix) logp_t sg(target_t - base_t)) - c ent_t; both gradients
 // loss_out[0] += mean over the (H-1)*N entries; dent = -c/cnt on rows < H-1, 0 on the last row.
 __global__ void actor_loss_kernel(const float* __restrict__ target, const float* __restrict__ value,
                                   const float* __restrict__ weights, const float* __restrict__ ent,
                                   const float* __restrict__ logp, const float* __restrict__ ema,
                                   float* __restrict__ loss_out, float* __restrict__ dtarget,
                                   float* __restrict__ dlogp, float* __restrict__ dent, int H, long N, float ent_coef,
-                                  int reinforce) {
+                                  int mode, float mix) {
   __shared__ float red[4];
   const long cnt = (long)(H - 1) * N;
   const float inv = 1.f / (float)cnt;
@@ -559,10 +570,15 @@ __global__ void actor_loss_kernel(const float* __restrict__ target, const float*
     if (i < cnt) {
       const float w = weights[i];
       float tgt;
-      if (reinforce) {
+      if (mode == 1) {  // reinforce
         const float adv = target[i] - value[i];
         tgt = logp[i] * adv;
         dlogp[i] = -w * adv * inv;
+      } else if (mode == 2) {  // both: mix * target + (1 - mix) * logp * sg(target - value)   (models.py:670-676)
+        const float adv = target[i] - value[i];
+        tgt = mix * target[i] + (1.f - mix) * logp[i] * adv;
+        dlogp[i] = -w * (1.f - mix) * adv * inv;
+        dtarget[i] = -w * mix * inv;
       } else {
         tgt = (target[i] - offset) / scale - (value[i] - offset) / scale;
         dtarget[i] = -w * inv / scale;
@@ -571,7 +587,7 @@ __global__ void actor_loss_kernel(const float* __restrict__ target, const float*
       dent[i] = -ent_coef * inv;
     } else {
       dent[i] = 0.f;
-      if (reinforce) dlogp[i] = 0.f;
+      if (mode != 0) dlogp[i] = 0.f;
     }
   }
   a = block_sum_256(a, red);
@@ -777,12 +793,14 @@ extern "C" int dv3_dot_accumulate(const float* x, const float* w, long n, float*
 }
 extern "C" int dv3_actor_loss(const float* target, const float* value, const float* weights, const float* entropy,
                               const float* logp, const float* ema_vals, float* loss_out, float* dtarget, float* dlogp,
-                              float* dentropy, int H, long N, float entropy_coef, int reinforce, void* stream) {
+                              float* dentropy, int H, long N, float entropy_coef, int mode, float mix, void* stream) {
   if (N <= 0) return 0;
   if (H < 2 || !target || !value || !weights || !entropy || !ema_vals || !loss_out || !dentropy) return DV3_ERR_ARG;
-  if (reinforce ? (!logp || !dlogp) : !dtarget) return DV3_ERR_ARG;
+  if (mode < 0 || mode > 2) return DV3_ERR_ARG;
+  if (mode != 0 && (!logp || !dlogp)) return DV3_ERR_ARG;
+  if (mode != 1 && !dtarget) return DV3_ERR_ARG;
   hipLaunchKernelGGL(actor_loss_kernel, dim3(nblk((long)H * N, 1024, 512)), dim3(256), 0, S_, target, value, weights,
-                     entropy, logp, ema_vals, loss_out, dtarget, dlogp, dentropy, H, N, entropy_coef, reinforce);
+                     entropy, logp, ema_vals, loss_out, dtarget, dlogp, dentropy, H, N, entropy_coef, mode, mix);
   return (int)hipGetLastError();
 }
 extern "C" int dv3_scale_neg(const float* w, float* out, long n, float s, void* stream) {

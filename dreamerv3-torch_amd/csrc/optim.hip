@@ -84,6 +84,74 @@ __global__ void fill_normal_kernel(float* __restrict__ out, long n, const unsign
   }
 }
 
+
+// Two quantiles of n values by exact radix selection + the return-normalisation EMA (models.RewardEMA, models.py:11-26:
+// torch.quantile(x, [0.05, 0.95]) -- linear interpolation between the two neighbouring order statistics at
+// q (n - 1) -- then ema = alpha q + (1 - alpha) ema).  One workgroup: the four order statistics (floor / ceil rank of
+// each quantile) are selected together, one key byte per pass (4 passes over x, LDS histograms), so the result is
+// the exact value torch.sort would give; n = (H-1) B T is 14 k .. 460 k on the BASELINE configs.
+__device__ __forceinline__ uint32_t fkey(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__global__ __launch_bounds__(1024) void quantile2_ema_kernel(const float* __restrict__ x, long n, double q0, double q1,
+                                                             float* __restrict__ ema, float alpha,
+                                                             float* __restrict__ out_q) {
+  __shared__ unsigned int hist[4][256];
+  __shared__ uint32_t prefix[4];
+  __shared__ long rank[4];
+  __shared__ float frac[2];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    const double p0 = q0 * (double)(n - 1), p1 = q1 * (double)(n - 1);
+    rank[0] = (long)floor(p0); rank[1] = (long)ceil(p0);
+    rank[2] = (long)floor(p1); rank[3] = (long)ceil(p1);
+    frac[0] = (float)(p0 - floor(p0)); frac[1] = (float)(p1 - floor(p1));
+    for (int t = 0; t < 4; ++t) prefix[t] = 0u;
+  }
+  uint32_t mask = 0u;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    for (int i = tid; i < 4 * 256; i += 1024) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    const uint32_t p0 = prefix[0], p1 = prefix[1], p2 = prefix[2], p3 = prefix[3];
+    for (long i = tid; i < n; i += 1024) {
+      const uint32_t k = fkey(x[i]);
+      const uint32_t km = k & mask, b = (k >> shift) & 255u;
+      if (km == p0) atomicAdd(&hist[0][b], 1u);
+      if (km == p1) atomicAdd(&hist[1][b], 1u);
+      if (km == p2) atomicAdd(&hist[2][b], 1u);
+      if (km == p3) atomicAdd(&hist[3][b], 1u);
+    }
+    __syncthreads();
+    if (tid < 4) {
+      long r = rank[tid];
+      unsigned int b = 0;
+      for (; b < 255; ++b) {
+        const unsigned int c = hist[tid][b];
+        if (r < (long)c) break;
+        r -= c;
+      }
+      rank[tid] = r;
+      prefix[tid] |= b << shift;
+    }
+    mask |= 0xFFu << shift;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float a0 = fkey_inv(prefix[0]), a1 = fkey_inv(prefix[1]), b0 = fkey_inv(prefix[2]), b1 = fkey_inv(prefix[3]);
+    const float v0 = a0 + (a1 - a0) * frac[0], v1 = b0 + (b1 - b0) * frac[1];
+    if (out_q) { out_q[0] = v0; out_q[1] = v1; }
+    if (ema) {
+      ema[0] = alpha * v0 + (1.f - alpha) * ema[0];
+      ema[1] = alpha * v1 + (1.f - alpha) * ema[1];
+    }
+  }
+}
+
 // advance the Philox offset kept in device memory: rng_state = {seed, offset}
 __global__ void rng_advance_kernel(unsigned long long* st, unsigned long long inc) { st[1] += inc; }
 
@@ -139,4 +207,11 @@ extern "C" int dv3_fill_normal(float* out, long n, const unsigned long long* rng
   return (int)hipGetLastError();
 }
 
-extern "C" int dv3_version(void) { return 1; }
+extern "C" int dv3_quantile2_ema(const float* x, long n, double q0, double q1, float* ema, float alpha, float* out_q,
+                                 void* stream) {
+  if (n <= 0 || !x || (!ema && !out_q) || q0 < 0.0 || q0 > 1.0 || q1 < 0.0 || q1 > 1.0) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(quantile2_ema_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, q0, q1, ema, alpha, out_q);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_version(void) { return 2; }

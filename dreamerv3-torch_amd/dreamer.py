@@ -37,7 +37,7 @@ class Dreamer(nn.Module):
         if config.expl_behavior != "greedy":
             raise NotImplementedError("only expl_behavior='greedy' is on the accelerated path")
         self._expl_behavior = self._task_behavior
-        self._runner, self._stager = None, None
+        self._runner, self._stager, self._policy_runner = None, None, None
         self._metric_keys, self._metric_sum, self._metric_n = [], None, 0
 
     def __call__(self, obs, reset, state=None, training=True):
@@ -65,6 +65,24 @@ class Dreamer(nn.Module):
         return policy_output, state
 
     def _policy(self, obs, state, training, noise=None):
+        """Acting step.  With config.hip_graph (default) the launch sequence is replayed from a hipGraph per
+        (number of envs, training) signature (dv3hip.graph.PolicyRunner); injected noise (tests) takes the eager path."""
+        if noise is None and bool(getattr(self._config, "hip_graph", True)) and self._policy_runner is not False:
+            try:
+                if self._policy_runner is None:
+                    from dv3hip.graph import PolicyRunner
+
+                    self._policy_runner = PolicyRunner(self)
+                return self._policy_runner.step(obs, state, training)
+            except Exception as e:  # a runtime that refuses capture: keep acting, launch eagerly
+                import sys
+
+                print(f"[dv3hip] hipGraph capture of the policy step failed ({type(e).__name__}: {e}); eager launches",
+                      file=sys.stderr)
+                self._policy_runner = False
+        return self._policy_eager(obs, state, training, noise)
+
+    def _policy_eager(self, obs, state, training, noise=None):
         """dreamer.py:116-188 for expl_behavior 'greedy' (expl_until 0 makes _should_expl always true there, so
         training samples the task actor; the counterfactual branch behind `_best_candidate` is unreachable, SURVEY.md
         section 0 gotcha 2).  noise (tests): dict(prior, post [n_envs,S,D] ~ Exp(1); act [n_envs,A], N(0,1) or

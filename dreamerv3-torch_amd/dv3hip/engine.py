@@ -34,6 +34,11 @@ F32 = torch.float32
 
 _FUSE_BLEND = os.environ.get("DV3_FUSE_BLEND", "1") != "0"  # development switch (A/B runs)
 _FUSE_SAMPLE = os.environ.get("DV3_FUSE_SAMPLE", "1") != "0"  # sampling in the epilogue of the prior-logit GEMM
+# img_out LayerNorm+SiLU applied on the A-load of the prior-logit GEMM instead of a launch of its own.  OFF: measured
+# (r02j, 1024 rows) the GEMM goes 27 -> 49.5 us -- its 16 column tiles each redo the SiLU of the same A rows and the
+# wave's VALU work (16 exp + 16 div per 64 MFMAs) exceeds its MFMA time -- against the 7 us LayerNorm launch it removes.
+_LN_ON_LOAD = os.environ.get("DV3_LN_ON_LOAD", "0") != "0"
+_GATHER_OBS = os.environ.get("DV3_GATHER_OBS", "1") != "0"  # one-hot gather for img_in / head first layers in observe
 
 
 class SideStream:
@@ -76,18 +81,24 @@ class SideStream:
 
 
 class Workspace:
-    """Named device buffers, allocated on first use and reused (no allocation in steady state)."""
+    """Named device buffers, allocated on first use and reused (no allocation in steady state).
+
+    A buffer is keyed by (name, shape, dtype) and is NEVER freed or replaced: captured hipGraphs hold raw pointers into
+    these buffers, and the same engine serves several shapes in turn (training on B*T rows, acting on #envs rows,
+    video prediction on 6 sequences) -- replacing "enc.pre0" when the row count changes would hand the old block
+    back to the allocator while a graph still writes to it."""
 
     def __init__(self, device):
         self.device = device
-        self._b: Dict[str, torch.Tensor] = {}
+        self._b: Dict[tuple, torch.Tensor] = {}
 
     def get(self, name, shape, dtype=F32) -> torch.Tensor:
         shape = tuple(int(s) for s in shape)
-        t = self._b.get(name)
-        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+        key = (name, shape, dtype)
+        t = self._b.get(key)
+        if t is None:
             t = torch.empty(shape, dtype=dtype, device=self.device)
-            self._b[name] = t
+            self._b[key] = t
         return t
 
     def zeros(self, name, shape, dtype=F32) -> torch.Tensor:
@@ -326,7 +337,8 @@ class RSSMEngine:
         l0 = ws.get("init.logit", (1, self.SD))
         ops.gemm(x0, P.ims.W, l0, bias=P.ims.b)
         s0 = ws.get("init.stoch", (1, self.SD))
-        ops.onehot_sample(l0.view(self.S, self.D), s0.view(self.S, self.D), unimix=self.unimix, mode=True)
+        ops.onehot_sample(l0.view(self.S, self.D), s0.view(self.S, self.D), unimix=self.unimix, mode=True,
+                          idx=ws.get("init.idx", (self.S,), torch.int32))
         return s0, d0
 
     def init_state_bwd(self, dstoch0, ddeter0):
@@ -379,6 +391,13 @@ class RSSMEngine:
         x3pre, x3 = g("obs.x3pre", (T, B, Hd)), g("obs.x3", (T, B, Hd))
         m3, r3 = g("obs.m3", (T, B)), g("obs.r3", (T, B))
         post_logit, post_stoch = g("obs.post_logit", (T, B, S, D)), g("obs.post_stoch", (T, B, S, D))
+        # class indices of the (one-hot) posterior samples and of the blended step inputs: the Linears that read
+        # them gather weight columns instead of multiplying the one-hot (ops.onehot_linear_ln)
+        post_idx, idx_in = g("obs.post_idx", (T, B, S), torch.int32), g("obs.idx_in", (T, B, S), torch.int32)
+        init_idx = g("init.idx", (S,), torch.int32)
+        gather = _GATHER_OBS
+        if gather:
+            wt_in = self.pack_img_in()
         # embed half of obs_out for all steps at once: x3pre = embed @ W_obs[:, De:]^T
         ops.gemm(v2(embed_tm, E), P.obs_out.W[:, De:], v2(x3pre, Hd))
         # Reset blends (networks.py:183-191) off the per-step critical path: the action blend needs no state (one
@@ -391,8 +410,14 @@ class RSSMEngine:
                 prev_s = post_stoch[t - 1].view(B, SD) if t > 0 else (None if state0 is None else state0[0])
                 prev_d = deter[t - 1] if t > 0 else (None if state0 is None else state0[1])
                 ops.obs_blend(prev_s, s0.view(SD), prev_d, d0.view(De), action_tm[t], first[t], sin[t], din[t], ain[t])
+                if gather:
+                    ops.onehot_to_idx(sin[t].view(B, S, D), idx_in[t].view(-1))
             nxt = fuse and t + 1 < T
-            dense_ln_fwd(P.img_in, sin[t], ain[t], x1pre[t], m1[t], r1[t], x1[t])
+            if gather:
+                ops.onehot_linear_ln(idx_in[t], D, wt_in, x1pre[t], x2=ain[t], gamma=P.img_in.g, beta=P.img_in.b,
+                                     y=x1[t], mean=m1[t], rstd=r1[t])
+            else:
+                dense_ln_fwd(P.img_in, sin[t], ain[t], x1pre[t], m1[t], r1[t], x1[t])
             ops.gemm(x1[t], P.gru.W, gpre[t], A2=din[t])
             ops.gru_fwd(gpre[t], P.gru.g, P.gru.b, din[t], deter[t], mg[t], rg[t],
                         next_blend=(first[t + 1], d0.view(De), din[t + 1]) if nxt else None)
@@ -401,8 +426,9 @@ class RSSMEngine:
             ops.gemm(x3[t], P.obs.W, post_logit[t].view(B, SD), bias=P.obs.b)
             ops.onehot_sample(post_logit[t], post_stoch[t], noise=None if q_post is None else q_post[t], rng=rng,
                               unimix=self.unimix,
-                              next_blend=(first[t + 1], s0.view(SD), sin[t + 1].view(B, S, D)) if nxt else None,
-                              forced=None if f_post is None else f_post[t], flips=flips)
+                              next_blend=(first[t + 1], s0.view(SD), sin[t + 1].view(B, S, D), init_idx,
+                                          idx_in[t + 1].view(-1)) if nxt else None,
+                              forced=None if f_post is None else f_post[t], flips=flips, idx=post_idx[t].view(-1))
         # prior head for all steps at once
         x2pre, x2 = g("obs.x2pre", (T, B, Hd)), g("obs.x2", (T, B, Hd))
         m2, r2 = g("obs.m2", (T, B)), g("obs.r2", (T, B))
@@ -413,7 +439,7 @@ class RSSMEngine:
                           flips=flips)
         self._embed = embed_tm
         return dict(post_stoch=post_stoch, post_logit=post_logit, deter=deter, prior_stoch=prior_stoch,
-                    prior_logit=prior_logit, action=ain)
+                    prior_logit=prior_logit, action=ain, post_idx=post_idx)
 
     def observe_bwd(self, dpost_logit, dprior_logit, gs, gd, dembed, extra_side=None):
         """Backward of observe_fwd.
@@ -523,23 +549,42 @@ class RSSMEngine:
             dense_ln_fwd(P.img_in, stoch, action, bufs["x1pre"], bufs["m1"], bufs["r1"], bufs["x1"])
         ops.gemm(bufs["x1"], P.gru.W, bufs["gpre"], A2=deter)
         ops.gru_fwd(bufs["gpre"], P.gru.g, P.gru.b, deter, bufs["deter"], bufs["mg"], bufs["rg"])
+        fuse_smp = _FUSE_SAMPLE and ops.gemm_sample_ok(M, self.SD, self.D)
+        # the img_out LayerNorm + SiLU rides on the operand load of the prior-logit GEMM (x2 is then never stored: the
+        # imagination backward needs x2pre and the statistics only)
+        ln_on_load = fuse_smp and _LN_ON_LOAD and self.Hd % 4 == 0 and bufs["x2pre"].stride(0) % 4 == 0
         if wcat is not None:
             ops.gemm(bufs["deter"], wcat, bufs["cat"])
-            ops.ln_act_fwd(bufs["x2pre"], P.img_out.g, P.img_out.b, bufs["x2"], bufs["m2"], bufs["r2"], act=True)
         else:
-            dense_ln_fwd(P.img_out, bufs["deter"], None, bufs["x2pre"], bufs["m2"], bufs["r2"], bufs["x2"])
+            ops.gemm(bufs["deter"], P.img_out.W, bufs["x2pre"])
+        if not ln_on_load:
+            ops.ln_act_fwd(bufs["x2pre"], P.img_out.g, P.img_out.b, bufs["x2"], bufs["m2"], bufs["r2"], act=True)
         io = None if idx_out is None else idx_out.view(-1)
-        if _FUSE_SAMPLE and ops.gemm_sample_ok(M, self.SD, self.D):
-            ops.gemm_sample(bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD), bufs["stoch"], bias=P.ims.b,
-                            noise=noise, rng=rng, idx=io, forced=forced, flips=flips, unimix=self.unimix,
-                            mode=not sample)
+        if fuse_smp:
+            ops.gemm_sample(bufs["x2pre"] if ln_on_load else bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD),
+                            bufs["stoch"], bias=P.ims.b, noise=noise, rng=rng, idx=io, forced=forced, flips=flips,
+                            unimix=self.unimix, mode=not sample,
+                            ln=(P.img_out.g, P.img_out.b, bufs["m2"], bufs["r2"]) if ln_on_load else None)
         else:
             ops.gemm(bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD), bias=P.ims.b)
             ops.onehot_sample(bufs["logit"], bufs["stoch"], noise=noise, rng=rng, unimix=self.unimix, mode=not sample,
                               forced=forced, flips=flips, idx=io)
 
+    def pack_bwd(self):
+        """Transposed copies of the four img_step weights for its data gradients: dX = dY W is then the y = x B^T form
+        with B = W^T [K_in, N_out] (k-contiguous rows: 16-byte operand loads in the register-direct kernel, and the
+        6-column action gradient takes the narrow-output path).  Once per behaviour update: the world model's weights
+        are frozen while it runs (models.py:335), the 14 steps of the reverse rollout share the copies."""
+        P, ws = self.P, self.ws
+        wt = {"in": self.pack_img_in()}
+        for nm, W in (("gru", P.gru.W), ("out", P.img_out.W), ("ims", P.ims.W)):
+            t = ws.get(f"rssm.{nm}_wt", (W.shape[1], W.shape[0]))
+            ops.transpose2d(W, t)
+            wt[nm] = t
+        return wt
+
     def img_step_bwd(self, dstoch, ddeter, prev_deter, bufs, scratch, dprev_stoch, dprev_deter, daction,
-                     accumulate_prev=False):
+                     accumulate_prev=False, wt=None):
         """Input gradients of img_step_fwd (world-model weights frozen: no wgrad; models.py:335).
         dstoch [M,SD] / ddeter [M,De]: total gradient on the step's outputs (ddeter is used as scratch).
         Writes (or, with accumulate_prev, adds into) dprev_stoch / dprev_deter; writes daction."""
@@ -548,6 +593,21 @@ class RSSMEngine:
         S, D, SD, De, Hd = self.S, self.D, self.SD, self.De, self.Hd
         dlogit = scratch["dlogit"]
         ops.onehot_st_bwd(bufs["logit"], dstoch.view(M, S, D), dlogit.view(M, S, D), unimix=self.unimix)
+        if wt is not None:  # transposed weights (pack_bwd): every data gradient in the y = x B^T form
+            ops.gemm(dlogit, wt["ims"], scratch["dx2"])
+            dense_ln_bwd_pre(P.img_out, scratch["dx2"], bufs["x2pre"], bufs["m2"], bufs["r2"], scratch["dx2pre"],
+                             wgrad=False)
+            ops.gemm(scratch["dx2pre"], wt["out"], ddeter, accumulate=True)
+            ops.gru_bwd(ddeter, bufs["gpre"], P.gru.g, P.gru.b, prev_deter, bufs["mg"], bufs["rg"], scratch["dgpre"],
+                        dprev_deter, accumulate_dh=accumulate_prev)
+            ops.gemm(scratch["dgpre"], wt["gru"][Hd:], dprev_deter, accumulate=True)
+            ops.gemm(scratch["dgpre"], wt["gru"][:Hd], scratch["dx1"])
+            dense_ln_bwd_pre(P.img_in, scratch["dx1"], bufs["x1pre"], bufs["m1"], bufs["r1"], scratch["dx1pre"],
+                             wgrad=False)
+            ops.gemm(scratch["dx1pre"], wt["in"][:SD], dprev_stoch, accumulate=accumulate_prev)
+            if daction is not None:
+                ops.gemm(scratch["dx1pre"], wt["in"][SD:], daction)
+            return
         ops.gemm(dlogit, P.ims.W, scratch["dx2"], transB=False)
         dense_ln_bwd_pre(P.img_out, scratch["dx2"], bufs["x2pre"], bufs["m2"], bufs["r2"], scratch["dx2pre"],
                          wgrad=False)

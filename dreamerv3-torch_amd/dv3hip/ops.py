@@ -100,6 +100,8 @@ def kernel_symbol(key: str) -> str:
     """Profile key -> the C++ kernel name rocprofv3 prints (to match bench.py's roofline with profiles/)."""
     import re
 
+    if key.startswith("gemm_kernel<direct32x64+sample"):
+        return "void dv3::gemm_direct_kernel<true, 4, 2, 1, 0>(dv3::GemmParams)"
     m = re.match(r"gemm_kernel<([^,]+),tA=(\d),tB=(\d)>", key)
     if m:
         tile = {v: k for k, v in _TILE_NAMES.items()}[m.group(1)]
@@ -107,7 +109,8 @@ def kernel_symbol(key: str) -> str:
         if tile in (3, 7):
             return f"void dv3::gemm_skinny_kernel<{tb if tile == 3 else 'true'}, 1>(dv3::GemmParams)"
         if tile == 9:
-            return f"void dv3::gemm_direct_kernel<{tb}, 4, 1>(dv3::GemmParams)"
+            return (f"void dv3::gemm_direct_kernel<{tb}, 4, 2, 0, 0>(dv3::GemmParams)" if tb == "true"
+                    else f"void dv3::gemm_direct_kernel<{tb}, 4, 1, 0, 1>(dv3::GemmParams)")
         if tile == 10:
             return "void dv3::gemm_direct_tn_kernel<4, 1>(dv3::GemmParams)"
         return f"void dv3::gemm_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, {ta}, {tb}>(dv3::GemmParams)"
@@ -364,17 +367,22 @@ def onehot_sample(logit, out, *, noise=None, rng=None, idx=None, unimix=0.01, mo
         _contig(flips, "flips", torch.int32)
         if flips.numel() != 1:
             raise ValueError("flips: one int32 counter")
-    nf = init = nout = None
+    nf = init = nout = init_idx = next_idx = None
     groups = 1
     if next_blend is not None:
-        nf, init, nout = next_blend
+        nf, init, nout = next_blend[:3]
         _contig(nf, "next_first"), _contig(init, "init"), _contig(nout, "next_out")
         if R % nf.numel() or init.numel() * nf.numel() != R * D or nout.numel() != R * D:
             raise ValueError("next_blend shapes mismatch")
         groups = R // nf.numel()
+        if len(next_blend) > 3:  # (..., init_idx [groups], next_idx [R]): class indices of the blended state
+            init_idx, next_idx = next_blend[3], next_blend[4]
+            _contig(init_idx, "init_idx", torch.int32), _contig(next_idx, "next_idx", torch.int32)
+            if init_idx.numel() != groups or next_idx.numel() != R:
+                raise ValueError("next_blend index shapes mismatch")
     _call("dv3_onehot_sample_fwd_ex", _ptr(logit), _ptr(noise), _ptr(rng_state), int(rng_off), _ptr(out), _ptr(idx),
           _ptr(forced), _ptr(flips), R, D, float(unimix), int(mode), _ptr(nf), _ptr(init), _ptr(nout), groups,
-          _stream(), key="dv3_onehot_sample_fwd")
+          _ptr(init_idx), _ptr(next_idx), _stream(), key="dv3_onehot_sample_fwd")
     return out
 
 
@@ -861,7 +869,9 @@ def dot_accumulate(x, out, *, w=None, clip_min=None, scale=1.0):
 
 
 def actor_loss(target, value, weights, entropy, ema_vals, loss_out, dent, *, dtarget=None, logp=None, dlogp=None,
-               entropy_coef, reinforce):
+               entropy_coef, reinforce=False, mode=None, mix=0.0):
+    """mode: 0 'dynamics', 1 'reinforce', 2 'both' (default: reinforce flag)."""
+    mode = int(bool(reinforce)) if mode is None else int(mode)
     H = value.shape[0]
     N = value.numel() // H
     for t, nm, n in ((target, "target", (H - 1) * N), (value, "value", H * N), (weights, "weights", H * N),
@@ -874,7 +884,7 @@ def actor_loss(target, value, weights, entropy, ema_vals, loss_out, dent, *, dta
         if n is not None and t.numel() != n:
             raise ValueError(f"{nm} size mismatch")
     _call("dv3_actor_loss", _ptr(target), _ptr(value), _ptr(weights), _ptr(entropy), _ptr(logp), _ptr(ema_vals),
-          _ptr(loss_out), _ptr(dtarget), _ptr(dlogp), _ptr(dent), H, N, float(entropy_coef), int(reinforce), _stream())
+          _ptr(loss_out), _ptr(dtarget), _ptr(dlogp), _ptr(dent), H, N, float(entropy_coef), mode, float(mix), _stream())
 
 
 def scale_neg(w, out, s):
@@ -1032,9 +1042,10 @@ def gemm_sample_ok(M, N, D, A=None) -> bool:
 
 
 def gemm_sample(A, B, logit, onehot, *, bias=None, noise=None, rng=None, idx=None, forced=None, flips=None,
-                unimix=0.01, mode=False):
+                unimix=0.01, mode=False, ln=None):
     """logit [M,N] = A @ B^T + bias and, in the same launch, the one-hot sample of every group of 32 logits
-    (onehot [M,N]; idx/forced int32 [M*N/32]) -- ops.gemm followed by ops.onehot_sample, fused."""
+    (onehot [M,N]; idx/forced int32 [M*N/32]) -- ops.gemm followed by ops.onehot_sample, fused.  ln: the
+    LayerNorm + SiLU of the layer that produced A, applied on the fly (A = its pre-activations)."""
     M, K, lda = _rows2d(A, "A")
     N, Kb, ldb = _rows2d(B, "B")
     Mc, Nc, ldc = _rows2d(logit, "logit")
@@ -1062,8 +1073,35 @@ def gemm_sample(A, B, logit, onehot, *, bias=None, noise=None, rng=None, idx=Non
         if rng is None:
             raise ValueError("sampling needs noise or an RngStream")
         rng_state, rng_off = rng.state, rng.take(M * N)
+    lg = lb = lm = lr = None
+    if ln is not None:  # (gamma [K], beta [K], mean_out [M] | None, rstd_out [M] | None): A = pre-activations
+        lg, lb, lm, lr = ln
+        _contig(lg, "ln gamma"), _contig(lb, "ln beta")
+        if lg.numel() != K or lb.numel() != K or K % 4 or lda % 4:
+            raise ValueError("gemm_sample ln shapes mismatch")
+        for t, nm in ((lm, "ln mean"), (lr, "ln rstd")):
+            if t is not None:
+                _contig(t, nm)
+                if t.numel() != M:
+                    raise ValueError(nm + " size mismatch")
     _call("dv3_gemm_sample_f32", M, N, K, _ptr(A), lda, 0, 0, 0, _ptr(B), ldb, _ptr(logit), ldc, _ptr(bias), _ptr(noise),
           _ptr(rng_state), int(rng_off), _ptr(onehot), _ptr(idx), _ptr(forced), _ptr(flips), float(unimix), int(mode),
+          _ptr(lg), _ptr(lb), _ptr(lm), _ptr(lr),
           _stream(), key="gemm_kernel<direct32x64+sample,tA=0,tB=1>" + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else ""),
           flops=2.0 * M * N * K, nbytes=4.0 * (M * K + N * K + 2 * M * N))
     return onehot
+
+
+def quantile2_ema(x, q0, q1, ema=None, alpha=0.0, out_q=None):
+    """Quantiles q0, q1 of all elements of x (torch.quantile, linear interpolation) by exact radix selection; with
+    ema [2]: ema <- alpha*q + (1-alpha)*ema in the same launch (models.RewardEMA)."""
+    _contig(x, "x")
+    for t, nm in ((ema, "ema"), (out_q, "out_q")):
+        if t is not None:
+            _contig(t, nm)
+            if t.numel() != 2:
+                raise ValueError(nm + " must hold 2 floats")
+    if ema is None and out_q is None:
+        raise ValueError("quantile2_ema: nothing to write")
+    _call("dv3_quantile2_ema", _ptr(x), x.numel(), float(q0), float(q1), _ptr(ema), float(alpha), _ptr(out_q), _stream())
+    return out_q if out_q is not None else ema

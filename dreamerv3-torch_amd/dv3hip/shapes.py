@@ -16,6 +16,9 @@ SHAPES = {
                  actor_dist="normal", imag_gradient="dynamics", encoder="cnn"),
     "tiny_onehot": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=5, cnn_depth=2, B=3, T=6, H=4,
                         actor_dist="onehot", imag_gradient="reinforce", encoder="cnn"),
+    # 'both' actor gradient (models.py:670-676) with the continuous actor: the log-prob term sees the rsampled action
+    "tiny_both": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
+                      actor_dist="normal", imag_gradient="both", imag_gradient_mix=0.3, encoder="cnn"),
     "tiny_proprio": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
                          actor_dist="normal", imag_gradient="dynamics", encoder="mlp",
                          enc_mlp_units=32, enc_mlp_layers=2),
@@ -31,10 +34,13 @@ SHAPES = {
                  actor_dist="normal", imag_gradient="dynamics", encoder="cnn"),
     # BASELINE cfg 5: crafter block (configs.yaml:158-174: 5-layer actor / reward / cont heads, one-hot actor,
     # reinforce; its `value: {layers: 5}` key is not read by models.py, the critic keeps 2 layers) with
-    # dyn_deter 2048, batch 128 x 256
-    "cfg5": dict(stoch=32, discrete=32, deter=2048, hidden=1024, units=1024, A=17, cnn_depth=96, B=128, T=256, H=15,
+    # dyn_deter 2048, sequence length 256.  BASELINE.json states the batch as 128 x 256 at DP = 8: B here is the
+    # per-GPU shard, 16 sequences (8 ranks x 16 = 128; bench.py scales weakly, so --gpus 8 is exactly that global
+    # batch).  One GPU cannot hold the activations of all 128 x 256 frames at fp32 without recomputation (conv stacks
+    # ~200 GB + 15 x 32768 imagination rows through five 1024-wide heads ~120 GB > 288 GB).
+    "cfg5": dict(stoch=32, discrete=32, deter=2048, hidden=1024, units=1024, A=17, cnn_depth=96, B=16, T=256, H=15,
                  actor_dist="onehot", imag_gradient="reinforce", encoder="cnn", actor_layers=5, reward_layers=5,
-                 cont_layers=5),
+                 cont_layers=5, global_B_dp8=128),
     # reduced-batch variants of the two (same layer widths: every kernel shape class of cfg 4 / cfg 5 at a size the
     # CPU oracle finishes in seconds)
     "cfg4_b4": dict(stoch=32, discrete=32, deter=4096, hidden=1024, units=1024, A=6, cnn_depth=96, B=4, T=8, H=5,
@@ -69,7 +75,8 @@ def make_config(name, device="cuda:0"):
     cfg = tools.load_config(os.path.join(PKG, "configs.yaml"), blocks)
     cfg.update(device=device, num_actions=s["A"], dyn_stoch=s["stoch"], dyn_discrete=s["discrete"],
                dyn_deter=s["deter"], dyn_hidden=s["hidden"], units=s["units"], batch_size=s["B"],
-               batch_length=s["T"], imag_horizon=s["H"], imag_gradient=s["imag_gradient"])
+               batch_length=s["T"], imag_horizon=s["H"], imag_gradient=s["imag_gradient"],
+               imag_gradient_mix=s.get("imag_gradient_mix", 0.0))
     cfg["encoder"]["cnn_depth"] = s["cnn_depth"]
     cfg["decoder"]["cnn_depth"] = s["cnn_depth"]
     if s["actor_dist"] == "onehot":

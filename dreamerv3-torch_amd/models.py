@@ -73,17 +73,11 @@ class RewardEMA:
         self.range = torch.tensor([0.05, 0.95], device=device)
 
     def quantiles(self, x):
-        flat = torch.sort(torch.flatten(x.detach()))[0]
-        n = flat.numel()
-        out = []
-        for q in (0.05, 0.95):
-            pos = q * (n - 1)
-            lo, hi = int(np.floor(pos)), int(np.ceil(pos))
-            out.append(flat[lo] + (flat[hi] - flat[lo]) * (pos - lo))
-        return torch.stack(out)
+        """torch.quantile(x.flatten(), [0.05, 0.95]) (models.py:20-21) by exact radix selection on the device."""
+        return ops.quantile2_ema(x.detach().contiguous(), 0.05, 0.95, out_q=torch.empty(2, device=x.device))
 
     def __call__(self, x, ema_vals):
-        ops.axpby(self.quantiles(x).contiguous(), ema_vals, self.alpha, 1.0 - self.alpha)
+        ops.quantile2_ema(x.detach().contiguous(), 0.05, 0.95, ema=ema_vals, alpha=self.alpha)
         scale = torch.clip(ema_vals[1] - ema_vals[0], min=1.0)
         return ema_vals[0].detach(), scale.detach()
 
@@ -267,8 +261,11 @@ class WorldModel(nn.Module):
         if not wrote:
             gs.zero_(), gd.zero_()
         # reward head: -log_prob(reward) under the 255-bucket two-hot head
+        pidx = out["post_idx"].view(TB, S) if E._GATHER_OBS else None
         reng = self.heads["reward"].engine_for(".wm")
-        _, r_logits, _ = reng.forward(ps, dt)
+        if pidx is not None:
+            reng.pack_onehot(SD)
+        _, r_logits, _ = reng.forward(ps, dt, idx=pidx, D=D)
         lp_r = ws.get("wm.lp_r", (TB,))
         ops.disc_logprob_fwd(r_logits, reward_tm.view(TB), lp_r)
         ops.dot_accumulate(lp_r, acc[2:3], scale=-up)
@@ -280,7 +277,9 @@ class WorldModel(nn.Module):
                       dx2=gd.view(TB, De) if g_r else None, acc_dx=True, defer=deferred)
         # continue head
         ceng = self.heads["cont"].engine_for(".wm")
-        _, c_logit, _ = ceng.forward(ps, dt)
+        if pidx is not None:
+            ceng.pack_onehot(SD)
+        _, c_logit, _ = ceng.forward(ps, dt, idx=pidx, D=D)
         lp_c = ws.get("wm.lp_c", (TB,))
         ops.bernoulli_logprob_fwd(c_logit.view(TB), cont_tm.view(TB), lp_c)
         ops.dot_accumulate(lp_c, acc[3:4], scale=-up)
@@ -386,7 +385,7 @@ class ImagBehavior(nn.Module):
             name="Value")
         if config.critic["dist"] != "symlog_disc" or config.actor["dist"] not in ("normal", "onehot"):
             raise NotImplementedError("critic symlog_disc; actor normal|onehot")
-        if config.imag_gradient not in ("dynamics", "reinforce"):
+        if config.imag_gradient not in ("dynamics", "reinforce", "both"):
             raise NotImplementedError(config.imag_gradient)
         if config.critic["slow_target"]:
             self._slow_value = copy.deepcopy(self.value)
@@ -573,9 +572,21 @@ class ImagBehavior(nn.Module):
                                       "the accelerated path")
         object.__setattr__(self, "_objective_checked", True)
 
+    def sync_ema(self):
+        """Data parallel: the return-normalisation EMA is computed from each rank's own imagined returns; average the
+        two floats over the ranks so that the replicas normalise alike (the reference is single-process).  Eager
+        collective, outside any hipGraph segment; no-op on one rank."""
+        import torch.distributed as dist
+
+        if self._config.reward_EMA and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.ema_vals, op=dist.ReduceOp.SUM)
+            self.ema_vals.mul_(1.0 / dist.get_world_size())
+
     def train_opt(self, allreduce=True):
         ret, metrics, losses = self._pending
         metrics = dict(metrics)
+        if allreduce:
+            self.sync_ema()
         metrics.update(self._actor_opt.finish(losses[0], allreduce))
         metrics.update(self._value_opt.finish(losses[1], allreduce))
         return ret + (_wrap(metrics),)
@@ -628,10 +639,15 @@ class ImagBehavior(nn.Module):
             ema[0], ema[1] = 0.0, 1.0
         acc = ws.zeros("bh.acc", (4,))  # [actor_loss, value_loss, entropy mean, spare]
         dent = g("bh.dent", (H, N))
-        reinforce = cfg.imag_gradient == "reinforce"
+        # imag_gradient (models.py:663-678): 'dynamics' back-propagates the normalised return through the imagined
+        # states; 'reinforce' weights log pi(a) with the detached advantage; 'both' mixes the raw return into the latter
+        use_logp = cfg.imag_gradient in ("reinforce", "both")
+        use_dyn = cfg.imag_gradient in ("dynamics", "both")
+        reinforce = not use_dyn
         normal = cfg.actor["dist"] == "normal"
         a_mean, a_std = self._actor_heads(im)
-        if reinforce:
+        dlogp = dtarget = logp = None
+        if use_logp:
             logp = g("bh.logp", (H, N))
             if normal:
                 ops.actor_normal_logp(a_mean, a_std, action.view(HN, A), logp.view(HN), min_std=cfg.actor["min_std"],
@@ -640,12 +656,11 @@ class ImagBehavior(nn.Module):
                 ops.onehot_ent_logp_fwd(a_mean, action.view(HN, A), None, logp.view(HN),
                                         unimix=cfg.actor["unimix_ratio"])
             dlogp = g("bh.dlogp", (H, N))
-            ops.actor_loss(target, value, weights, ent, ema, acc[0:1], dent, logp=logp, dlogp=dlogp,
-                           entropy_coef=cfg.actor["entropy"], reinforce=True)
-        else:
+        if use_dyn:
             dtarget = g("bh.dtarget", (H - 1, N))
-            ops.actor_loss(target, value, weights, ent, ema, acc[0:1], dent, dtarget=dtarget,
-                           entropy_coef=cfg.actor["entropy"], reinforce=False)
+        ops.actor_loss(target, value, weights, ent, ema, acc[0:1], dent, dtarget=dtarget, logp=logp, dlogp=dlogp,
+                       entropy_coef=cfg.actor["entropy"], mode={"dynamics": 0, "reinforce": 1, "both": 2}[cfg.imag_gradient],
+                       mix=getattr(cfg, "imag_gradient_mix", 0.0))
         # ---- critic branch: -log_prob(target) - log_prob(slow.mode), weighted by the cumulative discount.
         # Independent of the actor's backward, so it runs on the side stream beside the dynamics scan.
         R = H1N
@@ -684,26 +699,27 @@ class ImagBehavior(nn.Module):
             scratch = dict(dlogit=g("bh.s.dlogit", (N, SD)), dx2=g("bh.s.dx2", (N, Hd)), dx2pre=g("bh.s.dx2pre", (N, Hd)),
                            dgpre=g("bh.s.dgpre", (N, 3 * De)), dx1=g("bh.s.dx1", (N, Hd)),
                            dx1pre=g("bh.s.dx1pre", (N, Hd)))
+            wt_bwd = rssm.pack_bwd() if _FUSED_IMAG else None
             for t in range(H - 1, 0, -1):
                 b = {k: v[t - 1] for k, v in im["step"].items()}
                 b.update(logit=im["logit"][t].view(N, S, D))
                 # state gradients flow straight into gs/gd[t-1] (which already hold the heads' gradient);
                 # step 0 is the detached start state: its slot is scratch
                 rssm.img_step_bwd(gs[t], gd[t], deter[t - 1], b, scratch, gs[t - 1], gd[t - 1], daction[t - 1],
-                                  accumulate_prev=t > 1)
+                                  accumulate_prev=t > 1, wt=wt_bwd)
         # ---- actor backward over steps 0..H-2 (the last step's action feeds nothing that is used)
         dmean, dstd = g("bh.dmean", (R, A)), g("bh.dstd", (R, A))
         if normal:
             ops.actor_normal_bwd(a_mean[:R], a_std[:R], dmean, dstd, eps=im["eps"].view(HN, A)[:R],
                                  action=action.view(HN, A)[:R], daction=None if reinforce else daction.view(HN, A)[:R],
-                                 dent=dent.view(HN)[:R], dlogp=dlogp.view(HN)[:R] if reinforce else None,
+                                 dent=dent.view(HN)[:R], dlogp=dlogp.view(HN)[:R] if use_logp else None,
                                  min_std=cfg.actor["min_std"], max_std=cfg.actor["max_std"])
         else:
             if not reinforce:
                 # sampled one-hot action: straight-through gradient of the sample, plus the entropy term
                 ops.onehot_st_bwd(a_mean[:R], daction.view(HN, A)[:R], dmean, unimix=cfg.actor["unimix_ratio"])
             ops.onehot_ent_logp_bwd(a_mean[:R], action.view(HN, A)[:R], dent.view(HN)[:R],
-                                    dlogp.view(HN)[:R] if reinforce else None, dmean,
+                                    dlogp.view(HN)[:R] if use_logp else None, dmean,
                                     unimix=cfg.actor["unimix_ratio"], accumulate=not reinforce)
             dstd = None
         im["actor"].backward(fs[:R], fd[:R], slice(0, R), dout=dmean, dout2=dstd, wgrad=True)
@@ -718,6 +734,8 @@ class ImagBehavior(nn.Module):
             metrics.update(tools.tensorstats(action, "imag_action"))
         else:
             metrics.update(tools.tensorstats(torch.argmax(action, dim=-1).float(), "imag_action"))
+        if cfg.imag_gradient == "both":
+            metrics["imag_gradient_mix"] = cfg.imag_gradient_mix
         if cfg.reward_EMA:
             scale = torch.clip(ema[1] - ema[0], min=1.0)
             metrics.update(tools.tensorstats((target - ema[0]) / scale, "normed_target"))

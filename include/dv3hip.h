@@ -59,7 +59,11 @@ int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, lo
 int dv3_gemm_sample_f32(int M, int N, int K, const float* A, long lda, const float* A2, long lda2, int K1,
                         const float* B, long ldb, float* C, long ldc, const float* bias, const float* noise,
                         const unsigned long long* rng_state, unsigned long long rng_offset, float* onehot, int* idx,
-                        const int* forced, unsigned int* flips, float unimix, int mode, void* stream);
+                        const int* forced, unsigned int* flips, float unimix, int mode, const float* ln_gamma,
+                        const float* ln_beta, float* ln_mean, float* ln_rstd, void* stream);
+/* ln_gamma != NULL: A holds pre-activations and SiLU(LayerNorm(A) * gamma + beta) (eps 1e-3, over the K columns) is
+ * applied while the operand is loaded -- the `_img_out_layers` LayerNorm + SiLU of networks.py:62-69 without a launch
+ * of its own; ln_mean / ln_rstd [M] (optional) receive the row statistics for dv3_ln_act_bwd.  No A2, K % 4 == 0. */
 
 /* ---- LayerNorm(eps 1e-3) [+ SiLU] ----------------------------------------------------------------
  * y = act(LN(x) * gamma + beta), rows of length N <= 2048; mean/rstd [R] are saved for the backward
@@ -110,7 +114,10 @@ int dv3_onehot_sample_fwd_blend(const float* logit, const float* noise, const un
 int dv3_onehot_sample_fwd_ex(const float* logit, const float* noise, const unsigned long long* rng_state,
                              unsigned long long rng_offset, float* onehot, int* idx, const int* forced,
                              unsigned int* flips, long R, int D, float unimix, int mode, const float* next_first,
-                             const float* init, float* next_out, int groups, void* stream);
+                             const float* init, float* next_out, int groups, const int* init_idx, int* next_idx,
+                             void* stream);
+/* init_idx [groups] / next_idx [R] (optional, with the fused blend): class index of the blended next-step state,
+ * next_idx[r] = next_first ? init_idx[r % groups] : idx[r] (the input of dv3_onehot_linear_ln_fwd at that step). */
 /* rng_offset is added to rng_state's offset for this call (R*D/4+1 counters are consumed): the caller lays
  * the calls of one update out on disjoint counter ranges and advances rng_state once, so the launch
  * sequence stays static under hipGraph replay. */
@@ -223,13 +230,14 @@ int dv3_lambda_return_bwd(const float* dtarget, const float* value, const float*
  *   NULL = ones) -- the torch.mean / torch.clip(min=free) reductions of models.py:147-148, networks.py:286-288.
  * dv3_actor_loss: ImagBehavior._compute_actor_loss + entropy bonus (models.py:406-407, 640-681) and its
  *   gradients in one pass; target/value/weights/entropy/logp [H,N] (target: H-1 rows used), ema_vals [2].
- *   reinforce=0 ('dynamics'): writes dtarget [H-1,N]; reinforce=1: writes dlogp [H,N]. loss_out[0] += loss.
+ *   mode 0 ('dynamics'): writes dtarget [H-1,N]; mode 1 ('reinforce'): writes dlogp [H,N]; mode 2 ('both',
+ *   models.py:670-676: mix*target + (1-mix)*logp*sg(target-value)): writes both.  loss_out[0] += loss.
  * dv3_scale_neg: out = -s*w (upstream of the two critic log-prob terms, models.py:424-429). */
 int dv3_dot_accumulate(const float* x, const float* w, long n, float* out, int use_clip_min, float clip_min,
                        float scale, void* stream);
 int dv3_actor_loss(const float* target, const float* value, const float* weights, const float* entropy,
                    const float* logp, const float* ema_vals, float* loss_out, float* dtarget, float* dlogp,
-                   float* dentropy, int H, long N, float entropy_coef, int reinforce, void* stream);
+                   float* dentropy, int H, long N, float entropy_coef, int mode, float mix, void* stream);
 int dv3_scale_neg(const float* w, float* out, long n, float s, void* stream);
 
 /* ---- is_first reset -- RSSM.obs_step (networks.py:176-193), branch-free -----------------------------
@@ -270,6 +278,12 @@ int dv3_rng_advance(unsigned long long* rng_state, unsigned long long increment,
  * (torch.distributions.utils._standard_normal behind networks.py:697-699); consumes ceil(n/4) counters. */
 int dv3_fill_normal(float* out, long n, const unsigned long long* rng_state, unsigned long long rng_offset,
                     void* stream);
+
+/* Two quantiles q0, q1 of x[n] (torch.quantile's linear interpolation between the neighbouring order statistics,
+ * selected exactly by a 4-pass radix select) and, when ema != NULL, ema[i] = alpha*q_i + (1-alpha)*ema[i]:
+ * models.RewardEMA.__call__ (models.py:19-26) in one launch instead of a sort.  out_q (optional) receives q0, q1. */
+int dv3_quantile2_ema(const float* x, long n, double q0, double q1, float* ema, float alpha, float* out_q,
+                      void* stream);
 
 /* ---- row-fused layers of the imagination step (csrc/fusedops.hip) -----------------------------------
  * dv3_onehot_linear_ln_fwd: pre[M,N] = base + sum_s WT[s*D + idx[m][s]] + sum_a x2[m][a] * WT[S*D + a], then

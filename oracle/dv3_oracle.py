@@ -59,6 +59,7 @@ class PathConfig:
     critic_layers: int = 2
     reward_layers: int = 2
     cont_layers: int = 2
+    imag_gradient_mix: float = 0.0  # configs.yaml:112
     imag_gradient: str = "dynamics"  # "dynamics" | "reinforce"
     horizon: int = 15
     discount: float = 0.997
@@ -638,6 +639,9 @@ def behavior_forward(cfg: PathConfig, p, start: Dict[str, Tensor], act_noise: Te
         actor_target = adv
     elif cfg.imag_gradient == "reinforce":
         actor_target = actor_logprob(cfg, p, feats, actions)[:-1][:, :, None] * (target - value[:-1]).detach()
+    elif cfg.imag_gradient == "both":  # models.py:670-676 (the mixed-in target is the raw, un-normalised return)
+        actor_target = actor_logprob(cfg, p, feats, actions)[:-1][:, :, None] * (target - value[:-1]).detach()
+        actor_target = cfg.imag_gradient_mix * target + (1 - cfg.imag_gradient_mix) * actor_target
     else:
         raise NotImplementedError(cfg.imag_gradient)
     actor_loss = -weights[:-1] * actor_target

@@ -34,6 +34,7 @@ def path_config(name: str):
         imag_gradient=s["imag_gradient"], horizon=s["H"], encoder=s["encoder"],
         actor_layers=s.get("actor_layers", 2), reward_layers=s.get("reward_layers", 2),
         cont_layers=s.get("cont_layers", 2), critic_layers=s.get("critic_layers", 2),
+        imag_gradient_mix=s.get("imag_gradient_mix", 0.0),
     )
     if s["encoder"] == "mlp":
         kw.update(mlp_keys=PROPRIO_KEYS, enc_mlp_units=s["enc_mlp_units"], enc_mlp_layers=s["enc_mlp_layers"])

@@ -161,7 +161,7 @@ def build_reference(name, tools, networks, models):
         dyn_deter=s["deter"], dyn_hidden=s["hidden"], units=s["units"], batch_size=s["B"],
         batch_length=s["T"], imag_horizon=s["H"], imag_gradient=s["imag_gradient"],
         encoder=dict(cnn_depth=s["cnn_depth"]), decoder=dict(cnn_depth=s["cnn_depth"]),
-        causal_world_model=False,
+        causal_world_model=False, imag_gradient_mix=s.get("imag_gradient_mix", 0.0),
     )
     if s["actor_dist"] == "onehot":
         ov["actor"] = dict(dist="onehot", std="none")
@@ -401,8 +401,8 @@ def main():
     torch.set_num_threads(8)
     tools, networks, models = import_reference()
     install_noise_hooks(tools)
-    plan = [("tiny", True), ("tiny_onehot", True), ("tiny_proprio", True), ("cfg2", False), ("cfg1", False),
-            ("cfg3", False)]
+    plan = [("tiny", True), ("tiny_onehot", True), ("tiny_proprio", True), ("tiny_both", True), ("cfg2", False),
+            ("cfg1", False), ("cfg3", False)]
     for name, full in plan:
         if args.only and name != args.only:
             continue

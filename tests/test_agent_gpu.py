@@ -150,6 +150,39 @@ def test_policy_steps_match_oracle(name, n_envs):
         ostate, oaction = {k: v.detach() for k, v in post.items()}, act.detach()
 
 
+@pytest.mark.parametrize("name,n_envs", [("tiny", 3), ("tiny_onehot", 2), ("cfg2", 4)])
+def test_policy_graph_replay_equals_eager(name, n_envs):
+    """The hipGraph-replayed acting step (dv3hip.graph.PolicyRunner) returns what the eager launch sequence returns,
+    call after call, with the state carried and a reset in between (same Philox stream position for both)."""
+    import tools
+
+    agent, _ = _load_agent(name)
+    rs = np.random.RandomState(9)
+    seq = []
+    for step in range(4):
+        first = np.ones(n_envs, bool) if step == 0 else np.zeros(n_envs, bool)
+        if step == 2:
+            first[0] = True
+        seq.append({"image": rs.randint(0, 256, (n_envs, 64, 64, 3)).astype(np.uint8), "is_first": first,
+                    "is_terminal": np.zeros(n_envs, bool)})
+    outs = {}
+    for mode in ("eager", "graph"):
+        tools.default_rng(agent._config.device, seed=21)
+        state, res = None, []
+        for step, obs in enumerate(seq):
+            training = step != 3
+            if mode == "eager":
+                out, state = agent._policy_eager(obs, state, training)
+            else:
+                out, state = agent._policy(obs, state, training)
+            res.append((out["action"].clone(), out["logprob"].clone(), {k: v.clone() for k, v in state[0].items()}))
+        outs[mode] = res
+    assert agent._policy_runner not in (None, False) and len(agent._policy_runner._sig) == 2
+    for (a0, l0, s0), (a1, l1, s1) in zip(outs["eager"], outs["graph"]):
+        assert torch.equal(s0["stoch"], s1["stoch"]) and torch.allclose(s0["deter"], s1["deter"], atol=1e-6)
+        assert torch.allclose(a0, a1, atol=1e-6) and torch.allclose(l0, l1, atol=1e-5)
+
+
 @pytest.mark.parametrize("name", ["tiny", "cfg2"])
 def test_video_pred_matches_reference_golden(name):
     """WorldModel.video_pred (models.py:192-213) on the GPU path, same weights / batch / noise,

@@ -76,16 +76,16 @@ def test_optimizer_call_with_an_autograd_loss_is_clip_plus_adam():
     net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).cuda()
     ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).cuda()
     ref.load_state_dict(net.state_dict())
-    opt = tools.Optimizer("test", list(net.parameters()), lr=1e-2, eps=1e-5, clip=0.5)
+    opt = tools.Optimizer("test", list(net.parameters()), lr=1e-2, eps=1e-5, clip=1.0)
     ropt = torch.optim.Adam(ref.parameters(), lr=1e-2, eps=1e-5)
     x = torch.randn(11, 7, device="cuda")
     for _ in range(3):
-        loss = (net(x) ** 2).sum()
+        loss = (net(x) ** 2).sum() * 10
         mets = opt(loss, net.parameters())
-        rloss = (ref(x) ** 2).sum()
+        rloss = (ref(x) ** 2).sum() * 10
         ropt.zero_grad()
         rloss.backward()
-        norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
         ropt.step()
         assert float(mets["test_grad_norm"]) == pytest.approx(float(norm), rel=1e-4)
         assert float(mets["test_loss"]) == pytest.approx(float(rloss), rel=1e-5)

@@ -82,3 +82,42 @@ def test_two_ranks_equal_one_process_on_the_global_batch():
     diff = (single - r0["wm"]).abs()
     assert float((diff > 2e-6).float().mean()) < 2e-3
     assert float(diff.max()) <= 2.1 * wm._config.model_lr
+
+
+def _rccl_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        _, wm, beh = Hh.build_models(NAME)
+        batch, noise = _rank_inputs(0)
+        nz = {k: torch.from_numpy(v).cuda() for k, v in noise.items()}
+        post, _, mets = wm._train(batch, noise=dict(q_prior=nz["q_prior"], q_post=nz["q_post"]))
+        beh._train(post, None)
+        torch.save({"wm": torch.cat([p.detach().reshape(-1) for p in wm.parameters()]).cpu(),
+                    "backend": dist.get_backend(), "ema": beh.ema_vals.cpu()}, os.path.join(outdir, "rccl.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_update_on_one_rank():
+    """backend "nccl" (= RCCL on ROCm) with the only GPU of this box: the process group initialises, the flat-bucket
+    all-reduces and the EMA all-reduce go through RCCL (world size 1: the collective is the identity), and the update
+    equals the no-process-group update bit for bit.  (Two ranks cannot share one device under RCCL; the 2-rank logic is
+    covered with gloo above and on CPU in tests/test_dp_cpu.py.)"""
+    import torch.multiprocessing as mp
+
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_rccl_worker, args=(1, _free_port(), outdir), nprocs=1, join=True)
+        r = torch.load(os.path.join(outdir, "rccl.pt"), weights_only=True)
+    assert r["backend"] == "nccl"
+    _, wm, beh = Hh.build_models(NAME)
+    batch, noise = _rank_inputs(0)
+    nz = {k: torch.from_numpy(v).cuda() for k, v in noise.items()}
+    wm._train(batch, noise=dict(q_prior=nz["q_prior"], q_post=nz["q_post"]))
+    single = torch.cat([p.detach().reshape(-1) for p in wm.parameters()]).cpu()
+    diff = (single - r["wm"]).abs()
+    assert float((diff > 1e-6).float().mean()) < 2e-3 and float(diff.max()) <= 2.1 * wm._config.model_lr

@@ -715,6 +715,15 @@ def test_fused_next_step_reset_blend_outputs(ops):
     assert torch.equal(st, st2)
     want = st.cpu() * (1 - first[:, None, None]) + init_s.view(1, S, D) * first[:, None, None]
     assert_close(nxt_s, want, what="sample next blend")
+    # class indices of the blended state (the one-hot initial state's index where the next step resets)
+    init_i = torch.randint(0, D, (S,), generator=g, dtype=torch.int32)
+    init_oh = F.one_hot(init_i.long(), D).float().reshape(-1)
+    idx, nidx = torch.empty(M * S, dtype=torch.int32, device="cuda"), torch.empty(M * S, dtype=torch.int32, device="cuda")
+    ops.onehot_sample(dev(logit), st, noise=dev(q), idx=idx, next_blend=(dev(first), dev(init_oh), nxt_s, dev(init_i), nidx))
+    assert torch.equal(idx.cpu().view(M, S), st.cpu().argmax(-1).int())
+    assert torch.equal(nidx.cpu().view(M, S), nxt_s.cpu().argmax(-1).int())
+    want_i = torch.where(first[:, None] > 0, init_i[None].expand(M, S), st.cpu().argmax(-1).int())
+    assert torch.equal(nidx.cpu().view(M, S), want_i)
 
 
 # ----------------------------------------------------------------------------- row-fused imagination layers
@@ -864,3 +873,46 @@ def test_gemm_with_sampling_epilogue_equals_gemm_then_sample(ops, M, N, K, mode)
         ops.gemm_sample(A, W, lg1, st1, bias=b, noise=q, idx=i1, forced=forced, flips=flips)
         assert torch.equal(i1, forced) and torch.equal(st1.argmax(-1).int().view(-1), forced)
         assert int(flips.item()) == int((i0 != forced).sum())
+
+
+@pytest.mark.parametrize("n", [14336, 7, 1, 2, 1000, 458752])
+def test_quantile_ema_matches_torch_quantile(ops, n):
+    """models.RewardEMA (models.py:11-26): exact radix-selected 5 % / 95 % quantiles + EMA == torch.quantile + axpby."""
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g) * 3 + 0.5
+    if n > 10:
+        x[::5] = x[0]  # ties
+        x[1] = -0.0
+        x[2] = 0.0
+    ref = torch.quantile(x.double(), torch.tensor([0.05, 0.95], dtype=torch.float64)).float()
+    out = torch.empty(2, device="cuda")
+    ops.quantile2_ema(dev(x), 0.05, 0.95, out_q=out)
+    assert_close(out, ref, tol=1e-6, what="quantiles")
+    ema = torch.tensor([0.3, 2.0], device="cuda")
+    ops.quantile2_ema(dev(x), 0.05, 0.95, ema=ema, alpha=0.01)
+    assert_close(ema, 0.01 * ref + 0.99 * torch.tensor([0.3, 2.0]), tol=1e-6, what="ema")
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 512), (100, 128, 48), (40, 64, 1024)])
+def test_gemm_sample_with_layernorm_on_load(ops, M, N, K):
+    """ln=...: SiLU(LN(A)) applied while the operand is loaded == dv3_ln_act_fwd followed by the plain fused GEMM;
+    the A operand may be a column slice of a wider buffer (the stacked [x2pre | actor pre0] GEMM output)."""
+    g = torch.Generator().manual_seed(M + K)
+    wide = torch.randn(M, K + 32, generator=g) * 2 + 0.3
+    W, b = torch.randn(N, K, generator=g) / math.sqrt(K) * 3, torch.randn(N, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    q = torch.empty(M, N // 32, 32).exponential_(1.0, generator=g).clamp_min(1e-20)
+    wided = dev(wide)
+    A = wided[:, :K]
+    y, mean, rstd = torch.empty(M, K, device="cuda"), torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.ln_act_fwd(A, dev(gamma), dev(beta), y, mean, rstd, act=True)
+    lg0, st0 = torch.empty(M, N, device="cuda"), torch.empty(M, N // 32, 32, device="cuda")
+    ops.gemm_sample(y, dev(W), lg0, st0, bias=dev(b), noise=dev(q))
+    lg1, st1 = torch.empty_like(lg0), torch.empty_like(st0)
+    m1, r1 = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.gemm_sample(A, dev(W), lg1, st1, bias=dev(b), noise=dev(q), ln=(dev(gamma), dev(beta), m1, r1))
+    assert_close(m1, mean, tol=1e-6, what="mean"), assert_close(r1, rstd, tol=1e-6, what="rstd")
+    assert_close(lg1, lg0, tol=2e-6, what="logits")
+    ref = F.silu(O.layer_norm(wide[:, :K], gamma, beta)) @ W.t() + b
+    assert_close(lg1, ref, tol=2e-4, what="logits vs torch")
+    assert (st1 != st0).any(-1).float().mean() <= 1e-3

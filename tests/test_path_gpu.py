@@ -21,6 +21,15 @@ def close(got, ref, tol=TOL, what=""):
     assert err <= tol * scale, f"{what}: max err {err:.3e} (scale {scale:.3e})"
 
 
+def adam_close(got, ref, lr, what):
+    """Post-Adam parameters: equal to 1e-6, except where the first Adam step (lr * g / (|g| + eps)) turns a
+    rounding-level difference of a near-zero gradient into a fraction of lr -- rare (the 180 M-parameter configs have
+    a few such entries per tensor) and bounded by 2 lr."""
+    d = (got.detach().cpu().double() - ref.detach().cpu().double()).abs()
+    assert float(d.max()) <= 2.1 * lr, f"{what}: max {float(d.max()):.3e}"
+    assert float((d > 1e-6).double().mean()) <= 1e-3, f"{what}: {float((d > 1e-6).double().mean()):.3e} outliers"
+
+
 def gpu_noise(name):
     s = common.SHAPES[name]
     n = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(name).items()}
@@ -30,7 +39,7 @@ def gpu_noise(name):
     return wm_noise, im_noise
 
 
-@pytest.fixture(scope="module", params=["tiny", "tiny_onehot", "tiny_proprio"])
+@pytest.fixture(scope="module", params=["tiny", "tiny_onehot", "tiny_proprio", "tiny_both", "cfg4_b4", "cfg5_b4"])
 def tiny_run(request):
     name = request.param
     exp = Hh.oracle_update(name)
@@ -66,9 +75,13 @@ def test_world_model_gradients_and_adam_step(tiny_run):
     exp = tiny_run["exp"]
     for k, g in exp["wm_grads"].items():
         close(tiny_run["wm_grads"][k], g, tol=3e-4, what="grad " + k)
-    close(torch.tensor(float(tiny_run["mets"]["model_grad_norm"])), exp["model_grad_norm"], tol=2e-4, what="grad norm")
+    # the norm against the float64 norm of the oracle's gradients (tight); the oracle's own float32
+    # clip_grad_norm_ value drifts by up to ~1e-3 on the 180 M-parameter configs (float32 accumulation on the CPU)
+    true_norm = torch.sqrt(sum((g.double() ** 2).sum() for g in exp["wm_grads"].values()))
+    close(torch.tensor(float(tiny_run["mets"]["model_grad_norm"])), true_norm, tol=2e-5, what="grad norm (float64)")
+    close(torch.tensor(float(tiny_run["mets"]["model_grad_norm"])), exp["model_grad_norm"], tol=2e-3, what="grad norm")
     for k, v in tiny_run["wm_after"].items():
-        close(v, exp["params_after"][k], tol=1e-6, what="after " + k)
+        adam_close(v, exp["params_after"][k], 1e-4, "after " + k)
 
 
 def test_behaviour_update(tiny_run):
@@ -98,4 +111,7 @@ def test_behaviour_update(tiny_run):
     for k in sd:
         if k.startswith("_world_model.") or k == "ema_vals":
             continue
-        close(sd[k], exp["params_after"][k], tol=1e-6, what="after " + k)
+        if k.startswith("_slow_value."):
+            close(sd[k], exp["params_after"][k], tol=1e-6, what="after " + k)
+        else:
+            adam_close(sd[k], exp["params_after"][k], 3e-5, "after " + k)

@@ -1,0 +1,26 @@
+# rocprofv3 evidence for profiles/: kernel-trace stats, SQ (MFMA busy) counters, FETCH_SIZE and WRITE_SIZE passes
+# (separate passes; counters only with --kernel-trace, never with sys/runtime traces)
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+CMD="python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
+echo "trace rc=$?"
+timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
+echo "sq rc=$?"
+timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
+echo "fetch rc=$?"
+timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+echo "write rc=$?"
+find $OUT -name "*.csv" | head -20
+SQ=$(find $OUT/pmc_sq -name "*counter_collection.csv" | head -1)
+FE=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1)
+WR=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
+ST=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
+python tools/pmc_mfma.py $SQ $OUT/pmc_mfma.json | head -16
+python tools/pmc_traffic.py $FE $WR $OUT/pmc_traffic.json | head -14
+cp $ST $OUT/kernel_stats.csv
+# the raw counter CSVs are large: keep only the summaries
+rm -rf $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write
+find $OUT/trace -name "*.csv" ! -name "*kernel_stats.csv" -delete

@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/r02e
-timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py tests/test_agent_gpu.py -q -m gpu -x -k "actor_head or dreamer_agent or policy_steps" > gpurun_out/r02e/tests.log 2>&1; echo rc=$? >> gpurun_out/r02e/tests.log; tail -3 gpurun_out/r02e/tests.log
+timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py tests/test_agent_gpu.py tests/test_api_gpu.py tests/test_path_gpu.py -q -m gpu -x -k "actor_head or dreamer_agent or policy_steps or quantile or api_gpu or tiny_run or world_model or behaviour or gru_fwd" > gpurun_out/r02e/tests.log 2>&1; echo rc=$? >> gpurun_out/r02e/tests.log; tail -12 gpurun_out/r02e/tests.log
 timeout -k 10 200 python tools/imag_bench.py cfg2 > gpurun_out/r02e/imag.log 2>&1; head -8 gpurun_out/r02e/imag.log
 for v in "1 1" "0 1" "0 2" "0 4"; do set -- $v
   echo "== pipe $1 batch $2" >> gpurun_out/r02e/gemm_sweep.log

@@ -3,7 +3,8 @@
 
     python tools/policy_bench.py [--envs 1 4 16]
 
-Prints the host-visible time per call (launch + device + the final D2H of the action), eager.
+Prints the host-visible time per call (launch + device + the final D2H of the action): hipGraph replay
+(dv3hip.graph.PolicyRunner, the default of Dreamer._policy) and eager.
 """
 import argparse
 import os
@@ -64,7 +65,13 @@ def main():
             out, state = agent._policy(obs, state, training=True)
             a = out["action"].cpu()  # what the env loop needs back
         dt = (time.perf_counter() - t0) / args.reps
-        print(f"envs={E:3d}: {dt * 1e3:7.3f} ms per acting step (eager, incl. H2D of the image and D2H of the action)")
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            out, state = agent._policy_eager(obs, state, training=True)
+            a = out["action"].cpu()
+        de = (time.perf_counter() - t0) / args.reps
+        print(f"envs={E:3d}: {dt * 1e3:7.3f} ms per acting step with hipGraph replay, {de * 1e3:7.3f} ms eager "
+              "(incl. H2D of the image and D2H of the action)")
 
 
 if __name__ == "__main__":
