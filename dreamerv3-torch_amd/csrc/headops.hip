@@ -418,14 +418,15 @@ __global__ void actor_normal_logp_kernel(const float* __restrict__ mean_raw, con
 }
 // Backward of the three actor outputs w.r.t. (mean_raw, std_raw):
 //   daction (through the rsample; the absmax rescale factor is a constant), dent, dlogp (log-prob of the sampled
-//   action: with eps given the action is the rsample of this very (mean, std), as in models.py:667, else held fixed).
+//   action: logp_of_sample = 1: the action is the rsample of this very (mean, std) through eps, as in models.py:667;
+//   0: the action is a constant).
 // Any of daction / dent / dlogp may be null.
 __global__ void actor_normal_bwd_kernel(const float* __restrict__ mean_raw, const float* __restrict__ std_raw,
                                         const float* __restrict__ eps, const float* __restrict__ action,
                                         const float* __restrict__ daction, const float* __restrict__ dent,
                                         const float* __restrict__ dlogp, float* __restrict__ dmean_raw,
                                         float* __restrict__ dstd_raw, long M, int A, float min_std,
-                                        float max_std) {
+                                        float max_std, int logp_of_sample) {
   for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < M; r += (long)gridDim.x * blockDim.x) {
     for (int a = 0; a < A; ++a) {
       const long i = r * A + a;
@@ -445,7 +446,7 @@ __global__ void actor_normal_bwd_kernel(const float* __restrict__ mean_raw, cons
         // c = 1 / max(|mu + sd eps|, 1) is detached): the explicit dependence on (mu, sd) plus the path through a
         const float d = action[i] - mu;
         float dmu_l = d / (sd * sd), dsd_l = d * d / (sd * sd * sd) - 1.f / sd;
-        if (eps) {
+        if (logp_of_sample) {
           const float c = 1.f / fmaxf(fabsf(mu + sd * eps[i]), 1.f);
           const float dla = -d / (sd * sd);
           dmu_l += dla * c;
@@ -741,12 +742,12 @@ extern "C" int dv3_actor_normal_logp(const float* mean_raw, const float* std_raw
 extern "C" int dv3_actor_normal_bwd(const float* mean_raw, const float* std_raw, const float* eps,
                                     const float* action, const float* daction, const float* dent, const float* dlogp,
                                     float* dmean_raw, float* dstd_raw, long M, int A, float min_std, float max_std,
-                                    void* stream) {
+                                    int logp_of_sample, void* stream) {
   if (M <= 0) return 0;
   if (!mean_raw || !std_raw || !dmean_raw || !dstd_raw || A <= 0) return DV3_ERR_ARG;
-  if ((daction && !eps) || (dlogp && !action)) return DV3_ERR_ARG;
+  if ((daction && !eps) || (dlogp && !action) || (dlogp && logp_of_sample && !eps)) return DV3_ERR_ARG;
   hipLaunchKernelGGL(actor_normal_bwd_kernel, dim3(nblk(M, 256, 2048)), dim3(256), 0, S_, mean_raw, std_raw, eps, action,
-                     daction, dent, dlogp, dmean_raw, dstd_raw, M, A, min_std, max_std);
+                     daction, dent, dlogp, dmean_raw, dstd_raw, M, A, min_std, max_std, logp_of_sample);
   return (int)hipGetLastError();
 }
 extern "C" int dv3_lambda_return_fwd(const float* reward, const float* value, const float* cont_logit, float* target,

@@ -739,7 +739,9 @@ def actor_normal_logp(mean_raw, std_raw, action, logp, *, min_std=0.1, max_std=1
 
 
 def actor_normal_bwd(mean_raw, std_raw, dmean_raw, dstd_raw, *, eps=None, action=None, daction=None, dent=None,
-                     dlogp=None, min_std=0.1, max_std=1.0):
+                     dlogp=None, min_std=0.1, max_std=1.0, logp_of_sample=False):
+    """logp_of_sample: dlogp is on the log-prob of the action rsampled from this (mean, std) through eps (the path
+    through the action is differentiated, models.py:667); False: the action is a constant."""
     for t, nm in ((mean_raw, "mean_raw"), (std_raw, "std_raw"), (dmean_raw, "dmean_raw"), (dstd_raw, "dstd_raw")):
         _contig(t, nm)
     A = mean_raw.shape[-1]
@@ -753,7 +755,8 @@ def actor_normal_bwd(mean_raw, std_raw, dmean_raw, dstd_raw, *, eps=None, action
     if std_raw.numel() != M * A or dmean_raw.numel() != M * A or dstd_raw.numel() != M * A:
         raise ValueError("size mismatch")
     _call("dv3_actor_normal_bwd", _ptr(mean_raw), _ptr(std_raw), _ptr(eps), _ptr(action), _ptr(daction), _ptr(dent),
-          _ptr(dlogp), _ptr(dmean_raw), _ptr(dstd_raw), M, A, float(min_std), float(max_std), _stream())
+          _ptr(dlogp), _ptr(dmean_raw), _ptr(dstd_raw), M, A, float(min_std), float(max_std), int(logp_of_sample),
+          _stream())
 
 
 def lambda_return_fwd(reward, value, cont_logit, target, weights, disc=None, *, gamma, lam):
@@ -1105,3 +1108,4 @@ def quantile2_ema(x, q0, q1, ema=None, alpha=0.0, out_q=None):
         raise ValueError("quantile2_ema: nothing to write")
     _call("dv3_quantile2_ema", _ptr(x), x.numel(), float(q0), float(q1), _ptr(ema), float(alpha), _ptr(out_q), _stream())
     return out_q if out_q is not None else ema
+

@@ -482,7 +482,7 @@ class ImagBehavior(nn.Module):
         # The stochastic state is an exact one-hot (tools.py:452-460): carry its class indices and let every Linear
         # that reads it (actor layer 0, img_in) gather weight columns instead of multiplying zeros (engine.py).
         idx = g("im.idx", (H, N, S), torch.int32)
-        ops.onehot_to_idx(stoch[0].view(N, S, D), idx[0].view(-1))
+        ops.onehot_to_idx(stoch[0].view(N, S, D), idx[0].view(-1))  # class indices of the start states
         if _FUSED_IMAG:
             actor_eng.pack_onehot(SD)
             rssm.pack_img_in()
@@ -713,7 +713,7 @@ class ImagBehavior(nn.Module):
             ops.actor_normal_bwd(a_mean[:R], a_std[:R], dmean, dstd, eps=im["eps"].view(HN, A)[:R],
                                  action=action.view(HN, A)[:R], daction=None if reinforce else daction.view(HN, A)[:R],
                                  dent=dent.view(HN)[:R], dlogp=dlogp.view(HN)[:R] if use_logp else None,
-                                 min_std=cfg.actor["min_std"], max_std=cfg.actor["max_std"])
+                                 min_std=cfg.actor["min_std"], max_std=cfg.actor["max_std"], logp_of_sample=use_logp)
         else:
             if not reinforce:
                 # sampled one-hot action: straight-through gradient of the sample, plus the entropy term

@@ -215,7 +215,11 @@ int dv3_actor_normal_logp(const float* mean_raw, const float* std_raw, const flo
                           int A, float min_std, float max_std, void* stream);
 int dv3_actor_normal_bwd(const float* mean_raw, const float* std_raw, const float* eps, const float* action,
                          const float* daction, const float* dent, const float* dlogp, float* dmean_raw,
-                         float* dstd_raw, long M, int A, float min_std, float max_std, void* stream);
+                         float* dstd_raw, long M, int A, float min_std, float max_std,
+                         int logp_of_sample, void* stream);
+/* logp_of_sample = 1: dlogp is the gradient on log N(action) of the action rsampled from this very (mean, std)
+ * through eps (policy.log_prob(imag_action), models.py:667: the path through the action is included); 0: the action
+ * is a constant. */
 
 /* ---- lambda-return + discount weights -- tools.lambda_return (tools.py:682-728),
  * ImagBehavior._compute_target (models.py:620-638).  reward/value/cont_logit/weights/disc [H,N],

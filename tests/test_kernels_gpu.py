@@ -453,6 +453,16 @@ def test_actor_normal_fwd_bwd(ops):
     ops.actor_normal_bwd(mrd, srd, dm, ds, eps=dev(eps), action=dev(fixed), daction=dev(da), dent=dev(de), dlogp=dev(dl))
     assert_close(dm, mr.grad, what="dmean_raw")
     assert_close(ds, sr.grad, what="dstd_raw")
+    # log-prob of the rsampled action itself (policy.log_prob(imag_action), models.py:667): the path through the action
+    mr.grad = sr.grad = None
+    mean, std = torch.tanh(mr), 0.9 * torch.sigmoid(sr + 2.0) + 0.1
+    pre = mean + std * eps
+    act = pre * (1.0 / torch.clip(pre.abs(), min=1.0)).detach()
+    lp2 = (-((act - mean) ** 2) / (2 * std ** 2) - torch.log(std) - math.log(math.sqrt(2 * math.pi))).sum(-1)
+    (lp2 * dl).sum().backward()
+    ops.actor_normal_bwd(mrd, srd, dm, ds, eps=dev(eps), action=dev(act.detach()), dlogp=dev(dl), logp_of_sample=True)
+    assert_close(dm, mr.grad, what="dmean_raw (log-prob of the sample)")
+    assert_close(ds, sr.grad, what="dstd_raw (log-prob of the sample)")
 
 
 def test_lambda_return_fwd_bwd(ops):
@@ -916,3 +926,4 @@ def test_gemm_sample_with_layernorm_on_load(ops, M, N, K):
     ref = F.silu(O.layer_norm(wide[:, :K], gamma, beta)) @ W.t() + b
     assert_close(lg1, ref, tol=2e-4, what="logits vs torch")
     assert (st1 != st0).any(-1).float().mean() <= 1e-3
+

@@ -15,16 +15,24 @@ def ds():
     while True: yield common.make_batch(name)
 agent=dreamer.Dreamer(Hh.obs_space(name),None,cfg,L(),ds()).to(cfg.device); agent.requires_grad_(False)
 rs=np.random.RandomState(0)
-for E in (1,4,16):
+def series(tag, f, n=10, sync=True):
+    ts=[]
+    for _ in range(n):
+        t0=time.perf_counter(); r=f();
+        if sync: torch.cuda.synchronize()
+        ts.append((time.perf_counter()-t0)*1e3)
+    print(tag, " ".join("%.2f"%t for t in ts), flush=True)
+for E in (1,4):
     obs={"image":rs.randint(0,256,(E,64,64,3)).astype(np.uint8),"is_first":np.zeros((E,),bool),"is_terminal":np.zeros((E,),bool)}
-    out,state=agent._policy(dict(obs,is_first=np.ones((E,),bool)),None,True)
-    for _ in range(3): out,state=agent._policy(obs,state,True)
-    pr=agent._policy_runner; key=[k for k in pr._sig if k[0]==E][0]; st=pr._sig[key]
+    out,state=agent._policy_eager(dict(obs,is_first=np.ones((E,),bool)),None,True)
+    for _ in range(3): out,state=agent._policy_eager(obs,state,True)
     torch.cuda.synchronize()
-    def tm(f,n=20):
-        torch.cuda.synchronize(); t0=time.perf_counter()
-        for _ in range(n): f()
-        torch.cuda.synchronize(); return (time.perf_counter()-t0)/n*1e3
-    print(E, "load %.3f"%tm(lambda: pr._load(st,obs,state)), "replay %.3f"%tm(lambda: st["graph"].replay()),
-          "clone %.3f"%tm(lambda: st["packed"].clone()), "full %.3f"%tm(lambda: agent._policy(obs,state,True)),
-          "eager %.3f"%tm(lambda: agent._policy_eager(obs,state,True)), flush=True)
+    series(f"E={E} eager-before", lambda: agent._policy_eager(obs,state,True))
+    out,_=agent._policy(obs,state,True); torch.cuda.synchronize()
+    series(f"E={E} graph", lambda: agent._policy(obs,state,True))
+    series(f"E={E} graph+cpu", lambda: agent._policy(obs,state,True)[0]["action"].cpu(), sync=False)
+    series(f"E={E} eager-after", lambda: agent._policy_eager(obs,state,True))
+    pr=agent._policy_runner; key=[k for k in pr._sig if k[0]==E][0]; st=pr._sig[key]
+    series(f"E={E} load-only", lambda: pr._load(st,obs,state))
+    series(f"E={E} replay-only", lambda: st["graph"].replay())
+    print("mem allocated MB", torch.cuda.memory_allocated()/2**20, "reserved", torch.cuda.memory_reserved()/2**20)

@@ -60,18 +60,29 @@ def main():
         for _ in range(5):
             out, state = agent._policy(obs, state, training=True)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.reps):
+
+        def med(fn):
+            ts = []
+            for _ in range(args.reps):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts)) * 1e3, float(np.max(ts)) * 1e3
+
+        def graph_step():
+            nonlocal state
             out, state = agent._policy(obs, state, training=True)
-            a = out["action"].cpu()  # what the env loop needs back
-        dt = (time.perf_counter() - t0) / args.reps
-        t0 = time.perf_counter()
-        for _ in range(args.reps):
+            return out["action"].cpu()  # what the env loop needs back
+
+        def eager_step():
+            nonlocal state
             out, state = agent._policy_eager(obs, state, training=True)
-            a = out["action"].cpu()
-        de = (time.perf_counter() - t0) / args.reps
-        print(f"envs={E:3d}: {dt * 1e3:7.3f} ms per acting step with hipGraph replay, {de * 1e3:7.3f} ms eager "
-              "(incl. H2D of the image and D2H of the action)")
+            return out["action"].cpu()
+
+        g, gmax = med(graph_step)
+        e, emax = med(eager_step)
+        print(f"envs={E:3d}: median {g:6.3f} ms per acting step with hipGraph replay (max {gmax:.2f}), {e:6.3f} ms eager "
+              f"(max {emax:.2f}); incl. H2D of the image and D2H of the action")
 
 
 if __name__ == "__main__":
