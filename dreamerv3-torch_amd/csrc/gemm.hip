@@ -592,6 +592,165 @@ static void launch_direct(const GemmParams& p, hipStream_t s) {
   else launch_direct_rn<TB, 4>(p, waves, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled y = [A|A2] W^T (+ bias) for the 1024-row imagination GEMMs, v_mfma_f32_16x16x4_f32 with BOTH operands
+// kept k-contiguous in LDS: a lane's MFMA fragment for four consecutive k steps is one ds_read_b128 (row i = l & 15,
+// k = 16 kk + 4 (l >> 4) .. +3) and a staged float4 is one ds_write_b128 -- a quarter of the LDS instructions of
+// the k-major 32x32x2 tile engine, and every loaded element is reused BN/32 (A) or BM/32 (B) times from registers.
+// Row stride 40 floats: the 16 lanes a ds_read_b128 serves together (0-3, 12-15, 20-27 | ...) then cover all 64
+// banks exactly once (i*40 + 4q mod 64 is a permutation of the 16 four-bank windows), and the 8 lanes of a
+// ds_write_b128 group write 128 contiguous bytes.  One workgroup = 4 waves (2 x 2) = one BM x BN tile, BK = 32,
+// double-buffered: global loads of K-tile t+1 are issued before the MFMAs of tile t, one barrier per K-tile.
+// The tile is chosen so that M/BM * N/BN = 256 workgroups = one per CU (1024 x 1536: 64 x 96; 1024 x 1024: 64 x 64;
+// 1024 x 512: 32 x 64).  XCD-aware 2-D mapping: each XCD owns a (tiles_m/4) x (tiles_n/2) block of tiles, so its L2
+// holds a quarter of A and half of B instead of streaming one operand whole.
+// Requires K % 32 == 0, K1 % 32 == 0, lda/lda2/ldb % 4 == 0 (checked by the launcher).
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_l16_kernel(GemmParams p) {
+  constexpr int BK = 32, LD = 40;
+  constexpr int TMW = BM / 32, TNW = BN / 32;  // 16 x 16 blocks per wave (wave tile = BM/2 x BN/2)
+  constexpr int NA = BM * (BK / 4) / 256, NB = BN * (BK / 4) / 256;
+  static_assert(BM % 32 == 0 && BN % 32 == 0 && NA >= 1 && NB >= 1, "tile");
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm, tn;
+  {
+    const int id = blockIdx.x;
+    if ((p.tiles_m & 3) == 0 && (p.tiles_n & 1) == 0) {
+      const int xcd = id & 7, loc = id >> 3;
+      const int bm = p.tiles_m >> 2, bn = p.tiles_n >> 1;
+      tm = (xcd >> 1) * bm + loc / bn;
+      tn = (xcd & 1) * bn + loc % bn;
+    } else {
+      tm = id / p.tiles_n;
+      tn = id % p.tiles_n;
+    }
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  // staging: float4 f = tid + 256 j of a [rows][8] grid -> row f >> 3, k offset 4 (f & 7)
+  const float* asrc[NA];
+  const float* asrc2[NA];
+  bool aok[NA];
+  const float* bsrc[NB];
+  bool bok[NB];
+  const int c4 = (tid & 7) * 4;
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int row = m0 + ((tid + 256 * j) >> 3);
+    aok[j] = row < p.M;
+    asrc[j] = p.A + (long)(aok[j] ? row : 0) * p.lda + c4;
+    asrc2[j] = p.A2 ? p.A2 + (long)(aok[j] ? row : 0) * p.lda2 + c4 : nullptr;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int col = n0 + ((tid + 256 * j) >> 3);
+    bok[j] = col < p.N;
+    bsrc[j] = p.B + (long)(bok[j] ? col : 0) * p.ldb + c4;
+  }
+  f32x4 ra[NA], rb[NB];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto gload = [&](int k0) {
+    const bool seg2 = k0 >= p.K1;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(seg2 ? asrc2[j] + (k0 - p.K1) : asrc[j] + k0);
+      ra[j] = aok[j] ? v : zero4;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(bsrc[j] + k0);
+      rb[j] = bok[j] ? v : zero4;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      *reinterpret_cast<f32x4*>(&As[buf][((tid + 256 * j) >> 3) * LD + c4]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      *reinterpret_cast<f32x4*>(&Bs[buf][((tid + 256 * j) >> 3) * LD + c4]) = rb[j];
+  };
+  f32x4 acc[TMW][TNW];
+#pragma unroll
+  for (int a = 0; a < TMW; ++a)
+#pragma unroll
+    for (int b = 0; b < TNW; ++b) acc[a][b] = zero4;
+  const int nk = p.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int aoff = (wm * (BM / 2) + i) * LD + 4 * q;
+  const int boff = (wn * (BN / 2) + i) * LD + 4 * q;
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nk) gload((t + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      f32x4 af[TMW], bf[TNW];
+#pragma unroll
+      for (int a = 0; a < TMW; ++a) af[a] = *reinterpret_cast<const f32x4*>(&As[cur][aoff + 16 * a * LD + 16 * kk]);
+#pragma unroll
+      for (int b = 0; b < TNW; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&Bs[cur][boff + 16 * b * LD + 16 * kk]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int a = 0; a < TMW; ++a)
+#pragma unroll
+          for (int b = 0; b < TNW; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][g], bf[b][g], acc[a][b], 0, 0, 0);
+    }
+    if (t + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+  // accumulator register r of block (a, b): row 16 a + 4 q + r, column 16 b + i
+#pragma unroll
+  for (int a = 0; a < TMW; ++a)
+#pragma unroll
+    for (int b = 0; b < TNW; ++b) {
+      const int col = n0 + wn * (BN / 2) + 16 * b + i;
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * (BM / 2) + 16 * a + 4 * q + r;
+        if (row < p.M) {
+          float* o = p.C + (long)row * p.ldc + col;
+          float v = acc[a][b][r] + bv;
+          if (p.accumulate) v += *o;
+          *o = v;
+        }
+      }
+    }
+}
+
+static bool l16_ok(const GemmParams& p, int transA, int transB) {
+  return !transA && transB && p.K >= 32 && (p.K % 32) == 0 && (p.K1 % 32) == 0 && (p.lda % 4) == 0 &&
+         (!p.A2 || (p.lda2 % 4) == 0) && (p.ldb % 4) == 0 && ((uintptr_t)p.A % 16) == 0 &&
+         (!p.A2 || ((uintptr_t)p.A2 % 16) == 0) && ((uintptr_t)p.B % 16) == 0;
+}
+
+// tile: the largest of 64x96 / 64x64 / 32x64 that still gives every CU a workgroup
+static void launch_l16(const GemmParams& p0, hipStream_t s) {
+  static const int env = getenv("DV3_L16_TILE") ? atoi(getenv("DV3_L16_TILE")) : 0;
+  GemmParams p = p0;
+  auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  int sel = 3;
+  if (wgs(64, 96) >= 256 && (p.N % 96) == 0) sel = 1;
+  else if (wgs(64, 64) >= 256) sel = 2;
+  if (env >= 1 && env <= 3) sel = env;
+  const int bm = sel == 3 ? 32 : 64, bn = sel == 1 ? 96 : 64;
+  p.tiles_m = (p.M + bm - 1) / bm;
+  p.tiles_n = (p.N + bn - 1) / bn;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  if (sel == 1) hipLaunchKernelGGL((gemm_l16_kernel<64, 96>), grid, block, 0, s, p);
+  else if (sel == 2) hipLaunchKernelGGL((gemm_l16_kernel<64, 64>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_l16_kernel<32, 64>), grid, block, 0, s, p);
+}
+
 // Register-direct weight gradient: C[M,N] += A^T B with A [K][M] and B [K][N] (both row-major over the batch
 // rows K): every fragment element is one 4-byte load (a lane's four k values sit in four different rows), 16
 // lanes per 64 contiguous bytes.  K is split over gridDim.y workgroups (atomic adds) and then over the waves.
@@ -927,7 +1086,7 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   }
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
-  int t = ((tile >= 0 && tile <= 6) || (tile >= 8 && tile <= 10)) ? tile : pick_tile(M, N, K, accumulate);
+  int t = ((tile >= 0 && tile <= 6) || (tile >= 8 && tile <= 11)) ? tile : pick_tile(M, N, K, accumulate);
   if (t == 9 && tile < 0 && (transA || (A2 && (K1 % 16) != 0))) t = ((long)M * N <= 512L * 1024) ? 8 : 6;
   if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6 || t == 8)) t = 1;
   hipStream_t s = (hipStream_t)stream;
@@ -951,6 +1110,12 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
     // register-direct weight gradient: A [K][M], B [K][N]
     if (!transA || transB || A2 || bias) return DV3_ERR_ARG;
     launch_direct_tn(p, s);
+    return (int)hipGetLastError();
+  }
+  if (t == 11) {
+    // k-contiguous LDS tiles, 16x16x4 MFMA: y = x W^T only, K and the segment edge on 32-k tile boundaries
+    if (!l16_ok(p, transA, transB)) return DV3_ERR_ARG;
+    launch_l16(p, s);
     return (int)hipGetLastError();
   }
   if (t == 9) {

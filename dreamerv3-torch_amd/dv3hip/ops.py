@@ -89,7 +89,7 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
 
 
 _TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2", 7: "narrowN",
-               8: "32x32x64s4", 9: "direct32x64", 10: "directTN32x64"}
+               8: "32x32x64s4", 9: "direct32x64", 10: "directTN32x64", 11: "l16"}
 
 
 _TILE_TEMPLATES = {0: "2, 2, 2, 2, 16, 1", 1: "2, 2, 1, 1, 32, 1", 2: "1, 4, 1, 1, 32, 1", 4: "2, 2, 2, 2, 32, 1",
@@ -113,6 +113,8 @@ def kernel_symbol(key: str) -> str:
                     else f"void dv3::gemm_direct_kernel<{tb}, 4, 1, 0, 1>(dv3::GemmParams)")
         if tile == 10:
             return "void dv3::gemm_direct_tn_kernel<4, 1>(dv3::GemmParams)"
+        if tile == 11:
+            return "void dv3::gemm_l16_kernel<64, 96>(dv3::GemmParams)"
         return f"void dv3::gemm_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, {ta}, {tb}>(dv3::GemmParams)"
     m = re.match(r"conv_wgrad_kernel<([^,>]+)(,c3)?>", key)
     if m:
@@ -129,6 +131,13 @@ _SMALL_TILE = int(os.environ.get("DV3_SMALL_TILE", "9"))
 # 512k .. 2M outputs (1024 rows x 1024 / 1536 columns): direct again (4 waves per workgroup), 45.8 vs 48.3 us on
 # the GRU matmul against the 32x64 LDS tile (6)
 _MID_TILE = int(os.environ.get("DV3_MID_TILE", "9"))
+
+
+def l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb) -> bool:
+    """Preconditions of the k-contiguous LDS tile kernel (tile 11; csrc/gemm.hip l16_ok)."""
+    return (not transA and transB and K >= 32 and K % 32 == 0 and K1 % 32 == 0 and lda % 4 == 0 and ldb % 4 == 0
+            and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0
+            and (A2 is None or (lda2 % 4 == 0 and A2.data_ptr() % 16 == 0)))
 
 
 def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
@@ -193,6 +202,8 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
             tile = 3
         if tile in (6, 8) and A2 is not None and (K1 % 64) != 0:
             tile = 1
+        if tile == 11 and not l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb):
+            tile = 9
         if tile == 9 and (transA or (A2 is not None and (K1 % 16) != 0)):
             tile = (8 if M * N <= 512 * 1024 else 6) if not (A2 is not None and (K1 % 64) != 0) else 1
         if tile == 10 and (transB or A2 is not None or bias is not None):
