@@ -606,7 +606,7 @@ static void launch_direct(const GemmParams& p, hipStream_t s) {
 // holds a quarter of A and half of B instead of streaming one operand whole.
 // Requires K % 32 == 0, K1 % 32 == 0, lda/lda2/ldb % 4 == 0 (checked by the launcher).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, int PF, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_l16_kernel(GemmParams p) {
   constexpr int BK = 32, LD = 40;
   constexpr int TMW = BM / 32, TNW = BN / 32;  // 16 x 16 blocks per wave (wave tile = BM/2 x BN/2)
@@ -631,48 +631,43 @@ __global__ __launch_bounds__(256) void gemm_l16_kernel(GemmParams p) {
     }
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  // staging: float4 f = tid + 256 j of a [rows][8] grid -> row f >> 3, k offset 4 (f & 7)
+  // staging: float4 f = tid + 256 j of a [rows][8] grid -> row f >> 3, k offset 4 (f & 7).  Rows past the edge of
+  // the matrix read row 0 instead: they only feed outputs past the edge, which the epilogue does not store (no
+  // masking of the loaded values, which would make the wave wait for its prefetch as soon as it is issued).
   const float* asrc[NA];
   const float* asrc2[NA];
-  bool aok[NA];
   const float* bsrc[NB];
-  bool bok[NB];
   const int c4 = (tid & 7) * 4;
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int row = m0 + ((tid + 256 * j) >> 3);
-    aok[j] = row < p.M;
-    asrc[j] = p.A + (long)(aok[j] ? row : 0) * p.lda + c4;
-    asrc2[j] = p.A2 ? p.A2 + (long)(aok[j] ? row : 0) * p.lda2 + c4 : nullptr;
+    asrc[j] = p.A + (long)(row < p.M ? row : 0) * p.lda + c4;
+    asrc2[j] = p.A2 ? p.A2 + (long)(row < p.M ? row : 0) * p.lda2 + c4 : nullptr;
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int col = n0 + ((tid + 256 * j) >> 3);
-    bok[j] = col < p.N;
-    bsrc[j] = p.B + (long)(bok[j] ? col : 0) * p.ldb + c4;
+    bsrc[j] = p.B + (long)(col < p.N ? col : 0) * p.ldb + c4;
   }
-  f32x4 ra[NA], rb[NB];
+  // PF register sets: the loads of K-tile t + PF are in flight while tile t is multiplied (a tile's MFMAs take
+  // ~0.6 us, a load from the Infinity Cache / HBM under contention longer: PF = 1 leaves the wave waiting on it)
+  f32x4 ra[PF][NA], rb[PF][NB];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  auto gload = [&](int k0) {
+  auto gload = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB], int k0) {
     const bool seg2 = k0 >= p.K1;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(seg2 ? asrc2[j] + (k0 - p.K1) : asrc[j] + k0);
-      ra[j] = aok[j] ? v : zero4;
-    }
+    for (int j = 0; j < NA; ++j)
+      xa[j] = *reinterpret_cast<const f32x4*>(seg2 ? asrc2[j] + (k0 - p.K1) : asrc[j] + k0);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(bsrc[j] + k0);
-      rb[j] = bok[j] ? v : zero4;
-    }
+    for (int j = 0; j < NB; ++j) xb[j] = *reinterpret_cast<const f32x4*>(bsrc[j] + k0);
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](const f32x4 (&xa)[NA], const f32x4 (&xb)[NB], int buf) {
 #pragma unroll
     for (int j = 0; j < NA; ++j)
-      *reinterpret_cast<f32x4*>(&As[buf][((tid + 256 * j) >> 3) * LD + c4]) = ra[j];
+      *reinterpret_cast<f32x4*>(&As[buf][((tid + 256 * j) >> 3) * LD + c4]) = xa[j];
 #pragma unroll
     for (int j = 0; j < NB; ++j)
-      *reinterpret_cast<f32x4*>(&Bs[buf][((tid + 256 * j) >> 3) * LD + c4]) = rb[j];
+      *reinterpret_cast<f32x4*>(&Bs[buf][((tid + 256 * j) >> 3) * LD + c4]) = xb[j];
   };
   f32x4 acc[TMW][TNW];
 #pragma unroll
@@ -680,14 +675,21 @@ __global__ __launch_bounds__(256) void gemm_l16_kernel(GemmParams p) {
 #pragma unroll
     for (int b = 0; b < TNW; ++b) acc[a][b] = zero4;
   const int nk = p.K / BK;
-  gload(0);
-  lstore(0);
+  gload(ra[0], rb[0], 0);
+  lstore(ra[0], rb[0], 0);
+#pragma unroll
+  for (int u = 1; u < PF; ++u)
+    if (u < nk) gload(ra[u], rb[u], u * BK);
   __syncthreads();
   const int aoff = (wm * (BM / 2) + i) * LD + 4 * q;
   const int boff = (wn * (BN / 2) + i) * LD + 4 * q;
-  for (int t = 0; t < nk; ++t) {
+  for (int t0 = 0; t0 < nk; t0 += PF)
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int t = t0 + u;
+    if (t >= nk) break;
     const int cur = t & 1;
-    if (t + 1 < nk) gload((t + 1) * BK);
+    if (t + PF < nk) gload(ra[u], rb[u], (t + PF) * BK);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       f32x4 af[TMW], bf[TNW];
@@ -703,8 +705,109 @@ __global__ __launch_bounds__(256) void gemm_l16_kernel(GemmParams p) {
           for (int b = 0; b < TNW; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][g], bf[b][g], acc[a][b], 0, 0, 0);
     }
-    if (t + 1 < nk) lstore(cur ^ 1);
+    if (t + 1 < nk) lstore(ra[(u + 1) % PF], rb[(u + 1) % PF], cur ^ 1);
     __syncthreads();
+  }
+  if constexpr (EPI == 1) {
+    // Sampling epilogue (as gemm_direct_kernel EPI 1; 32 x 64 tile only): a wave's 16 x 32 tile is one whole
+    // categorical group of 16 rows, lane (i, q) holding classes i and 16 + i of rows 4q .. 4q+3, so the softmax,
+    // the p_hat / q argmax and the one-hot stay in registers (four xor-shuffles per reduction, the four rows of a
+    // lane interleaved).  Same reduction order as dv3_onehot_sample_fwd: class d first meets d ^ 16 (the lane's
+    // other register), then d ^ 8 .. d ^ 1 -- the sample is bit-equal to the two-launch form.
+    static_assert(BM == 32 && BN == 64, "sampling epilogue: 32 x 64 tile");
+    const int S = p.N >> 5;
+    const int colb = n0 + wn * 32;
+    if (colb >= p.N) return;  // wave-uniform; no barrier follows
+    unsigned long long seed = 0, offset = 0;
+    if (!p.smp_mode && !p.smp_noise) {
+      seed = p.smp_rng[0];
+      offset = p.smp_rng[1] + p.smp_off;
+    }
+    const float bias0 = p.bias ? p.bias[colb + i] : 0.f, bias1 = p.bias ? p.bias[colb + 16 + i] : 0.f;
+    float l0[4], l1[4], mx[4], e0[4], e1[4], sm[4], sc[4];
+    int bi[4];
+    long gi[4];
+    bool rv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wm * 16 + 4 * q + r;
+      rv[r] = row < p.M;
+      gi[r] = (long)row * S + (colb >> 5);
+      l0[r] = acc[0][0][r] + bias0;
+      l1[r] = acc[0][1][r] + bias1;
+      if (rv[r]) {
+        float* o = p.C + (long)row * p.ldc + colb + i;
+        o[0] = l0[r];
+        o[16] = l1[r];
+      }
+      mx[r] = fmaxf(l0[r], l1[r]);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      e0[r] = expf(l0[r] - mx[r]);
+      e1[r] = expf(l1[r] - mx[r]);
+      sm[r] = e0[r] + e1[r];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sm[r] += __shfl_xor(sm[r], o, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ph0 = (e0[r] / sm[r]) * (1.f - p.smp_unimix) + p.smp_unimix / 32.f;
+      const float ph1 = (e1[r] / sm[r]) * (1.f - p.smp_unimix) + p.smp_unimix / 32.f;
+      float s0 = ph0, s1 = ph1;
+      if (!p.smp_mode) {
+        float q0, q1;
+        if (p.smp_noise) {
+          q0 = rv[r] ? p.smp_noise[gi[r] * 32 + i] : 1.f;
+          q1 = rv[r] ? p.smp_noise[gi[r] * 32 + 16 + i] : 1.f;
+        } else {
+          uint32_t o4[4];
+          const unsigned long long ea = (unsigned long long)gi[r] * 32 + i, eb = ea + 16;
+          Philox ph4(seed);
+          ph4(offset + (ea >> 2), 0x5eedULL, o4);
+          q0 = fmaxf(-logf(u01(o4[ea & 3])), 1e-30f);
+          ph4(offset + (eb >> 2), 0x5eedULL, o4);
+          q1 = fmaxf(-logf(u01(o4[eb & 3])), 1e-30f);
+        }
+        s0 = ph0 / q0;
+        s1 = ph1 / q1;
+      }
+      const bool hi = s1 > s0;  // tie: the lower class index
+      sc[r] = hi ? s1 : s0;
+      bi[r] = hi ? 16 + i : i;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ob = __shfl_xor(sc[r], o, 64);
+        const int oi = __shfl_xor(bi[r], o, 64);
+        if (ob > sc[r] || (ob == sc[r] && oi < bi[r])) {
+          sc[r] = ob;
+          bi[r] = oi;
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (p.smp_forced) {
+        const int f = rv[r] ? p.smp_forced[gi[r]] : 0;
+        if (rv[r] && i == 0 && p.smp_flips && f != bi[r]) atomicAdd(p.smp_flips, 1u);
+        bi[r] = f;
+      }
+      if (rv[r]) {
+        float* o = p.smp_onehot + gi[r] * 32 + i;
+        o[0] = (i == bi[r]) ? 1.f : 0.f;
+        o[16] = (16 + i == bi[r]) ? 1.f : 0.f;
+        if (i == 0 && p.smp_idx) p.smp_idx[gi[r]] = bi[r];
+      }
+    }
+    return;
   }
   // accumulator register r of block (a, b): row 16 a + 4 q + r, column 16 b + i
 #pragma unroll
@@ -727,28 +830,42 @@ __global__ __launch_bounds__(256) void gemm_l16_kernel(GemmParams p) {
     }
 }
 
+static bool l16_ok(const GemmParams& p, int transA, int transB);
+static void launch_l16_sample(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  p.tiles_m = (p.M + 31) / 32;
+  p.tiles_n = (p.N + 63) / 64;
+  hipLaunchKernelGGL((gemm_l16_kernel<32, 64, 1, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+}
+
 static bool l16_ok(const GemmParams& p, int transA, int transB) {
   return !transA && transB && p.K >= 32 && (p.K % 32) == 0 && (p.K1 % 32) == 0 && (p.lda % 4) == 0 &&
          (!p.A2 || (p.lda2 % 4) == 0) && (p.ldb % 4) == 0 && ((uintptr_t)p.A % 16) == 0 &&
          (!p.A2 || ((uintptr_t)p.A2 % 16) == 0) && ((uintptr_t)p.B % 16) == 0;
 }
 
-// tile: the largest of 64x96 / 64x64 / 32x64 that still gives every CU a workgroup
-static void launch_l16(const GemmParams& p0, hipStream_t s) {
-  static const int env = getenv("DV3_L16_TILE") ? atoi(getenv("DV3_L16_TILE")) : 0;
+// tile shape: measured (gpurun_out/r02t), 1024 x 1536 x 1024: 32x64 35.9 us (768 workgroups, three per CU: one
+// workgroup's barrier / LDS-fill bubbles are covered by the MFMAs of the others), 64x96 39.8 (one per CU), 64x64 44.3,
+// register-direct 44.0; 4096^3: 64x64 and 64x96 115-119 TFLOP/s.  Prefetch distance 1 / 2 / 4 measured equal.
+static void launch_l16(const GemmParams& p0, int force, hipStream_t s) {
   GemmParams p = p0;
   auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  int sel = 3;
-  if (wgs(64, 96) >= 256 && (p.N % 96) == 0) sel = 1;
-  else if (wgs(64, 64) >= 256) sel = 2;
-  if (env >= 1 && env <= 3) sel = env;
+  int sel = wgs(64, 64) >= 1024 ? 2 : 3;
+  if (force >= 1 && force <= 3) sel = force;
   const int bm = sel == 3 ? 32 : 64, bn = sel == 1 ? 96 : 64;
   p.tiles_m = (p.M + bm - 1) / bm;
   p.tiles_n = (p.N + bn - 1) / bn;
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
-  if (sel == 1) hipLaunchKernelGGL((gemm_l16_kernel<64, 96>), grid, block, 0, s, p);
-  else if (sel == 2) hipLaunchKernelGGL((gemm_l16_kernel<64, 64>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm_l16_kernel<32, 64>), grid, block, 0, s, p);
+  static const int pf = getenv("DV3_L16_PF") ? atoi(getenv("DV3_L16_PF")) : 1;
+#define DV3_L16_LAUNCH(PFV)                                                                     \
+  do {                                                                                          \
+    if (sel == 1) hipLaunchKernelGGL((gemm_l16_kernel<64, 96, PFV>), grid, block, 0, s, p);      \
+    else if (sel == 2) hipLaunchKernelGGL((gemm_l16_kernel<64, 64, PFV>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((gemm_l16_kernel<32, 64, PFV>), grid, block, 0, s, p);               \
+  } while (0)
+  if (pf == 2) DV3_L16_LAUNCH(2);
+  else DV3_L16_LAUNCH(1);
+#undef DV3_L16_LAUNCH
 }
 
 // Register-direct weight gradient: C[M,N] += A^T B with A [K][M] and B [K][N] (both row-major over the batch
@@ -1046,7 +1163,7 @@ static int pick_tile(int M, int N, int K, int accumulate) {
   if (M <= 32) return 2;
   if (accumulate && K >= 4096 && (long)M * N >= 512L * 1024) return 4;
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
-  if (t64 <= 512 && !accumulate) return 9;
+  if (t64 <= 512 && !accumulate) return t64 <= 128 ? 9 : 11;
   const long c128 = (((long)((M + 127) / 128) * ((N + 127) / 128)) + 255) / 256 * 4;
   const long c64 = (t64 + 255) / 256;
   return (c64 < c128) ? 1 : 4;
@@ -1086,7 +1203,8 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   }
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
-  int t = ((tile >= 0 && tile <= 6) || (tile >= 8 && tile <= 11)) ? tile : pick_tile(M, N, K, accumulate);
+  int t = ((tile >= 0 && tile <= 6) || (tile >= 8 && tile <= 14)) ? tile : pick_tile(M, N, K, accumulate);
+  if (t == 11 && tile < 0 && !l16_ok(p, transA, transB)) t = 9;
   if (t == 9 && tile < 0 && (transA || (A2 && (K1 % 16) != 0))) t = ((long)M * N <= 512L * 1024) ? 8 : 6;
   if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6 || t == 8)) t = 1;
   hipStream_t s = (hipStream_t)stream;
@@ -1112,10 +1230,11 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
     launch_direct_tn(p, s);
     return (int)hipGetLastError();
   }
-  if (t == 11) {
+  if (t >= 11) {
     // k-contiguous LDS tiles, 16x16x4 MFMA: y = x W^T only, K and the segment edge on 32-k tile boundaries
+    // (11: tile shape by size; 12 / 13 / 14: 64x96 / 64x64 / 32x64)
     if (!l16_ok(p, transA, transB)) return DV3_ERR_ARG;
-    launch_l16(p, s);
+    launch_l16(p, t - 11, s);
     return (int)hipGetLastError();
   }
   if (t == 9) {
@@ -1159,6 +1278,11 @@ extern "C" int dv3_gemm_sample_f32(int M, int N, int K, const float* A, long lda
   p.smp_noise = noise; p.smp_rng = rng_state; p.smp_off = rng_offset; p.smp_onehot = onehot; p.smp_idx = idx;
   p.smp_forced = forced; p.smp_flips = flips; p.smp_unimix = unimix; p.smp_mode = mode;
   p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_mean = ln_mean; p.ln_rstd = ln_rstd;
+  // same kernel family as dv3_gemm_f32 picks for the plain product of this size (bit-equal logits)
+  if (!ln_gamma && pick_tile(M, N, K, 0) == 11 && l16_ok(p, 0, 1)) {
+    launch_l16_sample(p, (hipStream_t)stream);
+    return (int)hipGetLastError();
+  }
   const int chunks = (K + 15) / 16;
   launch_direct_rn<true, 4>(p, chunks >= 32 ? 8 : 4, (hipStream_t)stream);
   return (int)hipGetLastError();

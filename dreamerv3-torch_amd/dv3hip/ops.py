@@ -89,7 +89,8 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
 
 
 _TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2", 7: "narrowN",
-               8: "32x32x64s4", 9: "direct32x64", 10: "directTN32x64", 11: "l16"}
+               8: "32x32x64s4", 9: "direct32x64", 10: "directTN32x64", 11: "l16", 12: "l16_64x96", 13: "l16_64x64",
+               14: "l16_32x64"}
 
 
 _TILE_TEMPLATES = {0: "2, 2, 2, 2, 16, 1", 1: "2, 2, 1, 1, 32, 1", 2: "1, 4, 1, 1, 32, 1", 4: "2, 2, 2, 2, 32, 1",
@@ -100,6 +101,8 @@ def kernel_symbol(key: str) -> str:
     """Profile key -> the C++ kernel name rocprofv3 prints (to match bench.py's roofline with profiles/)."""
     import re
 
+    if key.startswith("gemm_kernel<l16+sample"):
+        return "void dv3::gemm_l16_kernel<32, 64, 1, 1>(dv3::GemmParams)"
     if key.startswith("gemm_kernel<direct32x64+sample"):
         return "void dv3::gemm_direct_kernel<true, 4, 2, 1, 0>(dv3::GemmParams)"
     m = re.match(r"gemm_kernel<([^,]+),tA=(\d),tB=(\d)>", key)
@@ -113,8 +116,10 @@ def kernel_symbol(key: str) -> str:
                     else f"void dv3::gemm_direct_kernel<{tb}, 4, 1, 0, 1>(dv3::GemmParams)")
         if tile == 10:
             return "void dv3::gemm_direct_tn_kernel<4, 1>(dv3::GemmParams)"
-        if tile == 11:
-            return "void dv3::gemm_l16_kernel<64, 96>(dv3::GemmParams)"
+        if tile >= 11:
+            return {12: "void dv3::gemm_l16_kernel<64, 96, 1>(dv3::GemmParams)",
+                    13: "void dv3::gemm_l16_kernel<64, 64, 1>(dv3::GemmParams)"}.get(
+                        tile, "void dv3::gemm_l16_kernel<32, 64, 1>(dv3::GemmParams)")
         return f"void dv3::gemm_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, {ta}, {tb}>(dv3::GemmParams)"
     m = re.match(r"conv_wgrad_kernel<([^,>]+)(,c3)?>", key)
     if m:
@@ -128,9 +133,10 @@ def kernel_symbol(key: str) -> str:
 # 16x16x4 MFMA, 32 x 64 outputs per workgroup, K over its waves).  A/B inside one box, ms per update:
 # 32x64 LDS tile (6) 22.46, 32x32 LDS tile with K over the waves (8) 21.65, direct (9) 21.42.
 _SMALL_TILE = int(os.environ.get("DV3_SMALL_TILE", "9"))
-# 512k .. 2M outputs (1024 rows x 1024 / 1536 columns): direct again (4 waves per workgroup), 45.8 vs 48.3 us on
-# the GRU matmul against the 32x64 LDS tile (6)
-_MID_TILE = int(os.environ.get("DV3_MID_TILE", "9"))
+# 512k .. 2M outputs (1024 rows x 1024 / 1536 columns): the k-contiguous LDS tile (11: 32 x 64, ds_read_b128
+# fragments): GRU matmul 35.9 us against 44.0 direct (9) and 48.3 on the k-major 32x64 LDS tile (6); 1024x1024x512
+# 14.5 against 16.7.  Falls back to 9 where its alignment preconditions do not hold.
+_MID_TILE = int(os.environ.get("DV3_MID_TILE", "11"))
 
 
 def l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb) -> bool:
@@ -202,7 +208,7 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
             tile = 3
         if tile in (6, 8) and A2 is not None and (K1 % 64) != 0:
             tile = 1
-        if tile == 11 and not l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb):
+        if tile >= 11 and not l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb):
             tile = 9
         if tile == 9 and (transA or (A2 is not None and (K1 % 16) != 0)):
             tile = (8 if M * N <= 512 * 1024 else 6) if not (A2 is not None and (K1 % 64) != 0) else 1
@@ -1052,7 +1058,7 @@ def actor_head(pre, gamma, beta, y, mean, rstd, Wm, bm, Ws, bs, out_m, out_s, ac
 def gemm_sample_ok(M, N, D, A=None) -> bool:
     """True when ops.gemm_sample applies: groups of 32 classes, whole groups per 64-column tile, and an output
     size for which dv3_gemm_f32 would pick the register-direct kernel anyway."""
-    return D == 32 and N % 64 == 0 and M > 32 and pick_gemm_tile(M, N) == 9
+    return D == 32 and N % 64 == 0 and M > 32 and pick_gemm_tile(M, N) in (9, 11)
 
 
 def gemm_sample(A, B, logit, onehot, *, bias=None, noise=None, rng=None, idx=None, forced=None, flips=None,
@@ -1098,10 +1104,13 @@ def gemm_sample(A, B, logit, onehot, *, bias=None, noise=None, rng=None, idx=Non
                 _contig(t, nm)
                 if t.numel() != M:
                     raise ValueError(nm + " size mismatch")
+    l16 = (ln is None and pick_gemm_tile(M, N) == 11 and _MID_TILE == 11
+           and l16_ok(A, None, B, False, True, K, K, lda, 0, ldb))  # profile key only: the library decides the same way
     _call("dv3_gemm_sample_f32", M, N, K, _ptr(A), lda, 0, 0, 0, _ptr(B), ldb, _ptr(logit), ldc, _ptr(bias), _ptr(noise),
           _ptr(rng_state), int(rng_off), _ptr(onehot), _ptr(idx), _ptr(forced), _ptr(flips), float(unimix), int(mode),
           _ptr(lg), _ptr(lb), _ptr(lm), _ptr(lr),
-          _stream(), key="gemm_kernel<direct32x64+sample,tA=0,tB=1>" + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else ""),
+          _stream(), key=("gemm_kernel<l16+sample,tA=0,tB=1>" if l16 else "gemm_kernel<direct32x64+sample,tA=0,tB=1>")
+          + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else ""),
           flops=2.0 * M * N * K, nbytes=4.0 * (M * K + N * K + 2 * M * N))
     return onehot
 

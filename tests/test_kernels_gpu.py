@@ -119,6 +119,27 @@ def test_gemm_register_direct_kernel(ops, M, N, K1, K2, transB, acc):
     assert_close(C, want, what="gemm tile 9")
 
 
+@pytest.mark.parametrize("M,N,K1,K2", [(1024, 1536, 512, 512), (1024, 1024, 512, 0), (1024, 512, 512, 1024),
+                                       (2048, 1536, 1024, 0), (77, 100, 64, 32), (130, 200, 96, 0), (4096, 3072, 2048, 0)])
+@pytest.mark.parametrize("acc", [False, True])
+@pytest.mark.parametrize("tile", [11, 12, 13, 14])
+def test_gemm_kcontiguous_lds_tile(ops, M, N, K1, K2, acc, tile):
+    """tiles 11-14 (both operands k-contiguous in LDS, ds_read_b128 fragments, 16x16x4 MFMA): y = [A | A2] W^T + b,
+    accumulate, ragged M / N; 11 picks the tile shape by size, 12 / 13 / 14 force 64x96 / 64x64 / 32x64."""
+    if tile != 11 and M * N * (K1 + K2) > 5e9:
+        pytest.skip("large shape: default tile only")
+    g = torch.Generator().manual_seed(M + N + K1 + K2)
+    K = K1 + K2
+    A, A2 = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    C = dev(C0.clone())
+    ops.gemm(dev(A), dev(W), C, A2=dev(A2) if K2 else None, bias=dev(b), accumulate=acc, tile=tile)
+    want = torch.cat([A, A2], -1) @ W.t() + b + (C0 if acc else 0)
+    assert_close(C, want, what=f"gemm tile {tile}")
+
+
 @pytest.mark.parametrize("rows,Nout,Kin", [(1024, 512, 1030), (1024, 1536, 1024), (333, 70, 45), (14336, 255, 512)])
 def test_gemm_tn_wgrad_accumulate(ops, rows, Nout, Kin):
     g = torch.Generator().manual_seed(2)
@@ -858,15 +879,16 @@ def test_onehot_sample_teacher_forcing_counts_flips(ops):
 @pytest.mark.parametrize("M,N,K", [(1024, 1024, 512), (100, 128, 48), (33, 64, 512), (2048, 1024, 512)])
 @pytest.mark.parametrize("mode", [False, True])
 def test_gemm_with_sampling_epilogue_equals_gemm_then_sample(ops, M, N, K, mode):
-    """dv3_gemm_sample_f32 == dv3_gemm_f32 (direct kernel) followed by dv3_onehot_sample_fwd: bit-equal logits and
-    samples, with injected noise, with the Philox stream, and teacher-forced."""
+    """dv3_gemm_sample_f32 == dv3_gemm_f32 (the tile it picks for the size: register-direct for the small shapes, the
+    k-contiguous LDS tile for 1024 x 1024 and up) followed by dv3_onehot_sample_fwd: bit-equal logits and samples,
+    with injected noise, with the Philox stream, and teacher-forced."""
     g = torch.Generator().manual_seed(M + N + K)
     A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K) * 3, torch.randn(N, generator=g)
     q = torch.empty(M, N // 32, 32).exponential_(1.0, generator=g).clamp_min(1e-20)
     A, W, b, q = dev(A), dev(W), dev(b), dev(q)
     lg0, st0 = torch.empty(M, N, device="cuda"), torch.empty(M, N // 32, 32, device="cuda")
     i0 = torch.empty(M * N // 32, dtype=torch.int32, device="cuda")
-    ops.gemm(A, W, lg0, bias=b, tile=9)
+    ops.gemm(A, W, lg0, bias=b, tile=ops.pick_gemm_tile(M, N))
     ops.onehot_sample(lg0.view(M, N // 32, 32), st0, noise=None if mode else q, idx=i0, mode=mode)
     lg1, st1 = torch.empty_like(lg0), torch.empty_like(st0)
     i1 = torch.empty_like(i0)
