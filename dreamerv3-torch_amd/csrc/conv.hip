@@ -873,6 +873,37 @@ extern "C" int dv3_pack_conv_weight(const float* w, float* wp, int Co, int Ci, i
   return (int)hipGetLastError();
 }
 
+// Explicit im2col of Conv2d k4 s2 "same" (networks.py:771-798) for few-image batches -- the acting step (SURVEY
+// 8(f) N1) runs the encoder on 1-16 images, where the tiled implicit-GEMM kernels have 1-16 workgroups walking the
+// whole reduction (30-77 us per layer at one image); cols [N*OH*OW][(ci,ky,kx)] is in the reference weight's own
+// order, so the product is a plain y = cols W.view(Co, 16 Ci)^T on the few-row / register-direct GEMM kernels.
+__global__ void im2col_s2_kernel(const float* __restrict__ x, float* __restrict__ cols, int Nimg, int H, int W, int C) {
+  const int OH = H >> 1, OW = W >> 1;
+  const long K = 16L * C, total = (long)Nimg * OH * OW * K;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % K);
+    long m = e / K;
+    const int kx = k & 3, ky = (k >> 2) & 3, ci = k >> 4;
+    const int ox = (int)(m % OW);
+    m /= OW;
+    const int oy = (int)(m % OH);
+    const long n = m / OH;
+    const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    cols[e] = ok ? x[((n * H + iy) * W + ix) * C + ci] : 0.f;
+  }
+}
+
+extern "C" int dv3_im2col_s2(const float* x, float* cols, int Nimg, int H, int W, int C, void* stream) {
+  if (Nimg <= 0) return 0;
+  if (!x || !cols || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return DV3_ERR_ARG;
+  const long total = (long)Nimg * (H / 2) * (W / 2) * 16 * C;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(im2col_s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, cols, Nimg, H, W, C);
+  return (int)hipGetLastError();
+}
+
 extern "C" int dv3_conv_s2_fwd(const float* x, const float* w_packed, float* y, int Nimg, int H, int W, int Ci, int Co,
                                int accumulate, void* stream) {
   if (Nimg <= 0) return 0;

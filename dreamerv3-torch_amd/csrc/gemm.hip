@@ -122,6 +122,7 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
   const int nwaves = blockDim.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * 16;
+  const int rb = blockIdx.z * (16 * MT);  // row block (gridDim.z > 1: up to 128 rows, e.g. the acting step's encoder)
   // K range of this workgroup (gridDim.y splits, accumulating calls only), then of this wave, in 16-k chunks
   const int chunks = (p.K + 15) >> 4;
   const int per_wg = (chunks + gridDim.y - 1) / gridDim.y;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
   const float* arow2[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    const int row = i + 16 * t;
+    const int row = rb + i + 16 * t;
     const bool ok = row < p.M;
     amask[t] = ok ? 1.f : 0.f;
     arow[t] = p.A + (long)(ok ? row : 0) * p.lda;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
   for (int e = tid; e < MT * 256; e += blockDim.x) {
     const int t = e >> 8, x = e & 255;
     const int r = x >> 6, l = x & 63;
-    const int row = 16 * t + 4 * (l >> 4) + r, col = n0 + (l & 15);
+    const int row = rb + 16 * t + 4 * (l >> 4) + r, col = n0 + (l & 15);
     if (row < p.M && col < p.N) {
       float v = 0.f;
       for (int w = 0; w < nwaves; ++w) v += red[w][t][x];
@@ -1115,7 +1116,7 @@ static void launch_skinny(const GemmParams& p, int accumulate, hipStream_t s) {
   }
   const int per_wg = (chunks + splits - 1) / splits;
   const int per = (per_wg + waves - 1) / waves;
-  const dim3 grid(tiles, splits), block(64 * waves);
+  const dim3 grid(tiles, splits, (p.M + 16 * MT - 1) / (16 * MT)), block(64 * waves);
   if (per <= 3) hipLaunchKernelGGL((gemm_skinny_kernel<TB, MT, 3>), grid, block, 0, s, p);
   else if (per <= 6 || MT > 1) hipLaunchKernelGGL((gemm_skinny_kernel<TB, MT, 6>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_skinny_kernel<TB, MT, (MT > 1 ? 6 : 12)>), grid, block, 0, s, p);
@@ -1210,9 +1211,9 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
   if (t == 3) {
-    // skinny path: M <= 32, A k-contiguous; segment edge on a 16-k chunk boundary
-    if (M > 32 || transA || (A2 && (K1 % 16) != 0)) return DV3_ERR_ARG;
-    if (accumulate == 2 && !transB && !A2 && (N % 64) == 0) {
+    // skinny path: M <= 128 (row blocks of 16 / 32 over grid.z), A k-contiguous; segment edge on a 16-k chunk boundary
+    if (M > 128 || transA || (A2 && (K1 % 16) != 0)) return DV3_ERR_ARG;
+    if (M <= 32 && accumulate == 2 && !transB && !A2 && (N % 64) == 0) {
       if (M <= 16) launch_skinny_nn64<1>(p, s);
       else launch_skinny_nn64<2>(p, s);
     } else if (M <= 16) {

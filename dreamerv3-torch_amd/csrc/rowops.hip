@@ -1106,3 +1106,43 @@ extern "C" int dv3_gru_bwd(const float* dh_new, long lddhn, const float* p, long
                      beta, h, ldh, mean, rstd, dp, lddp, dh, lddh, dgamma, dbeta, M, De, accumulate_dh);
   return (int)hipGetLastError();
 }
+
+// dst = s0 | s1 | ... | s5 (flat, float): the acting step's outputs packed in one launch for a single D2H hop
+struct Concat6 {
+  const float* src[6];
+  long end[6];  // exclusive prefix ends
+};
+__global__ void concat6_kernel(Concat6 c, float* __restrict__ dst) {
+  const long total = c.end[5];
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int k = 0;
+    long base = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (e >= c.end[j]) {
+        k = j + 1;
+        base = c.end[j];
+      }
+    dst[e] = c.src[k][e - base];
+  }
+}
+
+extern "C" int dv3_concat6(const float* s0, long n0, const float* s1, long n1, const float* s2, long n2, const float* s3,
+                           long n3, const float* s4, long n4, const float* s5, long n5, float* dst, void* stream) {
+  const float* src[6] = {s0, s1, s2, s3, s4, s5};
+  const long n[6] = {n0, n1, n2, n3, n4, n5};
+  Concat6 c;
+  long acc = 0;
+  for (int j = 0; j < 6; ++j) {
+    if (n[j] < 0 || (n[j] > 0 && !src[j])) return DV3_ERR_ARG;
+    acc += n[j];
+    c.src[j] = src[j];
+    c.end[j] = acc;
+  }
+  if (acc == 0) return 0;
+  if (!dst) return DV3_ERR_ARG;
+  unsigned blocks = (unsigned)((acc + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(concat6_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c, dst);
+  return (int)hipGetLastError();
+}

@@ -91,7 +91,7 @@ class Dreamer(nn.Module):
         nz = noise or {}
         obs = self._wm.preprocess(obs)
         embed = self._wm.encoder(obs)
-        latent, _ = self._wm.dynamics.obs_step(latent, action, embed, obs["is_first"], noise=nz or None)
+        latent, _ = self._wm.dynamics.obs_step(latent, action, embed, obs["is_first"], noise=nz or None, prior=False)
         if getattr(self._config, "eval_state_mean", False):
             raise NotImplementedError("eval_state_mean needs continuous latents (dyn_discrete: 0)")
         feat = self._wm.dynamics.get_feat(latent)

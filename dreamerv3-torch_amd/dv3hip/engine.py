@@ -532,13 +532,14 @@ class RSSMEngine:
         return wt
 
     def img_step_fwd(self, stoch, deter, action, bufs, *, noise=None, rng=None, sample=True, forced=None,
-                     flips=None, idx=None, idx_out=None, wcat=None):
+                     flips=None, idx=None, idx_out=None, wcat=None, head=True):
         """stoch [M,SD], deter [M,De], action [M,A]; bufs: dict of per-step buffers (see imagine_fwd).
         idx (int32 [M,S]): the class indices of stoch (an exact one-hot): img_in then runs as gather + LayerNorm +
         SiLU in one launch (pack_img_in must have run) instead of GEMM + LN.  idx_out (int32 [M,S]) receives the
         class indices of the sampled successor.  wcat ([Hd + X, De] = img_out weight stacked on other Linears that
         read the new deter, e.g. the actor's first layer): ONE GEMM writes bufs["cat"] [M, Hd + X] whose first Hd
-        columns are bufs["x2pre"] (a view of it) -- the consumers of deter' share its launch."""
+        columns are bufs["x2pre"] (a view of it) -- the consumers of deter' share its launch.
+        head=False stops after the GRU (deter' only): the acting step never reads the prior (dreamer.py:131-134)."""
         P = self.P
         M = stoch.shape[0]
         if idx is not None:
@@ -549,6 +550,8 @@ class RSSMEngine:
             dense_ln_fwd(P.img_in, stoch, action, bufs["x1pre"], bufs["m1"], bufs["r1"], bufs["x1"])
         ops.gemm(bufs["x1"], P.gru.W, bufs["gpre"], A2=deter)
         ops.gru_fwd(bufs["gpre"], P.gru.g, P.gru.b, deter, bufs["deter"], bufs["mg"], bufs["rg"])
+        if not head:
+            return
         fuse_smp = _FUSE_SAMPLE and ops.gemm_sample_ok(M, self.SD, self.D)
         # the img_out LayerNorm + SiLU rides on the operand load of the prior-logit GEMM (x2 is then never stored: the
         # imagination backward needs x2pre and the statistics only)
@@ -634,13 +637,18 @@ class PConvLayer:
     bias: Optional[torch.Tensor] = None  # only the decoder's last layer has a bias
 
 
+# acting path: conv layers with at most this many output pixels (all images) use im2col + GEMM
+_IM2COL_ROWS = int(os.environ.get("DV3_IM2COL_ROWS", "2048"))
+
+
 class ConvEncoderEngine:
     def __init__(self, layers: List[PConvLayer], ws: Workspace, size=64):
         self.L, self.ws, self.size = layers, ws, size
 
-    def forward(self, image_u8=None, perm=None, x_f32=None):
+    def forward(self, image_u8=None, perm=None, x_f32=None, keep=True):
         """image_u8 [B,T,H,W,C] u8 (or x_f32 [N,H,W,C] already = image/255 - 0.5) -> embed [N, E] in the
-        reference's (C,H,W) flatten order; rows time-major when perm=(B,T) (row t*B+b <- image b*T+t)."""
+        reference's (C,H,W) flatten order; rows time-major when perm=(B,T) (row t*B+b <- image b*T+t).
+        keep=False (inference, no backward follows): layers with few output rows go through im2col + GEMM."""
         ws = self.ws
         H = self.size
         if x_f32 is not None:
@@ -656,7 +664,12 @@ class ConvEncoderEngine:
             Co, Ci = L.W.shape[0], L.W.shape[1]
             OH = H // 2
             pre = ws.get(f"enc.pre{i}", (N, OH, OH, Co))
-            if Ci == 3 and Co in ops.C3_WIDTHS:
+            if N * OH * OH <= _IM2COL_ROWS and not keep:
+                # few images (the acting step): explicit patches + a plain GEMM against the weight as stored
+                cols = ws.get(f"enc.cols{i}", (N * OH * OH, 16 * Ci))
+                ops.im2col_s2(x, cols)
+                ops.gemm(cols, L.W.view(Co, 16 * Ci), pre.view(N * OH * OH, Co))
+            elif Ci == 3 and Co in ops.C3_WIDTHS:
                 ops.conv_s2_c3_fwd(x, L.W, pre, CW=Co)
             else:
                 wp = ws.get(f"enc.wp{i}", (Co, 16 * Ci))

@@ -15,6 +15,8 @@ from typing import Dict
 
 import torch
 
+from . import ops
+
 
 class UpdateRunner:
     def __init__(self, wm, beh, use_graph: bool = True, warm: int = 2):
@@ -116,20 +118,26 @@ class PolicyRunner:
             dt = torch.uint8 if (k == "image" and t.dtype == torch.uint8) else torch.float32
             st["obs"][k] = torch.zeros(tuple(t.shape), dtype=dt, device=dev)
             st["pin"][k] = torch.zeros(tuple(t.shape), dtype=dt).pin_memory()
-        st["state"] = {"stoch": torch.zeros(n, S, D, device=dev), "deter": torch.zeros(n, De, device=dev),
-                       "logit": torch.zeros(n, S, D, device=dev)}
-        st["action"] = torch.zeros(n, A, device=dev)
+        # one flat buffer holds the step's outputs [action | logprob | stoch | deter | logit]; the carried state the
+        # graph READS is the same memory (views of the previous step's outputs): when the caller hands back exactly
+        # what the last step returned, nothing has to be copied in (see _load)
         sizes = [n * A, n, n * S * D, n * De, n * S * D]
         st["packed"] = torch.zeros(sum(sizes), device=dev)
         st["sizes"] = sizes
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + sz)
+        pk = st["packed"]
+        st["action"] = pk[offs[0]:offs[1]].view(n, A)
+        st["state"] = {"stoch": pk[offs[2]:offs[3]].view(n, S, D), "deter": pk[offs[3]:offs[4]].view(n, De),
+                       "logit": pk[offs[4]:offs[5]].view(n, S, D)}
+        st["offs"] = offs
 
         def core():
             out, (latent, action) = ag._policy_eager(st["obs"], (st["state"], st["action"]), training)
-            parts = [out["action"], out["logprob"], latent["stoch"], latent["deter"], latent["logit"]]
-            off = 0
-            for p_, sz in zip(parts, sizes):
-                st["packed"][off:off + sz].copy_(p_.reshape(-1))
-                off += sz
+            # every read of the carried state precedes this launch in stream order
+            ops.concat_flat([out["action"], out["logprob"].reshape(-1), latent["stoch"], latent["deter"], latent["logit"]],
+                            st["packed"])
 
         self._load(st, obs, state)
         import tools
@@ -164,11 +172,31 @@ class PolicyRunner:
             # obs_step with prev_state None == every env resets (networks.py:176-180): force is_first
             st["obs"]["is_first"].fill_(1.0)
             st["action"].zero_()
-        else:
+        elif not PolicyRunner._is_last_output(st, state):
             latent, action = state
             for k in ("stoch", "deter", "logit"):
                 st["state"][k].copy_(latent[k], non_blocking=True)
             st["action"].copy_(action, non_blocking=True)
+
+    @staticmethod
+    def _is_last_output(st, state):
+        """True when `state` is, untouched, what the previous step() returned: its tensors are views of the clone of
+        the packed buffer taken then (same storage, no in-place write since), so the packed buffer still holds the
+        same values and the graph can read them where they are."""
+        last = st.get("last")
+        if last is None:
+            return False
+        flat, version = last
+        latent, action = state
+        offs = st["offs"]
+        want = ((action, offs[0]), (latent.get("stoch"), offs[2]), (latent.get("deter"), offs[3]),
+                (latent.get("logit"), offs[4]))
+        for t, off in want:
+            if not isinstance(t, torch.Tensor) or t.dtype != torch.float32 or not t.is_contiguous():
+                return False
+            if t.data_ptr() != flat.data_ptr() + 4 * off or t._version != version:
+                return False
+        return flat._version == version
 
     def step(self, obs, state, training):
         n = len(obs["is_first"])
@@ -180,12 +208,11 @@ class PolicyRunner:
         self._load(st, obs, state)
         st["graph"].replay()
         flat = st["packed"].clone()
+        st["last"] = (flat, flat._version)
         dyn = self.agent._wm.dynamics
         S, D, De, A = dyn._stoch, dyn._discrete, dyn._deter, dyn._num_actions
-        outs, off = [], 0
-        for sz in st["sizes"]:
-            outs.append(flat[off:off + sz])
-            off += sz
-        action, logprob = outs[0].view(n, A), outs[1].view(n)
-        latent = {"stoch": outs[2].view(n, S, D), "deter": outs[3].view(n, De), "logit": outs[4].view(n, S, D)}
+        o = st["offs"]
+        action, logprob = flat[o[0]:o[1]].view(n, A), flat[o[1]:o[2]].view(n)
+        latent = {"stoch": flat[o[2]:o[3]].view(n, S, D), "deter": flat[o[3]:o[4]].view(n, De),
+                  "logit": flat[o[4]:o[5]].view(n, S, D)}
         return {"action": action, "logprob": logprob}, (latent, action)

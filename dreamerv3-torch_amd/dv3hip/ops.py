@@ -206,6 +206,8 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         tile = pick_gemm_tile(M, N, bool(transA), K)
         if M <= 32 and not transA:
             tile = 3
+        if 32 < M <= 128 and tile == 9 and not transA and (A2 is None or K1 % 16 == 0):
+            tile = 3  # few-row kernel over row blocks: 4x the workgroups of the 32 x 64 direct tile (acting-step encoder)
         if tile in (6, 8) and A2 is not None and (K1 % 64) != 0:
             tile = 1
         if tile >= 11 and not l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb):
@@ -222,6 +224,24 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
                + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else "")), flops=2.0 * M * N * K,
           nbytes=4.0 * (M * K + N * K + M * N))
     return C
+
+
+def concat_flat(parts, dst):
+    """dst[flat] = concatenation of up to 6 contiguous float tensors, one launch (the acting step packs its outputs
+    for a single device-to-host hop; dv3hip.graph.PolicyRunner)."""
+    if not 1 <= len(parts) <= 6:
+        raise ValueError("concat_flat takes 1..6 parts")
+    _contig(dst, "dst")
+    args, total = [], 0
+    for t in parts:
+        _contig(t, "part")
+        args += [_ptr(t), t.numel()]
+        total += t.numel()
+    if total != dst.numel():
+        raise ValueError("concat_flat size mismatch")
+    args += [None, 0] * (6 - len(parts))
+    _call("dv3_concat6", *args, _ptr(dst), _stream())
+    return dst
 
 
 def ln_act_fwd(x, gamma, beta, y, mean=None, rstd=None, *, act=True, chw_group=0):
@@ -614,6 +634,18 @@ def pack_conv_weight(w, wp, *, transposed):
         Co, Ci = w.shape[0], w.shape[1]
     _call("dv3_pack_conv_weight", _ptr(w), _ptr(wp), Co, Ci, int(transposed), _stream())
     return wp
+
+
+def im2col_s2(x, cols):
+    """x [N,H,W,C] NHWC -> cols [N*(H/2)*(W/2), 16*C], columns in the Conv2d weight's (ci, ky, kx) order."""
+    _contig(x, "x"), _contig(cols, "cols")
+    if x.dim() != 4 or x.shape[1] % 2 or x.shape[2] % 2:
+        raise ValueError("im2col input must be [N,H,W,C] with even H,W")
+    N, H, W, C = x.shape
+    if cols.numel() != N * (H // 2) * (W // 2) * 16 * C:
+        raise ValueError("im2col output size mismatch")
+    _call("dv3_im2col_s2", _ptr(x), _ptr(cols), N, H, W, C, _stream())
+    return cols
 
 
 def conv_s2_fwd(x, wp, y, *, Ci, Co, accumulate=False):

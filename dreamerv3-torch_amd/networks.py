@@ -172,11 +172,12 @@ class RSSM(nn.Module):
         self._rng().commit()
         return {"stoch": b["stoch"], "deter": b["deter"], "logit": b["logit"]}
 
-    def obs_step(self, prev_state, prev_action, embed, is_first, sample=True, noise=None):
+    def obs_step(self, prev_state, prev_action, embed, is_first, sample=True, noise=None, prior=True):
         """networks.py:174-206 (branch-free reset; no host sync on is_first).
 
         Returns (post, prior).  Unlike the reference this does not write through `prev_action` /
-        `prev_state`: the zeroed action is used internally."""
+        `prev_state`: the zeroed action is used internally.  prior=False (the acting step, which
+        drops the prior: dreamer.py:131-134) skips the prior head and returns (post, None)."""
         p = self.params()
         B = embed.shape[0]
         dev = embed.device
@@ -196,8 +197,8 @@ class RSSM(nn.Module):
             ops.reset_blend(prev_action.to(torch.float32).contiguous(), None, first, ain)
         nz = noise or {}
         b = self._step_bufs(B, dev)
-        self.engine.img_step_fwd(sin, din, ain, b, noise=nz.get("prior"), rng=self._rng(), sample=sample)
-        prior = {"stoch": b["stoch"], "deter": b["deter"], "logit": b["logit"]}
+        self.engine.img_step_fwd(sin, din, ain, b, noise=nz.get("prior"), rng=self._rng(), sample=sample, head=prior)
+        prior = {"stoch": b["stoch"], "deter": b["deter"], "logit": b["logit"]} if prior else None
         x3pre, x3 = torch.empty(B, Hd, device=dev), torch.empty(B, Hd, device=dev)
         E.dense_ln_fwd(p.obs_out, b["deter"], embed.contiguous(), x3pre, None, None, x3)
         logit = torch.empty(B, S, D, device=dev)
@@ -399,7 +400,7 @@ class ConvEncoder(nn.Module):
         """obs f32 in [0,1], [..., H, W, C] (networks.py:486-496) -> [..., outdim]."""
         lead = obs.shape[:-3]
         x = (obs.to(torch.float32) - 0.5).reshape((-1,) + tuple(obs.shape[-3:])).contiguous()
-        emb = self.engine.forward(x_f32=x)
+        emb = self.engine.forward(x_f32=x, keep=False)
         return emb.reshape(tuple(lead) + (emb.shape[-1],)).clone()
 
 

@@ -169,6 +169,10 @@ int dv3_mse_image(const float* recon, const unsigned char* image_u8, float* loss
  * dv3_colsum: out[N] (+)= sum over rows of x[R,N] (bias gradients of the stat/head Linears).
  * dv3_tanh_*: RSSM.initial's deter = tanh(W) (networks.py:121) and its backward (from y = tanh x). */
 int dv3_transpose01(const float* x, float* y, int B, int T, int k, void* stream);
+/* dv3_concat6: dst = s0 | s1 | ... | s5 (flat; n_j elements each, n_j = 0 skips): the acting step's outputs
+ * (action, logprob, stoch, deter, logit: dreamer.py:183-188) packed in one launch for a single device-to-host hop. */
+int dv3_concat6(const float* s0, long n0, const float* s1, long n1, const float* s2, long n2, const float* s3, long n3,
+                const float* s4, long n4, const float* s5, long n5, float* dst, void* stream);
 int dv3_colsum(const float* x, long ldx, float* out, long R, int N, int accumulate, void* stream);
 int dv3_tanh_fwd(const float* x, float* y, long n, void* stream);
 int dv3_tanh_bwd(const float* y, const float* dy, float* dx, long n, int accumulate, void* stream);
@@ -184,6 +188,14 @@ int dv3_tanh_bwd(const float* y, const float* dy, float* dx, long n, int accumul
  * dv3_conv_s2_wgrad: dw[Ccoarse][Cfine][4][4] += sum coarse[m,:]^T (x) gather(fine)  -- the weight gradient of
  *   either op (conv: coarse=dY, fine=x; convT: coarse=layer input, fine=dOut), in the reference layout. */
 int dv3_pack_conv_weight(const float* w, float* w_packed, int Co, int Ci, int transposed, void* stream);
+
+/*
+ * dv3_im2col_s2: cols [Nimg*(H/2)*(W/2)][16*C] = the 4x4 stride-2 "same"-padded patches of x [Nimg][H][W][C] (NHWC),
+ * column order (ci, ky, kx) = the Conv2d weight's own [Co][Ci][4][4] order, so the convolution of a few images is
+ * y = cols * W.view(Co, 16 C)^T through dv3_gemm_f32 (ConvEncoder on the acting path, networks.py:398-440,
+ * 771-798; dreamer.py:116-188).
+ */
+int dv3_im2col_s2(const float* x, float* cols, int Nimg, int H, int W, int C, void* stream);
 int dv3_conv_s2_fwd(const float* x, const float* w_packed, float* y, int Nimg, int H, int W, int Ci, int Co,
                     int accumulate, void* stream);
 int dv3_convT_s2_fwd(const float* x, const float* w_packed, const float* bias, float out_add, float* y, int Nimg,

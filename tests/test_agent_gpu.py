@@ -183,6 +183,33 @@ def test_policy_graph_replay_equals_eager(name, n_envs):
         assert torch.allclose(a0, a1, atol=1e-6) and torch.allclose(l0, l1, atol=1e-5)
 
 
+def test_policy_graph_sees_a_state_the_caller_rewrote():
+    """PolicyRunner keeps the carried state where the previous replay left it and skips the copy-in when the caller
+    hands back exactly what it was given; a state edited in place (or any other tensors) must be copied in."""
+    import tools
+
+    agent, _ = _load_agent("tiny")
+    rs = np.random.RandomState(3)
+    mk = lambda first: {"image": rs.randint(0, 256, (2, 64, 64, 3)).astype(np.uint8),
+                        "is_first": np.full(2, first, bool), "is_terminal": np.zeros(2, bool)}
+    o0, o1, o2 = mk(True), mk(False), mk(False)
+    tools.default_rng(agent._config.device, seed=4)
+    _, state = agent._policy(o0, None, True)
+    _, state = agent._policy(o1, state, True)  # untouched hand-back: no copy
+    runner = agent._policy_runner
+    st = next(iter(runner._sig.values()))
+    assert runner._is_last_output(st, state)
+    state[0]["deter"].mul_(0.5)  # in place: same storage, new version
+    assert not runner._is_last_output(st, state)
+    edited = ({k: v.clone() for k, v in state[0].items()}, state[1].clone())
+    saved = tools.default_rng(agent._config.device).state.clone()
+    out_g, _ = agent._policy(o2, state, True)
+    tools.default_rng(agent._config.device).state.copy_(saved)
+    out_e, _ = agent._policy_eager(o2, edited, True)
+    assert torch.allclose(out_g["action"], out_e["action"], atol=1e-6)
+    assert torch.allclose(out_g["logprob"], out_e["logprob"], atol=1e-5)
+
+
 @pytest.mark.parametrize("name", ["tiny", "cfg2"])
 def test_video_pred_matches_reference_golden(name):
     """WorldModel.video_pred (models.py:192-213) on the GPU path, same weights / batch / noise,

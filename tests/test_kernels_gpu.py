@@ -907,6 +907,24 @@ def test_gemm_with_sampling_epilogue_equals_gemm_then_sample(ops, M, N, K, mode)
         assert int(flips.item()) == int((i0 != forced).sum())
 
 
+@pytest.mark.parametrize("N,H,Ci,Co", [(1, 64, 3, 32), (1, 32, 32, 64), (2, 8, 128, 256), (16, 16, 64, 128), (3, 4, 5, 7)])
+def test_im2col_then_gemm_is_the_same_pad_stride2_conv(ops, N, H, Ci, Co):
+    """Few-image encoder path (acting step): dv3_im2col_s2 + dv3_gemm_f32 against the weight as stored ==
+    Conv2dSamePad k4 s2 (networks.py:771-798: pad 1 before, 1 after for even sizes)."""
+    g = torch.Generator().manual_seed(N + H + Ci + Co)
+    x = torch.randn(N, H, H, Ci, generator=g)
+    w = torch.randn(Co, Ci, 4, 4, generator=g) / math.sqrt(16 * Ci)
+    OH = H // 2
+    cols = torch.empty(N * OH * OH, 16 * Ci, device="cuda")
+    ops.im2col_s2(dev(x), cols)
+    ref_cols = F.unfold(F.pad(x.permute(0, 3, 1, 2), (1, 1, 1, 1)), kernel_size=4, stride=2)  # [N, Ci*16, OH*OH]
+    assert torch.equal(cols.cpu(), ref_cols.transpose(1, 2).reshape(N * OH * OH, 16 * Ci))
+    y = torch.empty(N * OH * OH, Co, device="cuda")
+    ops.gemm(cols, dev(w).view(Co, 16 * Ci), y)
+    ref = F.conv2d(F.pad(x.permute(0, 3, 1, 2), (1, 1, 1, 1)), w, stride=2).permute(0, 2, 3, 1)
+    assert_close(y.view(N, OH, OH, Co), ref, tol=2e-5, what="conv via im2col")
+
+
 @pytest.mark.parametrize("n", [14336, 7, 1, 2, 1000, 458752])
 def test_quantile_ema_matches_torch_quantile(ops, n):
     """models.RewardEMA (models.py:11-26): exact radix-selected 5 % / 95 % quantiles + EMA == torch.quantile + axpby."""
