@@ -30,6 +30,12 @@ struct GemmParams {
   int vecA, vecB;
   int tiles_m, tiles_n;
   int splits, kchunk;  // split-K over workgroups (accumulating GEMMs only: partial sums land with atomics)
+  // l16 kernel: output columns >= nsplit go to C2[row * ldc2 + (col - nsplit)] with their own accumulate flag
+  // (one product feeding two destinations: the GRU matmul's data gradient = [dx | dh])
+  float* C2;
+  long ldc2;
+  int nsplit, accumulate2;
+  int xcd_m, xcd_n;    // direct / l16 kernels: the 8 XCDs as an xcd_m x xcd_n grid of tile blocks (0: linear order)
   int transC;          // skinny kernel only: store C[col*ldc + row] and index bias by row
   // direct kernel, EPI = 1: C holds the logits of N/32 categorical groups of 32 classes per row; each group is
   // sampled in the epilogue (tools.OneHotDist.sample, tools.py:452-460; same draws as dv3_onehot_sample_fwd)
@@ -233,6 +239,39 @@ __global__ __launch_bounds__(64 * kSkinnyWaves) void gemm_skinny_kernel(GemmPara
   }
 }
 
+// XCD-aware tile order for the 1-D grids of the direct / l16 kernels.  Workgroup ids go round-robin to the 8 XCDs,
+// each with a private L2 that pulls its own copy of every operand panel its workgroups touch: with the XCDs laid
+// out as an xcd_m x xcd_n grid of tile blocks, the fabric sees the A panel xcd_n times and the B panel xcd_m times.
+// The host picks the factorisation of 8 that minimises bytes(A) * xcd_n + bytes(B) * xcd_m among those that divide
+// the tile counts (pick_xcd_grid); e.g. 1024 x 1536 x 1024: 2 x 4 -> 28 MB, against 52 MB for row strips (8 x 1).
+__device__ __forceinline__ void xcd_tile(const GemmParams& p, int id, int& tm, int& tn) {
+  if (p.xcd_m > 0) {
+    const int xcd = id & 7, loc = id >> 3;
+    const int bm = p.tiles_m / p.xcd_m, bn = p.tiles_n / p.xcd_n;
+    tm = (xcd / p.xcd_n) * bm + loc / bn;
+    tn = (xcd % p.xcd_n) * bn + loc % bn;
+  } else {
+    tm = id / p.tiles_n;
+    tn = id % p.tiles_n;
+  }
+}
+
+static void pick_xcd_grid(GemmParams& p) {
+  p.xcd_m = p.xcd_n = 0;
+  const double a = (double)p.M * p.K, b = (double)p.N * p.K;
+  double best = 0.0;
+  for (int xm = 8; xm >= 1; xm >>= 1) {
+    const int xn = 8 / xm;
+    if (p.tiles_m % xm || p.tiles_n % xn) continue;
+    const double cost = a * xn + b * xm;
+    if (p.xcd_m == 0 || cost < best) {
+      best = cost;
+      p.xcd_m = xm;
+      p.xcd_n = xn;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Register-direct GEMM for mid-size outputs (the 1024 imagination rows x 512..1536 columns): the same
 // no-LDS scheme as the few-row kernel, tiled over M.  A workgroup owns 32 rows x 16*RN columns; its waves split
@@ -252,17 +291,8 @@ __global__ __launch_bounds__(512) void gemm_direct_kernel(GemmParams p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int nwaves = blockDim.x >> 6;
   const int i = lane & 15, q = lane >> 4;
-  // 1-D grid of tiles_m x tiles_n workgroups.  Workgroups go to the 8 XCDs round-robin and each XCD's L2 pulls
-  // its own copy of every panel its workgroups touch, so an XCD is given whole ROW tiles (tiles_m / 8 of them, all
-  // column tiles): its A rows are private and only B is replicated, instead of every XCD streaming all of A.
   int tm, tn;
-  {
-    const int id = blockIdx.x, tiles = p.tiles_m * p.tiles_n;
-    int lin = id;
-    if ((p.tiles_m & 7) == 0) lin = (id & 7) * (tiles >> 3) + (id >> 3);
-    tm = lin / p.tiles_n;
-    tn = lin % p.tiles_n;
-  }
+  xcd_tile(p, blockIdx.x, tm, tn);  // XCD-aware order of the tiles_m x tiles_n tiles (see xcd_tile)
   const int n0 = tn * (16 * RN), m0 = tm * 32;
   const int chunks = (p.K + 15) >> 4;
   const int per = (chunks + nwaves - 1) / nwaves;
@@ -553,6 +583,7 @@ static void launch_direct_rn(const GemmParams& p0, int waves, hipStream_t s) {
   GemmParams p = p0;
   p.tiles_n = (p.N + 16 * RN - 1) / (16 * RN);
   p.tiles_m = (p.M + 31) / 32;
+  pick_xcd_grid(p);
   const dim3 grid(p.tiles_m * p.tiles_n), block(64 * waves);
   const size_t sh = (size_t)waves * 2 * RN * 256 * sizeof(float);
   // one chunk of lookahead (BATCH 1) measured best: ~100 VGPRs keep 4 waves per SIMD resident, which hides more
@@ -603,8 +634,7 @@ static void launch_direct(const GemmParams& p, hipStream_t s) {
 // ds_write_b128 group write 128 contiguous bytes.  One workgroup = 4 waves (2 x 2) = one BM x BN tile, BK = 32,
 // double-buffered: global loads of K-tile t+1 are issued before the MFMAs of tile t, one barrier per K-tile.
 // The tile is chosen so that M/BM * N/BN = 256 workgroups = one per CU (1024 x 1536: 64 x 96; 1024 x 1024: 64 x 64;
-// 1024 x 512: 32 x 64).  XCD-aware 2-D mapping: each XCD owns a (tiles_m/4) x (tiles_n/2) block of tiles, so its L2
-// holds a quarter of A and half of B instead of streaming one operand whole.
+// 1024 x 512: 32 x 64).  Tile order: xcd_tile (each XCD owns a block of tiles chosen by operand bytes).
 // Requires K % 32 == 0, K1 % 32 == 0, lda/lda2/ldb % 4 == 0 (checked by the launcher).
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int PF, int EPI = 0>
@@ -619,18 +649,7 @@ __global__ __launch_bounds__(256) void gemm_l16_kernel(GemmParams p) {
   const int i = lane & 15, q = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn;
-  {
-    const int id = blockIdx.x;
-    if ((p.tiles_m & 3) == 0 && (p.tiles_n & 1) == 0) {
-      const int xcd = id & 7, loc = id >> 3;
-      const int bm = p.tiles_m >> 2, bn = p.tiles_n >> 1;
-      tm = (xcd >> 1) * bm + loc / bn;
-      tn = (xcd & 1) * bn + loc % bn;
-    } else {
-      tm = id / p.tiles_n;
-      tn = id % p.tiles_n;
-    }
-  }
+  xcd_tile(p, blockIdx.x, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   // staging: float4 f = tid + 256 j of a [rows][8] grid -> row f >> 3, k offset 4 (f & 7).  Rows past the edge of
   // the matrix read row 0 instead: they only feed outputs past the edge, which the epilogue does not store (no
@@ -818,13 +837,17 @@ __global__ __launch_bounds__(256) void gemm_l16_kernel(GemmParams p) {
       const int col = n0 + wn * (BN / 2) + 16 * b + i;
       if (col >= p.N) continue;
       const float bv = p.bias ? p.bias[col] : 0.f;
+      const bool second = p.C2 && col >= p.nsplit;
+      float* const cbase = second ? p.C2 + (col - p.nsplit) : p.C + col;
+      const long ldo = second ? p.ldc2 : p.ldc;
+      const int accf = second ? p.accumulate2 : p.accumulate;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * (BM / 2) + 16 * a + 4 * q + r;
         if (row < p.M) {
-          float* o = p.C + (long)row * p.ldc + col;
+          float* o = cbase + (long)row * ldo;
           float v = acc[a][b][r] + bv;
-          if (p.accumulate) v += *o;
+          if (accf) v += *o;
           *o = v;
         }
       }
@@ -836,6 +859,7 @@ static void launch_l16_sample(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
   p.tiles_m = (p.M + 31) / 32;
   p.tiles_n = (p.N + 63) / 64;
+  pick_xcd_grid(p);
   hipLaunchKernelGGL((gemm_l16_kernel<32, 64, 1, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
 }
 
@@ -856,6 +880,7 @@ static void launch_l16(const GemmParams& p0, int force, hipStream_t s) {
   const int bm = sel == 3 ? 32 : 64, bn = sel == 1 ? 96 : 64;
   p.tiles_m = (p.M + bm - 1) / bm;
   p.tiles_n = (p.N + bn - 1) / bn;
+  pick_xcd_grid(p);
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
   static const int pf = getenv("DV3_L16_PF") ? atoi(getenv("DV3_L16_PF")) : 1;
 #define DV3_L16_LAUNCH(PFV)                                                                     \
@@ -1286,5 +1311,23 @@ extern "C" int dv3_gemm_sample_f32(int M, int N, int K, const float* A, long lda
   }
   const int chunks = (K + 15) / 16;
   launch_direct_rn<true, 4>(p, chunks >= 32 ? 8 : 4, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
+
+// y = A W^T (dv3_gemm_f32 transA = 0, transB = 1, k-contiguous LDS tile kernel) with the output columns split over two
+// destinations: columns [0, nsplit) -> C (ldc, accumulate), columns [nsplit, N) -> C2 (ldc2, accumulate2).
+extern "C" int dv3_gemm_split_f32(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
+                                  long ldc, int accumulate, float* C2, long ldc2, int nsplit, int accumulate2,
+                                  void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (K <= 0 || !A || !B || !C || !C2 || nsplit <= 0 || nsplit >= N || (nsplit % 16) != 0) return DV3_ERR_ARG;
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C;
+  p.M = M; p.N = N; p.K = K; p.K1 = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.accumulate = accumulate ? 1 : 0;
+  p.C2 = C2; p.ldc2 = ldc2; p.nsplit = nsplit; p.accumulate2 = accumulate2 ? 1 : 0;
+  if (!l16_ok(p, 0, 1)) return DV3_ERR_ARG;
+  launch_l16(p, 0, (hipStream_t)stream);
   return (int)hipGetLastError();
 }

@@ -603,8 +603,12 @@ class RSSMEngine:
             ops.gemm(scratch["dx2pre"], wt["out"], ddeter, accumulate=True)
             ops.gru_bwd(ddeter, bufs["gpre"], P.gru.g, P.gru.b, prev_deter, bufs["mg"], bufs["rg"], scratch["dgpre"],
                         dprev_deter, accumulate_dh=accumulate_prev)
-            ops.gemm(scratch["dgpre"], wt["gru"][Hd:], dprev_deter, accumulate=True)
-            ops.gemm(scratch["dgpre"], wt["gru"][:Hd], scratch["dx1"])
+            if M > 128 and ops.gemm_split_ok(scratch["dgpre"], wt["gru"]):
+                # [dx1 | dh] = dgpre W_gru in one launch, dh accumulating onto the direct path gru_bwd just wrote
+                ops.gemm_split(scratch["dgpre"], wt["gru"], scratch["dx1"], dprev_deter, accumulate2=True)
+            else:
+                ops.gemm(scratch["dgpre"], wt["gru"][Hd:], dprev_deter, accumulate=True)
+                ops.gemm(scratch["dgpre"], wt["gru"][:Hd], scratch["dx1"])
             dense_ln_bwd_pre(P.img_in, scratch["dx1"], bufs["x1pre"], bufs["m1"], bufs["r1"], scratch["dx1pre"],
                              wgrad=False)
             ops.gemm(scratch["dx1pre"], wt["in"][:SD], dprev_stoch, accumulate=accumulate_prev)

@@ -244,6 +244,29 @@ def concat_flat(parts, dst):
     return dst
 
 
+def gemm_split_ok(A, B) -> bool:
+    """Preconditions of ops.gemm_split (the k-contiguous LDS tile kernel)."""
+    if A.dim() != 2 or B.dim() != 2 or A.stride(1) != 1 or B.stride(1) != 1:
+        return False
+    K = A.shape[1]
+    return l16_ok(A, None, B, False, True, K, K, A.stride(0), 0, B.stride(0))
+
+
+def gemm_split(A, B, C, C2, *, accumulate=False, accumulate2=False):
+    """[C | C2] (+)= A @ B^T: the first C.shape[1] output columns go to C, the rest to C2, each with its own
+    accumulate flag (one launch for two destinations)."""
+    M, K, lda = _rows2d(A, "A")
+    N, Kb, ldb = _rows2d(B, "B")
+    M1, n1, ldc = _rows2d(C, "C")
+    M2, n2, ldc2 = _rows2d(C2, "C2")
+    if Kb != K or M1 != M or M2 != M or n1 + n2 != N or n1 % 16:
+        raise ValueError("gemm_split shapes mismatch")
+    _call("dv3_gemm_split_f32", M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(C), ldc, int(bool(accumulate)), _ptr(C2),
+          ldc2, n1, int(bool(accumulate2)), _stream(),
+          key="gemm_kernel<l16,tA=0,tB=1>" + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else ""), flops=2.0 * M * N * K,
+          nbytes=4.0 * (M * K + N * K + M * N))
+
+
 def ln_act_fwd(x, gamma, beta, y, mean=None, rstd=None, *, act=True, chw_group=0):
     R, N, ldx = _rows2d(x, "x")
     _contig(gamma, "gamma"), _contig(beta, "beta")

@@ -52,6 +52,13 @@ int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, lo
                  long lda2, int K1, const float* B, long ldb, float* C, long ldc, const float* bias,
                  int accumulate, int tile, void* stream);
 
+/* y = A B^T (A [M,K], B [N,K], both k-contiguous; K % 32 == 0, 16-byte aligned rows) with the output columns split
+ * over two destinations: [0, nsplit) -> C (ldc, accumulate), [nsplit, N) -> C2 (ldc2, accumulate2); nsplit % 16 == 0.
+ * One launch for the two data gradients of GRUCell's Linear over cat([x, h]) (networks.py:760-763): B = W^T,
+ * C = dx, C2 = dh (accumulating into the gradient the successor state already carries). */
+int dv3_gemm_split_f32(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                       int accumulate, float* C2, long ldc2, int nsplit, int accumulate2, void* stream);
+
 /* dv3_gemm_f32 (transA=0, transB=1, register-direct kernel) with the one-hot categorical sampling of its output fused
  * into the epilogue: C [M,N] = the logits of N/32 groups of 32 classes per row (N % 64 == 0), sampled exactly as
  * dv3_onehot_sample_fwd_ex would (same noise layout [M*N/32, 32], same Philox counters).  Replaces

@@ -140,6 +140,22 @@ def test_gemm_kcontiguous_lds_tile(ops, M, N, K1, K2, acc, tile):
     assert_close(C, want, what=f"gemm tile {tile}")
 
 
+@pytest.mark.parametrize("M,n1,n2,K", [(1024, 512, 512, 1536), (200, 48, 80, 64), (77, 16, 100, 96)])
+def test_gemm_split_output(ops, M, n1, n2, K):
+    """dv3_gemm_split_f32: one product, columns [0, n1) overwrite C, columns [n1, n1+n2) accumulate into a strided C2."""
+    g = torch.Generator().manual_seed(M + n1 + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(n1 + n2, K, generator=g) / math.sqrt(K)
+    C = torch.full((M, n1), float("nan")).cuda()
+    wide0 = torch.randn(M, n2 + 8, generator=g)
+    wide = dev(wide0.clone())
+    assert ops.gemm_split_ok(dev(A), dev(W))
+    ops.gemm_split(dev(A), dev(W), C, wide[:, 8:], accumulate2=True)
+    ref = A @ W.t()
+    assert_close(C, ref[:, :n1], what="first block")
+    assert_close(wide[:, 8:], wide0[:, 8:] + ref[:, n1:], what="second block (accumulated)")
+    assert torch.equal(wide[:, :8].cpu(), wide0[:, :8])
+
+
 @pytest.mark.parametrize("rows,Nout,Kin", [(1024, 512, 1030), (1024, 1536, 1024), (333, 70, 45), (14336, 255, 512)])
 def test_gemm_tn_wgrad_accumulate(ops, rows, Nout, Kin):
     g = torch.Generator().manual_seed(2)

@@ -1,5 +1,6 @@
 #!/bin/bash
-mkdir -p gpurun_out/r02v
-timeout -k 10 400 python -m pytest tests/test_kernels_gpu.py tests/test_agent_gpu.py tests/test_api_gpu.py -q -m gpu > gpurun_out/r02v/t.log 2>&1; tail -5 gpurun_out/r02v/t.log
-timeout -k 10 300 python tools/_policy_probe.py 2>&1 | grep -v amdgpu.ids | grep "E="
-timeout -k 10 300 python tools/policy_bench.py 2>&1 | grep -v amdgpu.ids
+mkdir -p gpurun_out/r02w
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py tests/test_path_gpu.py tests/test_fullsize_gpu.py -q -m gpu -x > gpurun_out/r02w/t.log 2>&1; tail -4 gpurun_out/r02w/t.log
+timeout -k 10 300 python tools/imag_bench.py 2>&1 | grep -v amdgpu.ids | head -3
+timeout -k 10 300 python bench.py > gpurun_out/r02w/bench.log 2>&1 || exit 1
+tail -1 gpurun_out/r02w/bench.log | cut -c1-200

@@ -77,6 +77,15 @@ def main():
     for k, v in rows[:24]:
         print(f"  {v['ms']:8.3f} ms  n={v['launches']:4d}  {v['ms'] * 1e3 / v['launches']:7.1f} us/launch  "
               f"{v['flops'] / max(v['ms'], 1e-9) / 1e9:7.1f} TF/s  {k}")
+    if "--beh" in sys.argv:  # the whole behaviour update (imagine + returns + losses + backward + Adam), eager-timed
+        ops.PROFILE.start()
+        behaviour()
+        pb = ops.PROFILE.stop()
+        tot = sum(v["ms"] for v in pb.values())
+        print(f"behaviour update, per kernel (eager event times, sum {tot:.2f} ms, {sum(v['launches'] for v in pb.values())} launches):")
+        for k, v in sorted(pb.items(), key=lambda kv: -kv[1]["ms"])[:40]:
+            print(f"  {v['ms']:8.3f} ms  n={v['launches']:4d}  {v['ms'] * 1e3 / v['launches']:7.1f} us/launch  "
+                  f"{v['flops'] / max(v['ms'], 1e-9) / 1e9:7.1f} TF/s  {k}")
     if out_json:
         json.dump({"config": name, "T_img_ms": t_img, "T_beh_ms": t_beh, "launches": n_launch,
                    "gflop_dense_equivalent": gflop, "gflop_mfma": mfma,
