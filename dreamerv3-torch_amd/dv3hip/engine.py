@@ -50,7 +50,7 @@ class SideStream:
     # Measured on MI355X at cfg 2 (r01): OFF is faster (27.7 vs 29.8 ms/update).  The heavy side kernels
     # (conv wgrads) take every CU and each of the ~640 latency-critical scan launches then queues behind
     # them.  Kept as a switch: it needs a CU-masked side stream to pay.
-    enabled = False
+    enabled = os.environ.get("DV3_SIDE_STREAM", "0") != "0"
     _streams: Dict[str, "torch.cuda.Stream"] = {}
 
     def __init__(self, device):

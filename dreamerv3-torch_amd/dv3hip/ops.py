@@ -117,9 +117,9 @@ def kernel_symbol(key: str) -> str:
         if tile == 10:
             return "void dv3::gemm_direct_tn_kernel<4, 1>(dv3::GemmParams)"
         if tile >= 11:
-            return {12: "void dv3::gemm_l16_kernel<64, 96, 1>(dv3::GemmParams)",
-                    13: "void dv3::gemm_l16_kernel<64, 64, 1>(dv3::GemmParams)"}.get(
-                        tile, "void dv3::gemm_l16_kernel<32, 64, 1>(dv3::GemmParams)")
+            return {12: "void dv3::gemm_l16_kernel<64, 96, 1, 0>(dv3::GemmParams)",
+                    13: "void dv3::gemm_l16_kernel<64, 64, 1, 0>(dv3::GemmParams)"}.get(
+                        tile, "void dv3::gemm_l16_kernel<32, 64, 1, 0>(dv3::GemmParams)")
         return f"void dv3::gemm_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, {ta}, {tb}>(dv3::GemmParams)"
     m = re.match(r"conv_wgrad_kernel<([^,>]+)(,c3)?>", key)
     if m:

@@ -4,7 +4,10 @@ TAG=${1:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline"
+CMD="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline"
+# counter passes run for minutes without output: keep gpurun's silence watchdog fed
+( while true; do date >> $OUT/heartbeat.log; sleep 45; done ) &
+HB=$!
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace_bench.json 2> $OUT/trace.err
 echo "trace rc=$?"
 timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
@@ -24,3 +27,4 @@ cp $ST $OUT/kernel_stats.csv
 # the raw counter CSVs are large: keep only the summaries
 rm -rf $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write
 find $OUT/trace -name "*.csv" ! -name "*kernel_stats.csv" -delete
+kill $HB
