@@ -873,6 +873,152 @@ extern "C" int dv3_pack_conv_weight(const float* w, float* wp, int Co, int Ci, i
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_s2 as an implicit GEMM on the k-contiguous LDS tile scheme of gemm_l16_kernel (gemm.hip): M = output pixels,
+// N = Co, K = (ky, kx, ci).  With Ci % 32 == 0 a 32-wide K-tile is 32 consecutive channels of ONE tap, i.e. 128
+// contiguous bytes of the NHWC input per output pixel: the A staging is the dense loader with a per-tile row pointer
+// (tap offset, zero for padding taps) and both operands sit k-contiguous in LDS (stride 40 floats), so an MFMA
+// fragment for four k-steps is one ds_read_b128 -- against the k-major image of the 32x32x2 tile engine above that is
+// a quarter of the LDS instructions and no transposing ds_write_b32.  4 waves (2 x 2), v_mfma_f32_16x16x4_f32,
+// double-buffered LDS, global loads of tile t+1 in flight during the MFMAs of tile t; padding is zeroed when the
+// tile is written to LDS (not when it is loaded: that would make the wave wait for its own prefetch).
+// ------------------------------------------------------------------------------------------------
+// TR = false: conv_s2 (rows = output pixels, K = 16 Ci, taps (ky, kx), input at (2oy-1+ky, 2ox-1+kx)).
+// TR = true : convT_s2, one parity class (py, px) = blockIdx.y per grid row (rows = INPUT pixels (y, x), K = 4 Ci, taps
+//             (a, b), input at (y+py-a, x+px-b), weights wp[cls][Co][4 Ci], output pixel (2y+py, 2x+px); + bias, + out_add).
+template <int BM, int BN, bool TR>
+__global__ __launch_bounds__(256) void conv_s2_l16_kernel(ConvParams p) {
+  constexpr int BK = 32, LD = 40;
+  constexpr int WM = 2, WN = 2;                // waves: 2 x 2
+  constexpr int TM = BM / 32, TN = BN / 32;    // 16 x 16 blocks per wave
+  constexpr int NA = BM * (BK / 4) / 256, NB = BN * (BK / 4) / 256;
+  static_assert(BM % 32 == 0 && BN % 32 == 0 && NA >= 1 && NB >= 1, "tile");
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  static_assert(WM * WN == 4, "four waves");
+  const int cls = TR ? blockIdx.y : 0, py = cls >> 1, px = cls & 1;
+  const int RH = TR ? p.H : (p.H >> 1), RW = TR ? p.W : (p.W >> 1);  // the grid of pixels the rows enumerate
+  const long M = (long)p.Nimg * RH * RW;
+  const int K = (TR ? 4 : 16) * p.Ci;
+  // an XCD owns a contiguous range of pixel tiles (its share of x is private to its L2; the weights are small)
+  int lin = blockIdx.x;
+  {
+    const int tiles = p.tiles_m * p.tiles_n;
+    if ((p.tiles_m & 7) == 0) lin = (blockIdx.x & 7) * (tiles >> 3) + (blockIdx.x >> 3);
+  }
+  const int tm = lin / p.tiles_n, tn = lin % p.tiles_n;
+  const long m0 = (long)tm * BM;
+  const int n0 = tn * BN;
+  const int c4 = (tid & 7) * 4;
+  const float* abase[NA];
+  int iy0[NA], ix0[NA];
+  bool rowok[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const long m = m0 + ((tid + 256 * j) >> 3);
+    rowok[j] = m < M;
+    const long mm = rowok[j] ? m : 0;
+    const int rx = (int)(mm % RW);
+    const long t = mm / RW;
+    const int ry = (int)(t % RH);
+    const long n = t / RH;
+    iy0[j] = TR ? ry + py : 2 * ry - 1;
+    ix0[j] = TR ? rx + px : 2 * rx - 1;
+    abase[j] = p.x + n * p.H * p.W * p.Ci + c4;
+  }
+  const float* bsrc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int col = n0 + ((tid + 256 * j) >> 3);
+    bsrc[j] = p.wp + (long)cls * p.Co * K + (long)(col < p.Co ? col : 0) * K + c4;
+  }
+  f32x4 ra[NA], rb[NB];
+  bool aok[NA];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto gload = [&](int k0) {
+    const int tap = k0 / p.Ci, ci0 = k0 - tap * p.Ci;
+    const int ty = TR ? -(tap >> 1) : (tap >> 2), tx = TR ? -(tap & 1) : (tap & 3);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int iy = iy0[j] + ty, ix = ix0[j] + tx;
+      aok[j] = rowok[j] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const float* src = aok[j] ? abase[j] + ((long)iy * p.W + ix) * p.Ci + ci0 : p.x;
+      ra[j] = *reinterpret_cast<const f32x4*>(src);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bsrc[j] + k0);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      *reinterpret_cast<f32x4*>(&As[buf][((tid + 256 * j) >> 3) * LD + c4]) = aok[j] ? ra[j] : zero4;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(&Bs[buf][((tid + 256 * j) >> 3) * LD + c4]) = rb[j];
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = zero4;
+  const int nk = K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int aoff = (wm * (16 * TM) + i) * LD + 4 * q;
+  const int boff = (wn * (16 * TN) + i) * LD + 4 * q;
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nk) gload((t + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const f32x4*>(&As[cur][aoff + 16 * a * LD + 16 * kk]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&Bs[cur][boff + 16 * b * LD + 16 * kk]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][g], bf[b][g], acc[a][b], 0, 0, 0);
+    }
+    if (t + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + wn * (16 * TN) + 16 * b + i;
+      if (col >= p.Co) continue;
+      const float add = TR ? (p.bias ? p.bias[col] : 0.f) + p.out_add : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * (16 * TM) + 16 * a + 4 * q + r;
+        if (row < M) {
+          float* o;
+          if (TR) {
+            const int x2 = (int)(row % p.W);
+            const long t = row / p.W;
+            const int y2 = (int)(t % p.H);
+            const long img = t / p.H;
+            o = p.y + ((img * (2 * p.H) + 2 * y2 + py) * (2L * p.W) + 2 * x2 + px) * p.Co + col;
+          } else {
+            o = p.y + row * p.Co + col;
+          }
+          float v = acc[a][b][r] + add;
+          if (p.accumulate) v += *o;
+          *o = v;
+        }
+      }
+    }
+}
+
 // Explicit im2col of Conv2d k4 s2 "same" (networks.py:771-798) for few-image batches -- the acting step (SURVEY
 // 8(f) N1) runs the encoder on 1-16 images, where the tiled implicit-GEMM kernels have 1-16 workgroups walking the
 // whole reduction (30-77 us per layer at one image); cols [N*OH*OW][(ci,ky,kx)] is in the reference weight's own
@@ -921,6 +1067,19 @@ extern "C" int dv3_conv_s2_fwd(const float* x, const float* w_packed, float* y, 
   // 128x128 tiles need more than one workgroup per CU to pay for themselves: the deepest encoder layer
   // (16k rows x 256 channels = 256 such tiles) runs 14 % faster on 64x64 tiles (1024 workgroups)
   const long tiles128 = ((M + 127) / 128) * ((Co + 127) / 128);
+  // measured (tools/conv_bench.py, 1024 frames, us): 32->64 213 -> 193, 64->128 196 -> 163, 128->256 207 -> 159 against
+  // the k-major 32x32x2 tiles / the register-direct kernel
+  static const int env_l16 = getenv("DV3_CONV_L16") ? atoi(getenv("DV3_CONV_L16")) : 1;
+  if (env_l16 && (Ci % 32) == 0 && Co >= 64 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0) {
+    const bool wide = (env_l16 != 3) && (Co % 128) == 0;
+    const int bn = wide ? 128 : 64;
+    p.tiles_m = (int)((M + 63) / 64);
+    p.tiles_n = (Co + bn - 1) / bn;
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    if (wide) hipLaunchKernelGGL((conv_s2_l16_kernel<64, 128, false>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_s2_l16_kernel<64, 64, false>), grid, dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+  }
   static const int env_direct = getenv("DV3_CONV_DIRECT") ? atoi(getenv("DV3_CONV_DIRECT")) : 64;
   if ((Ci & 3) == 0 && Co <= env_direct && Co <= 128) {
     const dim3 grid((unsigned)((M + 127) / 128));
@@ -949,6 +1108,22 @@ extern "C" int dv3_convT_s2_fwd(const float* x, const float* w_packed, const flo
     p.tiles_n = (Co + TS::BN - 1) / TS::BN;
     hipLaunchKernelGGL((convT_s2_kernel<TS>), dim3(p.tiles_m * p.tiles_n, 4), dim3(kThreads), 0, s, p);
   };
+  static const int env_l16 = getenv("DV3_CONVT_L16") ? atoi(getenv("DV3_CONVT_L16")) : 1;
+  // measured (tools/conv_bench.py, 1024 frames, us): Co 32: direct 247 / l16 278; Co 64: 195 / 195; Co 128: 183 / 178 --
+  // the register-direct kernels keep the narrow layers, the LDS tile takes Co >= 128 (and everything wider, which
+  // used to run on the k-major 32x32x2 tiles)
+  if (env_l16 && (Ci % 32) == 0 && Co >= (env_l16 == 2 ? 32 : 128) && ((uintptr_t)x % 16) == 0 &&
+      ((uintptr_t)w_packed % 16) == 0) {
+    const int bn = (Co % 128) == 0 && env_l16 != 3 ? 128 : (Co % 64) == 0 ? 64 : 32;
+    const int bm = bn == 32 ? 128 : 64;
+    p.tiles_m = (int)((M + bm - 1) / bm);
+    p.tiles_n = (Co + bn - 1) / bn;
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 4);
+    if (bn == 128) hipLaunchKernelGGL((conv_s2_l16_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv_s2_l16_kernel<64, 64, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_s2_l16_kernel<128, 32, true>), grid, dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+  }
   static const int env_direct = getenv("DV3_CONVT_DIRECT") ? atoi(getenv("DV3_CONVT_DIRECT")) : 128;
   if ((Ci & 3) == 0 && Co <= env_direct && Co <= 128) {
     const dim3 grid((unsigned)((M + 127) / 128), 4);

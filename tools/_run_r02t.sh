@@ -1,6 +1,9 @@
 #!/bin/bash
-mkdir -p gpurun_out/r02x
-DV3_SIDE_STREAM=1 timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/r02x/bench_side.log 2>&1 || { tail -5 gpurun_out/r02x/bench_side.log; exit 1; }
-tail -1 gpurun_out/r02x/bench_side.log | cut -c1-200
-timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/r02x/bench_noside.log 2>&1 || exit 1
-tail -1 gpurun_out/r02x/bench_noside.log | cut -c1-200
+mkdir -p gpurun_out/r02z
+for r in 1 2; do
+DV3_CONV_L16=0 DV3_CONVT_L16=0 timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/r02z/bench_off.log 2>&1 || exit 1
+echo "off: $(tail -1 gpurun_out/r02z/bench_off.log | cut -c95-180)"
+timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/r02z/bench_on.log 2>&1 || exit 1
+echo "on : $(tail -1 gpurun_out/r02z/bench_on.log | cut -c95-180)"
+done
+timeout -k 10 300 python tools/wm_bench.py 2>&1 | grep -v amdgpu | grep -i "conv\|world"
