@@ -875,7 +875,7 @@ static bool l16_ok(const GemmParams& p, int transA, int transB) {
 static void launch_l16(const GemmParams& p0, int force, hipStream_t s) {
   GemmParams p = p0;
   auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  int sel = wgs(64, 64) >= 1024 ? 2 : 3;
+  int sel = wgs(64, 64) >= 512 ? 2 : 3;  // explicit tile 11: 64 x 64 from 512 tiles up, else 32 x 64
   if (force >= 1 && force <= 3) sel = force;
   const int bm = sel == 3 ? 32 : 64, bn = sel == 1 ? 96 : 64;
   p.tiles_m = (p.M + bm - 1) / bm;
@@ -1185,14 +1185,24 @@ using T32x32S4 = TileShape<1, 1, 1, 1, 64, 4>;  // 32 x 32, BK 64, K split over 
 using T32x128 = TileShape<1, 4, 1, 1, 32>;  // 32 x 128, BK 32 (few rows: the observe scan, M = batch)
 
 // Tile choice when the caller passes tile = -1 (the Python wrapper normally decides, same rule).
+static int legacy_tile(int M, int N) {
+  const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+  if (t64 <= 512) return 9;
+  const long c128 = (((long)((M + 127) / 128) * ((N + 127) / 128)) + 255) / 256 * 4;
+  const long c64 = (t64 + 255) / 256;
+  return (c64 < c128) ? 1 : 4;
+}
 static int pick_tile(int M, int N, int K, int accumulate) {
   if (M <= 32) return 2;
   if (accumulate && K >= 4096 && (long)M * N >= 512L * 1024) return 4;
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
-  if (t64 <= 512 && !accumulate) return t64 <= 128 ? 9 : 11;
-  const long c128 = (((long)((M + 127) / 128) * ((N + 127) / 128)) + 255) / 256 * 4;
-  const long c64 = (t64 + 255) / 256;
-  return (c64 < c128) ? 1 : 4;
+  if (t64 <= 128) return 9;
+  // y = x W^T by output size: see dv3hip/ops.py pick_gemm_tile for the measurements behind the thresholds
+  if (t64 < 512) return 14;
+  if (t64 <= 1024) return 13;
+  if (t64 <= 2048 && N >= 3072) return 14;
+  if (t64 >= 4096 && N >= 4096 && (N % 96) == 0) return 12;
+  return legacy_tile(M, N);
 }
 
 }  // namespace dv3
@@ -1230,7 +1240,7 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
   int t = ((tile >= 0 && tile <= 6) || (tile >= 8 && tile <= 14)) ? tile : pick_tile(M, N, K, accumulate);
-  if (t == 11 && tile < 0 && !l16_ok(p, transA, transB)) t = 9;
+  if (t >= 11 && tile < 0 && !l16_ok(p, transA, transB)) t = legacy_tile(M, N);
   if (t == 9 && tile < 0 && (transA || (A2 && (K1 % 16) != 0))) t = ((long)M * N <= 512L * 1024) ? 8 : 6;
   if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6 || t == 8)) t = 1;
   hipStream_t s = (hipStream_t)stream;
@@ -1305,7 +1315,7 @@ extern "C" int dv3_gemm_sample_f32(int M, int N, int K, const float* A, long lda
   p.smp_forced = forced; p.smp_flips = flips; p.smp_unimix = unimix; p.smp_mode = mode;
   p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_mean = ln_mean; p.ln_rstd = ln_rstd;
   // same kernel family as dv3_gemm_f32 picks for the plain product of this size (bit-equal logits)
-  if (!ln_gamma && pick_tile(M, N, K, 0) == 11 && l16_ok(p, 0, 1)) {
+  if (!ln_gamma && pick_tile(M, N, K, 0) >= 11 && l16_ok(p, 0, 1)) {
     launch_l16_sample(p, (hipStream_t)stream);
     return (int)hipGetLastError();
   }

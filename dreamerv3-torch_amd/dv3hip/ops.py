@@ -146,10 +146,26 @@ def l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb) -> bool:
             and (A2 is None or (lda2 % 4 == 0 and A2.data_ptr() % 16 == 0)))
 
 
+def _legacy_tile(M: int, N: int) -> int:
+    """Tile for y = x W^T shapes the k-contiguous LDS kernel cannot take (alignment, K % 32, transposed operands)."""
+    t64 = -(-M // 64) * -(-N // 64)
+    if t64 <= 512:
+        return _SMALL_TILE if t64 <= 128 else 9
+    c128 = ((-(-M // 128) * -(-N // 128)) + 255) // 256 * 4
+    c64 = (t64 + 255) // 256 * 1
+    return 1 if c64 < c128 else 4
+
+
 def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
-    """Tile choice (mirrors csrc/gemm.hip): small outputs take the 32x64 tile with the K split inside the
-    workgroup (fills the 256 CUs when M*N is small); otherwise minimise (waves of workgroups over 256 CUs)
-    x (MFMAs per wave per k-step) between 64x64 and 128x128."""
+    """Tile choice (mirrors csrc/gemm.hip pick_tile).  Few rows: the few-row kernel.  Weight gradients: the 128x128
+    LDS tile for big outputs with a long reduction, else the register-direct TN kernel.  y = x W^T by output size
+    (t64 = number of 64 x 64 tiles), measured with tools/gemm_bench.py (gpurun_out/r02z):
+      t64 <= 128            register-direct 32 x 64 (9)                1024 x 512 x 512: 9.3 us vs 10.2 (l16)
+      t64 <  512            k-contiguous LDS tile 32 x 64 (14)         1024 x 1536 x 1024: 35.9 vs 44.0 (9)
+      512 <= t64 <= 1024    k-contiguous LDS tile 64 x 64 (13)         2048 x 1024 x 1024: 46.6 vs 54.7 (1); 4096 x 1024 x 1024: 87.6 vs 96.8 (4)
+      wide, t64 <= 2048     32 x 64 again (14)                         2048 x 3072 x 1536: 208 vs 254 (1)
+      N % 96 == 0, >= 4096  k-contiguous LDS tile 64 x 96 (12)         4096 x 12288 x 5120: 4286 vs 4395 (4)
+      otherwise             k-major 32x32x2 tiles, 64 x 64 (1) or 128 x 128 (4) by waves of workgroups."""
     if M <= 32:
         return 2
     if wgrad:
@@ -157,11 +173,19 @@ def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
         # the register-direct weight-gradient kernel (K split over workgroups, atomics)
         return 4 if (K >= 4096 and M * N >= 512 * 1024) else 10
     t64 = -(-M // 64) * -(-N // 64)
-    if t64 <= 512 and not wgrad:  # weight gradients split K across workgroups instead (long reduction)
-        return _SMALL_TILE if t64 <= 128 else _MID_TILE
-    c128 = ((-(-M // 128) * -(-N // 128)) + 255) // 256 * 4
-    c64 = (t64 + 255) // 256 * 1
-    return 1 if c64 < c128 else 4
+    if t64 <= 128:
+        return _SMALL_TILE
+    if _MID_TILE != 11:  # development switch: one tile for every mid-size shape
+        return _MID_TILE if t64 <= 512 else _legacy_tile(M, N)
+    if t64 < 512:
+        return 14
+    if t64 <= 1024:
+        return 13
+    if t64 <= 2048 and N >= 3072:
+        return 14
+    if t64 >= 4096 and N >= 4096 and N % 96 == 0:
+        return 12
+    return _legacy_tile(M, N)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -211,7 +235,7 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         if tile in (6, 8) and A2 is not None and (K1 % 64) != 0:
             tile = 1
         if tile >= 11 and not l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb):
-            tile = 9
+            tile = _legacy_tile(M, N)
         if tile == 9 and (transA or (A2 is not None and (K1 % 16) != 0)):
             tile = (8 if M * N <= 512 * 1024 else 6) if not (A2 is not None and (K1 % 64) != 0) else 1
         if tile == 10 and (transB or A2 is not None or bias is not None):
@@ -1113,7 +1137,7 @@ def actor_head(pre, gamma, beta, y, mean, rstd, Wm, bm, Ws, bs, out_m, out_s, ac
 def gemm_sample_ok(M, N, D, A=None) -> bool:
     """True when ops.gemm_sample applies: groups of 32 classes, whole groups per 64-column tile, and an output
     size for which dv3_gemm_f32 would pick the register-direct kernel anyway."""
-    return D == 32 and N % 64 == 0 and M > 32 and pick_gemm_tile(M, N) in (9, 11)
+    return D == 32 and N % 64 == 0 and M > 32 and -(-M // 64) * (N // 64) <= 512
 
 
 def gemm_sample(A, B, logit, onehot, *, bias=None, noise=None, rng=None, idx=None, forced=None, flips=None,
@@ -1159,7 +1183,7 @@ def gemm_sample(A, B, logit, onehot, *, bias=None, noise=None, rng=None, idx=Non
                 _contig(t, nm)
                 if t.numel() != M:
                     raise ValueError(nm + " size mismatch")
-    l16 = (ln is None and pick_gemm_tile(M, N) == 11 and _MID_TILE == 11
+    l16 = (ln is None and pick_gemm_tile(M, N) >= 11
            and l16_ok(A, None, B, False, True, K, K, lda, 0, ldb))  # profile key only: the library decides the same way
     _call("dv3_gemm_sample_f32", M, N, K, _ptr(A), lda, 0, 0, 0, _ptr(B), ldb, _ptr(logit), ldc, _ptr(bias), _ptr(noise),
           _ptr(rng_state), int(rng_off), _ptr(onehot), _ptr(idx), _ptr(forced), _ptr(flips), float(unimix), int(mode),

@@ -36,6 +36,12 @@ SHAPES = [
     (1024, 512, 512, 0, 0, "imagine dgrad"),
     (1024, 1536, 1024, 0, 0, "imagine dgrad gru"),
     (4096, 4096, 4096, 0, 1, "square 4k"),
+    (2048, 3072, 1536, 0, 1, "big: cfg3 GRU fwd"),
+    (2048, 1024, 1024, 0, 1, "big: cfg3 stacked"),
+    (4096, 1024, 1024, 0, 1, "big: cfg5 hidden"),
+    (4096, 2048, 2048, 0, 1, "big: cfg5 stacked"),
+    (4096, 6144, 3072, 0, 1, "big: cfg5 GRU fwd"),
+    (4096, 12288, 5120, 0, 1, "big: cfg4 GRU fwd"),
 ]
 
 
