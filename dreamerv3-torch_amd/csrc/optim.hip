@@ -214,4 +214,73 @@ extern "C" int dv3_quantile2_ema(const float* x, long n, double q0, double q1, f
   return (int)hipGetLastError();
 }
 
+// tools.tensorstats (tools.py:949-958): out[0..3] = mean, std (unbiased, torch.std), min, max of (x[i] - shift) * scale
+// in one launch (the reference's four reductions per logged tensor).  shift / scale (optional device scalars) fold
+// the normed_target expression (models.py:412-414) into the read.
+__global__ __launch_bounds__(1024) void tensorstats_kernel(const float* __restrict__ x, long n,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ inv_scale, float* __restrict__ out) {
+  __shared__ double red[16];
+  __shared__ float redmin[16], redmax[16];
+  __shared__ double mean_sh;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float sh = shift ? shift[0] : 0.f;
+  double s = 0.0;
+  float mn = INFINITY, mx = -INFINITY;
+  for (long i = tid; i < n; i += 1024) {
+    const float v = inv_scale ? (x[i] - sh) / inv_scale[0] : (x[i] - sh);
+    s += (double)v;
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  if (lane == 0) {
+    red[wave] = s;
+    redmin[wave] = mn;
+    redmax[wave] = mx;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    float a = INFINITY, b = -INFINITY;
+    for (int w = 0; w < 16; ++w) {
+      t += red[w];
+      a = fminf(a, redmin[w]);
+      b = fmaxf(b, redmax[w]);
+    }
+    mean_sh = t / (double)n;
+    out[0] = (float)mean_sh;
+    out[2] = a;
+    out[3] = b;
+  }
+  __syncthreads();
+  const double mean = mean_sh;
+  double q = 0.0;
+  for (long i = tid; i < n; i += 1024) {
+    const float v = inv_scale ? (x[i] - sh) / inv_scale[0] : (x[i] - sh);
+    const double d = (double)v - mean;
+    q += d * d;
+  }
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  __syncthreads();
+  if (lane == 0) red[wave] = q;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[1] = n > 1 ? (float)sqrt(t / (double)(n - 1)) : NAN;
+  }
+}
+
+extern "C" int dv3_tensorstats(const float* x, long n, const float* shift, const float* scale, float* out4,
+                               void* stream) {
+  if (n <= 0 || !x || !out4) return DV3_ERR_ARG;
+  hipLaunchKernelGGL(tensorstats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, shift, scale, out4);
+  return (int)hipGetLastError();
+}
+
 extern "C" int dv3_version(void) { return 2; }

@@ -250,6 +250,18 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
     return C
 
 
+def tensorstats(x, out4, *, shift=None, scale=None):
+    """out4 [4] = mean, std (unbiased), min, max of (x - shift) / scale (shift / scale: optional 1-element device tensors)."""
+    _contig(x, "x"), _contig(out4, "out4")
+    if out4.numel() != 4:
+        raise ValueError("tensorstats output must have 4 elements")
+    for t, nm in ((shift, "shift"), (scale, "scale")):
+        if t is not None:
+            _contig(t, nm)
+    _call("dv3_tensorstats", _ptr(x), x.numel(), _ptr(shift), _ptr(scale), _ptr(out4), _stream())
+    return out4
+
+
 def concat_flat(parts, dst):
     """dst[flat] = concatenation of up to 6 contiguous float tensors, one launch (the acting step packs its outputs
     for a single device-to-host hop; dv3hip.graph.PolicyRunner)."""

@@ -620,9 +620,19 @@ def uniform_weight_init(given_scale):
     return f
 
 
-def tensorstats(tensor, prefix=None):  # tools.py:949-958 (device scalars; converted lazily)
-    metrics = {"mean": torch.mean(tensor), "std": torch.std(tensor), "min": torch.min(tensor),
-               "max": torch.max(tensor)}
+def tensorstats(tensor, prefix=None, *, shift=None, scale=None):
+    """tools.py:949-958: mean / std / min / max as device scalars (converted lazily).  One launch for the four
+    reductions on device float tensors; shift / scale (1-element device tensors): statistics of (tensor - shift) /
+    scale without materialising it."""
+    if tensor.is_cuda and tensor.dtype == torch.float32 and tensor.numel() > 0:
+        out = torch.empty(4, device=tensor.device)
+        ops.tensorstats(tensor.detach().contiguous(), out, shift=shift, scale=scale)
+        metrics = {"mean": out[0], "std": out[1], "min": out[2], "max": out[3]}
+    else:
+        if shift is not None:
+            tensor = (tensor - shift) / (1.0 if scale is None else scale)
+        metrics = {"mean": torch.mean(tensor), "std": torch.std(tensor), "min": torch.min(tensor),
+                   "max": torch.max(tensor)}
     return {f"{prefix}_{k}": v for k, v in metrics.items()} if prefix else metrics
 
 

@@ -308,6 +308,11 @@ int dv3_fill_normal(float* out, long n, const unsigned long long* rng_state, uns
 int dv3_quantile2_ema(const float* x, long n, double q0, double q1, float* ema, float alpha, float* out_q,
                       void* stream);
 
+/* tools.tensorstats (tools.py:949-958) in one launch: out4 = {mean, std (unbiased), min, max} of (x[i] - shift[0]) /
+ * scale[0] over x[n]; shift / scale are optional DEVICE scalars (NULL: 0 / 1) -- the normed_target statistics of
+ * models.py:412-414 read (target - ema[0]) / (ema[1] - ema[0] clipped) without materialising it. */
+int dv3_tensorstats(const float* x, long n, const float* shift, const float* scale, float* out4, void* stream);
+
 /* ---- row-fused layers of the imagination step (csrc/fusedops.hip) -----------------------------------
  * dv3_onehot_linear_ln_fwd: pre[M,N] = base + sum_s WT[s*D + idx[m][s]] + sum_a x2[m][a] * WT[S*D + a], then
  * y = act(LN(pre)) (y == NULL: pre only).  The Linear + LayerNorm + SiLU whose input is cat[stoch.flat, tail]

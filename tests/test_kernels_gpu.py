@@ -586,7 +586,8 @@ def test_adam_clip_matches_oracle(ops):
 # ------------------------------------------------------------------------------------------ conv stacks
 CONV_CASES = [(4, 64, 64, 3, 32), (3, 32, 32, 32, 64), (2, 16, 16, 64, 128), (5, 8, 8, 128, 256),
               (3, 64, 64, 3, 2), (3, 32, 32, 2, 4), (2, 8, 8, 8, 16), (1, 4, 4, 6, 5),
-              (2, 64, 64, 3, 32), (5, 2, 2, 3, 32), (2, 4, 4, 3, 96), (33, 8, 8, 3, 40)]  # image-side wgrad path
+              (2, 64, 64, 3, 32), (5, 2, 2, 3, 32), (2, 4, 4, 3, 96), (33, 8, 8, 3, 40),  # image-side wgrad path
+              (2, 16, 16, 96, 192), (3, 8, 8, 64, 160), (1, 4, 4, 32, 72)]  # k-contiguous LDS tile path, crafter widths / ragged Co
 
 
 def nhwc(x):
@@ -621,7 +622,8 @@ def test_conv_s2_fwd_dgrad_wgrad(ops, N, H, W, Ci, Co):
 
 
 @pytest.mark.parametrize("N,H,W,Ci,Co", [(4, 4, 4, 256, 128), (3, 8, 8, 128, 64), (2, 16, 16, 64, 32),
-                                         (3, 32, 32, 32, 3), (2, 4, 4, 16, 8), (2, 32, 32, 2, 3)])
+                                         (3, 32, 32, 32, 3), (2, 4, 4, 16, 8), (2, 32, 32, 2, 3),
+                                         (2, 4, 4, 384, 192), (3, 4, 4, 64, 160), (1, 8, 8, 32, 256)])
 def test_convT_s2_fwd_dgrad_wgrad(ops, N, H, W, Ci, Co):
     """Decoder layer: ConvTranspose2d(k4,s2,p1) + bias + 0.5, its input gradient (= conv with the
     same weight) and its weight gradient."""
@@ -939,6 +941,22 @@ def test_im2col_then_gemm_is_the_same_pad_stride2_conv(ops, N, H, Ci, Co):
     ops.gemm(cols, dev(w).view(Co, 16 * Ci), y)
     ref = F.conv2d(F.pad(x.permute(0, 3, 1, 2), (1, 1, 1, 1)), w, stride=2).permute(0, 2, 3, 1)
     assert_close(y.view(N, OH, OH, Co), ref, tol=2e-5, what="conv via im2col")
+
+
+@pytest.mark.parametrize("n", [15360, 5, 2, 1025, 300000])
+def test_tensorstats_kernel_matches_torch_reductions(ops, n):
+    """tools.tensorstats (tools.py:949-958): mean / unbiased std / min / max in one launch, optionally of
+    (x - shift) / scale (models.py:412-414)."""
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g) * 3 + 1.5
+    out = torch.empty(4, device="cuda")
+    ops.tensorstats(dev(x), out)
+    ref = torch.stack([x.mean(), x.std(), x.min(), x.max()])
+    assert_close(out, ref, tol=2e-6, what="stats")
+    sh, sc = torch.tensor([0.7]), torch.tensor([2.5])
+    ops.tensorstats(dev(x), out, shift=dev(sh), scale=dev(sc))
+    y = (x - sh) / sc
+    assert_close(out, torch.stack([y.mean(), y.std(), y.min(), y.max()]), tol=2e-6, what="shifted stats")
 
 
 @pytest.mark.parametrize("n", [14336, 7, 1, 2, 1000, 458752])
