@@ -116,6 +116,58 @@ __global__ __launch_bounds__(256) void onehot_st_bwd_kernel(const float* __restr
   }
 }
 
+// Reverse observe scan, the two row operations between step t's last data-gradient GEMM and step t-1's first one in ONE
+// launch (obs_blend_bwd + onehot_st_bwd):
+//   carry   gs_prev += dsin (1 - m),  gd_prev += ddin (1 - m),  dstoch0 / ddeter0 += sum_b (.) m   (networks.py:183-191)
+//   ST      dpost_logit_prev += (1-u) sm (t - sum_j sm_j t_j),  t = the just-updated gs_prev      (tools.py:452-460)
+// Blocks [0, nb_s) take the B*S categorical groups (one class per lane), blocks [nb_s, ...) the B*De deter elements.
+template <int G>
+__global__ __launch_bounds__(256) void obs_carry_st_bwd_kernel(const float* __restrict__ dsin, long ld_dsin,
+                                                               const float* __restrict__ ddin, long ld_ddin,
+                                                               const float* __restrict__ first,
+                                                               float* __restrict__ gs_prev, float* __restrict__ gd_prev,
+                                                               float* __restrict__ ds0, float* __restrict__ dd0,
+                                                               const float* __restrict__ logit_prev,
+                                                               float* __restrict__ dlogit_prev, int B, int S, int D,
+                                                               int De, float unimix, int nb_s) {
+  if ((int)blockIdx.x < nb_s) {
+    constexpr int GPB = 256 / G;
+    const int sub = threadIdx.x / G, d = threadIdx.x % G;
+    const bool valid = d < D;
+    const long R = (long)B * S;
+    const int SD = S * D;
+    for (long r0 = (long)blockIdx.x * GPB; r0 < R; r0 += (long)nb_s * GPB) {
+      const long r = r0 + sub;
+      const bool rv = r < R;
+      const int b = rv ? (int)(r / S) : 0, sg = rv ? (int)(r % S) : 0;
+      const int j = sg * D + d;
+      float t = 0.f;
+      if (rv && valid) {
+        const float m = first[b];
+        const float g = dsin[(long)b * ld_dsin + j];
+        t = gs_prev[(long)b * SD + j] + g * (1.f - m);
+        gs_prev[(long)b * SD + j] = t;
+        if (m != 0.f) atomicAdd(ds0 + j, g * m);
+      }
+      const float l = (rv && valid) ? logit_prev[r * D + d] : 0.f;
+      float sm, ph;
+      unimix_probs<G>(l, valid, D, unimix, sm, ph);
+      const float dot = group_sum<G>(sm * t);
+      if (rv && valid) dlogit_prev[r * D + d] += (1.f - unimix) * sm * (t - dot);
+    }
+  } else {
+    const long total = (long)B * De;
+    const long nb_d = gridDim.x - nb_s;
+    for (long e = (long)(blockIdx.x - nb_s) * 256 + threadIdx.x; e < total; e += nb_d * 256) {
+      const int b = (int)(e / De), k = (int)(e % De);
+      const float m = first[b];
+      const float g = ddin[(long)b * ld_ddin + k];
+      gd_prev[e] += g * (1.f - m);
+      if (m != 0.f) atomicAdd(dd0 + k, g * m);
+    }
+  }
+}
+
 // KL(post || prior) summed over the S groups of one state row, plus both entropies.
 //   kl = sum p (log p - log q),  ent = -sum p log p      (p, q unimixed)
 template <int G>
@@ -338,6 +390,27 @@ extern "C" int dv3_onehot_st_bwd(const float* logit, const float* dstoch, float*
   hipStream_t s = (hipStream_t)stream;
   DV3_G_DISPATCH(D, hipLaunchKernelGGL((onehot_st_bwd_kernel<G>), dim3(cap_blocks(R, 256 / G, 8192)), dim3(256), 0, s,
                                        logit, dstoch, dlogit, R, D, unimix, mode, accumulate));
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_obs_carry_st_bwd(const float* dsin, long ld_dsin, const float* ddin, long ld_ddin,
+                                    const float* is_first, float* gs_prev, float* gd_prev, float* dstoch0,
+                                    float* ddeter0, const float* logit_prev, float* dlogit_prev, int B, int S, int D,
+                                    int De, float unimix, void* stream) {
+  if (B <= 0) return 0;
+  if (!dsin || !ddin || !is_first || !gs_prev || !gd_prev || !dstoch0 || !ddeter0 || !logit_prev || !dlogit_prev ||
+      S <= 0 || D <= 0 || D > 64 || De <= 0 || ld_dsin < (long)S * D || ld_ddin < De)
+    return DV3_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long R = (long)B * S;
+  DV3_G_DISPATCH(D, {
+    const int nb_s = (int)cap_blocks(R, 256 / G, 4096);
+    long nb_d = ((long)B * De + 255) / 256;
+    if (nb_d > 1024) nb_d = 1024;
+    hipLaunchKernelGGL((obs_carry_st_bwd_kernel<G>), dim3((unsigned)(nb_s + nb_d)), dim3(256), 0, s, dsin, ld_dsin, ddin,
+                       ld_ddin, is_first, gs_prev, gd_prev, dstoch0, ddeter0, logit_prev, dlogit_prev, B, S, D, De,
+                       unimix, nb_s);
+  });
   return (int)hipGetLastError();
 }
 

@@ -38,7 +38,8 @@ _FUSE_SAMPLE = os.environ.get("DV3_FUSE_SAMPLE", "1") != "0"  # sampling in the 
 # (r02j, 1024 rows) the GEMM goes 27 -> 49.5 us -- its 16 column tiles each redo the SiLU of the same A rows and the
 # wave's VALU work (16 exp + 16 div per 64 MFMAs) exceeds its MFMA time -- against the 7 us LayerNorm launch it removes.
 _LN_ON_LOAD = os.environ.get("DV3_LN_ON_LOAD", "0") != "0"
-_GATHER_OBS = os.environ.get("DV3_GATHER_OBS", "1") != "0"  # one-hot gather for img_in / head first layers in observe
+_GATHER_OBS = os.environ.get("DV3_GATHER_OBS", "1") != "0"
+_FUSE_CARRY = os.environ.get("DV3_FUSE_CARRY", "1") != "0"  # reverse scan: carry + next straight-through in one launch  # one-hot gather for img_in / head first layers in observe
 
 
 class SideStream:
@@ -492,10 +493,13 @@ class RSSMEngine:
         dx1pre = g("obs.dx1pre", (T, B, Hd))
         dsin = ws.zeros("obs.dsin", (T, B, SD))
         dstoch0, ddeter0 = ws.zeros("obs.dstoch0", (SD,)), ws.zeros("obs.ddeter0", (De,))
+        fuse_carry = _FUSE_CARRY
         for t in reversed(range(T)):
             gs_t, gd_t = gs[t], gd[t]  # already hold the carry from step t+1 (folded in by obs_blend_bwd)
             dx1, ddin = dxd[t][:, :Hd], dxd[t][:, Hd:]
-            ops.onehot_st_bwd(post_logit[t], gs_t.view(B, S, D), dpost_logit[t], unimix=self.unimix, accumulate=True)
+            if t == T - 1 or not fuse_carry:  # (otherwise done by step t+1's fused carry + straight-through launch)
+                ops.onehot_st_bwd(post_logit[t], gs_t.view(B, S, D), dpost_logit[t], unimix=self.unimix,
+                                  accumulate=True)
             ops.gemm(dpost_logit[t].view(B, SD), P.obs.W, dx3[t], transB=False, accumulate="atomic")
             dense_ln_bwd_pre(P.obs_out, dx3[t], x3pre[t], m3[t], r3[t], dx3pre[t], wgrad=True)
             ops.gemm(dx3pre[t], P.obs_out.W[:, :De], gd_t, transB=False, accumulate="atomic")
@@ -504,8 +508,12 @@ class RSSMEngine:
             ops.gemm(dgpre[t], P.gru.W, dxd[t], transB=False, accumulate="atomic")
             dense_ln_bwd_pre(P.img_in, dx1, x1pre[t], m1[t], r1[t], dx1pre[t], wgrad=True)
             ops.gemm(dx1pre[t], P.img_in.W[:, :SD], dsin[t], transB=False, accumulate="atomic")
-            ops.obs_blend_bwd(dsin[t], ddin, first[t], gs[t - 1] if t > 0 else None, gd[t - 1] if t > 0 else None,
-                              dstoch0, ddeter0)
+            if fuse_carry and t > 0:
+                ops.obs_carry_st_bwd(dsin[t], ddin, first[t], gs[t - 1], gd[t - 1], dstoch0, ddeter0, post_logit[t - 1],
+                                     dpost_logit[t - 1], unimix=self.unimix)
+            else:
+                ops.obs_blend_bwd(dsin[t], ddin, first[t], gs[t - 1] if t > 0 else None,
+                                  gd[t - 1] if t > 0 else None, dstoch0, ddeter0)
         # ---- the encoder-output gradient (critical path) and, beside it, the batched weight gradients
         side.join()  # the init-state backward below adds into the same prior-head gradients
         ops.gemm(v2(dx3pre, Hd), P.obs_out.W[:, De:], v2(dembed, E), transB=False)

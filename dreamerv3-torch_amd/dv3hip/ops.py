@@ -968,6 +968,23 @@ def obs_blend_bwd(dsin, ddin, is_first, gs_prev, gd_prev, dstoch0, ddeter0):
           _ptr(dstoch0), _ptr(ddeter0), B, SD, De, _stream())
 
 
+def obs_carry_st_bwd(dsin, ddin, is_first, gs_prev, gd_prev, dstoch0, ddeter0, logit_prev, dlogit_prev, *, unimix=0.01):
+    """obs_blend_bwd (step t) + onehot_st_bwd(accumulate=True) (step t-1) in one launch; logit_prev [B,S,D]."""
+    B, SD, ld_s = _rows2d(dsin, "dsin")
+    Bd, De, ld_d = _rows2d(ddin, "ddin")
+    if logit_prev.dim() != 3 or logit_prev.shape[0] != B or logit_prev.shape[1] * logit_prev.shape[2] != SD or Bd != B:
+        raise ValueError("obs_carry_st_bwd shapes mismatch")
+    S, D = logit_prev.shape[1], logit_prev.shape[2]
+    for t, nm, n in ((is_first, "is_first", B), (gs_prev, "gs_prev", B * SD), (gd_prev, "gd_prev", B * De),
+                     (dstoch0, "dstoch0", SD), (ddeter0, "ddeter0", De), (logit_prev, "logit_prev", B * SD),
+                     (dlogit_prev, "dlogit_prev", B * SD)):
+        _contig(t, nm)
+        if t.numel() != n:
+            raise ValueError(nm + " size mismatch")
+    _call("dv3_obs_carry_st_bwd", _ptr(dsin), ld_s, _ptr(ddin), ld_d, _ptr(is_first), _ptr(gs_prev), _ptr(gd_prev),
+          _ptr(dstoch0), _ptr(ddeter0), _ptr(logit_prev), _ptr(dlogit_prev), B, S, D, De, float(unimix), _stream())
+
+
 def dot_accumulate(x, out, *, w=None, clip_min=None, scale=1.0):
     """out[0] += scale * sum(max(x, clip_min) * w)."""
     _contig(x, "x"), _contig(out, "out")

@@ -282,6 +282,14 @@ int dv3_obs_blend_bwd(const float* dsin, long ld_dsin, const float* ddin, long l
                       float* gs_prev, float* gd_prev, float* dstoch0, float* ddeter0, int B, int SD, int De,
                       void* stream);
 
+/* dv3_obs_blend_bwd of step t followed by dv3_onehot_st_bwd (sample form, accumulate) of step t-1 in one launch: the
+ * carry gs_prev / gd_prev (+)= as above, then dlogit_prev [B,S,D] += the straight-through gradient of the posterior
+ * sample of step t-1 (logit_prev [B,S,D]) with t = the updated gs_prev (RSSM.observe backward: networks.py:183-191,
+ * tools.py:452-460).  dsin [B, S*D] / ddin [B, De] row-strided. */
+int dv3_obs_carry_st_bwd(const float* dsin, long ld_dsin, const float* ddin, long ld_ddin, const float* is_first,
+                         float* gs_prev, float* gd_prev, float* dstoch0, float* ddeter0, const float* logit_prev,
+                         float* dlogit_prev, int B, int S, int D, int De, float unimix, void* stream);
+
 /* ---- optimizer -- tools.Optimizer.__call__ (tools.py:760-776) on a flat fp32 bucket ----------------
  * state[0] = step count, state[1] = sum of squares accumulator, state[2] = last grad norm.
  * dv3_sumsq_accumulate adds sum(x^2) into *out (x 16-byte aligned).  dv3_adam_step clips by

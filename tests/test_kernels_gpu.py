@@ -943,6 +943,32 @@ def test_im2col_then_gemm_is_the_same_pad_stride2_conv(ops, N, H, Ci, Co):
     assert_close(y.view(N, OH, OH, Co), ref, tol=2e-5, what="conv via im2col")
 
 
+@pytest.mark.parametrize("B,S,D,De", [(16, 32, 32, 512), (5, 3, 7, 20), (32, 32, 32, 1024)])
+def test_obs_carry_st_bwd_equals_blend_bwd_then_st_bwd(ops, B, S, D, De):
+    """Reverse observe scan: the fused carry + straight-through launch == dv3_obs_blend_bwd followed by
+    dv3_onehot_st_bwd(accumulate) on the previous step."""
+    g = torch.Generator().manual_seed(B + S + De)
+    SD = S * D
+    wide = dev(torch.randn(B, SD + De + 4, generator=g))
+    dsin, ddin = wide[:, :SD], wide[:, SD + 4:]
+    first = dev((torch.rand(B, generator=g) < 0.3).float())
+    logit = dev(torch.randn(B, S, D, generator=g))
+    gs0, gd0 = torch.randn(B, SD, generator=g), torch.randn(B, De, generator=g)
+    dl0 = torch.randn(B, S, D, generator=g)
+    res = []
+    for fused in (False, True):
+        gs, gd, dl = dev(gs0.clone()), dev(gd0.clone()), dev(dl0.clone())
+        ds0, dd0 = torch.zeros(SD, device="cuda"), torch.zeros(De, device="cuda")
+        if fused:
+            ops.obs_carry_st_bwd(dsin, ddin, first, gs, gd, ds0, dd0, logit, dl, unimix=0.01)
+        else:
+            ops.obs_blend_bwd(dsin, ddin, first, gs, gd, ds0, dd0)
+            ops.onehot_st_bwd(logit, gs.view(B, S, D), dl, unimix=0.01, accumulate=True)
+        res.append((gs, gd, dl, ds0, dd0))
+    for a, b, nm in zip(res[0], res[1], ("gs", "gd", "dlogit", "dstoch0", "ddeter0")):
+        assert_close(b, a, tol=1e-6, what=nm)
+
+
 @pytest.mark.parametrize("n", [15360, 5, 2, 1025, 300000])
 def test_tensorstats_kernel_matches_torch_reductions(ops, n):
     """tools.tensorstats (tools.py:949-958): mean / unbiased std / min / max in one launch, optionally of
