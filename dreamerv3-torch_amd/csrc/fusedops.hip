@@ -44,23 +44,105 @@ struct OLParams {
   long M;
   int N;
   int act;
+  // SMP variant (observe scan, D == 32): the row's S categorical groups are SAMPLED here first from smp_logit
+  // [M][S][32] (dv3_onehot_sample_fwd_ex semantics incl. the next step's reset blend), and the gather reads the
+  // blended class indices from LDS: the posterior sample of step t and the img_in layer of step t+1 in one launch.
+  const float* smp_logit;
+  const float* smp_noise;
+  const unsigned long long* smp_rng;
+  unsigned long long smp_off;
+  float* smp_onehot;
+  int* smp_idx;
+  const int* smp_forced;
+  unsigned int* smp_flips;
+  float smp_unimix;
+  int smp_mode;
+  const float* nb_first;  // [M] is_first of the NEXT step
+  const float* nb_init;   // [S][32] initial stoch (a one-hot: the mode of the initial prior)
+  const int* nb_init_idx;  // [S]
+  float* nb_out;          // [M][S][32] blended one-hot (next step's stoch input)
+  int* nb_idx_out;        // [M][S] its class indices (= what the gather uses)
 };
 
 // N == 256 * NV4.  One workgroup (4 waves) per output row: wave w gathers the rows s = w, w+4, ... of its share in
 // ONE batch of independent 16-byte loads (lane l owns columns 4*(l + 64 v) .. +3), the four partial rows meet in
 // LDS, and every wave then sums them in the same fixed order and normalises -- one memory round trip and one
 // barrier per row (a wave per row needed S / 8 dependent round trips at one wave per SIMD).
-template <int NV4>
-__global__ __launch_bounds__(256) void onehot_linear_ln_vec_kernel(OLParams p) {
+template <int NV4, bool SMP = false>
+__global__ __launch_bounds__(SMP ? 1024 : 256) void onehot_linear_ln_vec_kernel(OLParams p) {
   __shared__ __attribute__((aligned(16))) float part[4][256 * NV4];
+  __shared__ int sidx[64];
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
   const float inv_n = 1.f / (float)p.N;
   constexpr int MAXB = 8;  // gathered rows per wave and batch (S <= 32: one batch)
   for (long r = blockIdx.x; r < p.M; r += gridDim.x) {
-    const int my = (l < p.S) ? p.idx[r * p.S + l] : 0;
+    int my;
+    if constexpr (SMP) {
+      // one group of 32 classes per half-wave (16 waves); same arithmetic and draws as onehot_sample_kernel<32>.
+      // Waves 4..15 only sample: the gather below is the 4-wave scheme of the plain kernel (they keep its barriers).
+      const int d = threadIdx.x & 31;
+      unsigned long long seed = 0, offset = 0;
+      if (!p.smp_mode && !p.smp_noise) {
+        seed = p.smp_rng[0];
+        offset = p.smp_rng[1] + p.smp_off;
+      }
+      const float m = p.nb_first[r];
+      __syncthreads();  // the previous row's gather is done with sidx
+      for (int sg = threadIdx.x >> 5; sg < p.S; sg += 32) {  // 1024 threads: all S <= 32 groups in one pass
+        const long gi = r * p.S + sg;
+        const float lg = p.smp_logit[gi * 32 + d];
+        float sm, ph;
+        unimix_probs<32>(lg, true, 32, p.smp_unimix, sm, ph);
+        float score = ph;
+        if (!p.smp_mode) {
+          float q;
+          if (p.smp_noise) {
+            q = p.smp_noise[gi * 32 + d];
+          } else {
+            uint32_t o4[4];
+            const unsigned long long e = (unsigned long long)gi * 32 + d;
+            Philox ph4(seed);
+            ph4(offset + (e >> 2), 0x5eedULL, o4);
+            q = fmaxf(-logf(u01(o4[e & 3])), 1e-30f);
+          }
+          score = ph / q;
+        }
+        float best = score;
+        int bi = d;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          const float ob = __shfl_xor(best, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+          }
+        }
+        if (p.smp_forced) {
+          const int f = p.smp_forced[gi];
+          if (d == 0 && p.smp_flips && f != bi) atomicAdd(p.smp_flips, 1u);
+          bi = f;
+        }
+        const float v = (d == bi) ? 1.f : 0.f;
+        p.smp_onehot[gi * 32 + d] = v;
+        p.nb_out[gi * 32 + d] = v * (1.f - m) + p.nb_init[sg * 32 + d] * m;
+        if (d == 0) {
+          if (p.smp_idx) p.smp_idx[gi] = bi;
+          const int ni = (m != 0.f) ? p.nb_init_idx[sg] : bi;
+          p.nb_idx_out[gi] = ni;
+          sidx[sg] = ni;
+        }
+      }
+      __syncthreads();
+      my = (l < p.S) ? sidx[l] : 0;
+    } else {
+      my = (l < p.S) ? p.idx[r * p.S + l] : 0;
+    }
+    const bool worker = !SMP || wave < 4;  // wave-uniform
     f32x4 acc[NV4];
 #pragma unroll
     for (int v = 0; v < NV4; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (worker) {
     if (wave == 0 && p.base) {
 #pragma unroll
       for (int v = 0; v < NV4; ++v) acc[v] = *reinterpret_cast<const f32x4u*>(p.base + r * p.ldbase + 4 * (l + 64 * v));
@@ -91,10 +173,14 @@ __global__ __launch_bounds__(256) void onehot_linear_ln_vec_kernel(OLParams p) {
 #pragma unroll
       for (int v = 0; v < NV4; ++v) acc[v] += xa * *reinterpret_cast<const f32x4u*>(w + 256 * v);
     }
+    }
     __syncthreads();  // the previous row's readers are done with `part`
+    if (worker) {
 #pragma unroll
-    for (int v = 0; v < NV4; ++v) *reinterpret_cast<f32x4*>(&part[wave][4 * (l + 64 * v)]) = acc[v];
+      for (int v = 0; v < NV4; ++v) *reinterpret_cast<f32x4*>(&part[wave][4 * (l + 64 * v)]) = acc[v];
+    }
     __syncthreads();
+    if (!worker) continue;  // no barrier below
 #pragma unroll
     for (int v = 0; v < NV4; ++v) {
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(&part[0][4 * (l + 64 * v)]);
@@ -464,6 +550,38 @@ extern "C" int dv3_onehot_linear_ln_fwd(const int* idx, int S, int D, const floa
     }
   } else {
     hipLaunchKernelGGL(onehot_linear_ln_generic_kernel, dim3(cap_grid(M, 1, 16384)), dim3(256), 0, s, p);
+  }
+  return (int)hipGetLastError();
+}
+
+// dv3_onehot_sample_fwd_ex (with the next step's reset blend) on logit [M][S][32] followed by dv3_onehot_linear_ln_fwd
+// on the blended class indices, in one launch (row per workgroup): the last launch of observe step t and the first of
+// step t+1.  N % 256 == 0, N <= 1024, S <= 32.
+extern "C" int dv3_onehot_sample_linear_ln_fwd(const float* logit, const float* noise,
+                                               const unsigned long long* rng_state, unsigned long long rng_offset,
+                                               float* onehot, int* idx, const int* forced, unsigned int* flips,
+                                               float unimix, int mode, const float* next_first, const float* init,
+                                               const int* init_idx, float* next_out, int* next_idx, int S,
+                                               const float* x2, long ldx2, int A2, const float* WT, long ldw,
+                                               float* pre, long ldpre, const float* gamma, const float* beta, float* y,
+                                               long ldy, float* mean, float* rstd, long M, int N, int act,
+                                               void* stream) {
+  if (M <= 0) return 0;
+  if (!logit || !onehot || !next_first || !init || !init_idx || !next_out || !next_idx || !WT || !pre || !gamma ||
+      !beta || !y || S <= 0 || S > 32 || N <= 0 || (N % 256) != 0 || N > 1024 || A2 < 0 || (A2 > 0 && !x2) ||
+      ldw < N || ldpre < N || ldy < N || (ldw % 4) || (ldpre % 4) || (ldy % 4))
+    return DV3_ERR_ARG;
+  if (!mode && !noise && !rng_state) return DV3_ERR_ARG;
+  OLParams p{nullptr, S, 32, x2, ldx2, A2, WT, ldw, nullptr, 0, pre, ldpre, gamma, beta, y, ldy, mean, rstd, M, N, act,
+             logit, noise, rng_state, rng_offset, onehot, idx, forced, flips, unimix, mode, next_first, init, init_idx,
+             next_out, next_idx};
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(cap_grid(M, 1, 32768)), block(1024);
+  switch (N / 256) {
+    case 1: hipLaunchKernelGGL((onehot_linear_ln_vec_kernel<1, true>), grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((onehot_linear_ln_vec_kernel<2, true>), grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((onehot_linear_ln_vec_kernel<3, true>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((onehot_linear_ln_vec_kernel<4, true>), grid, block, 0, s, p); break;
   }
   return (int)hipGetLastError();
 }

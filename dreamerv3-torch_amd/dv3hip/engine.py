@@ -39,6 +39,7 @@ _FUSE_SAMPLE = os.environ.get("DV3_FUSE_SAMPLE", "1") != "0"  # sampling in the 
 # wave's VALU work (16 exp + 16 div per 64 MFMAs) exceeds its MFMA time -- against the 7 us LayerNorm launch it removes.
 _LN_ON_LOAD = os.environ.get("DV3_LN_ON_LOAD", "0") != "0"
 _GATHER_OBS = os.environ.get("DV3_GATHER_OBS", "1") != "0"
+_FUSE_SAMPLE_IN = os.environ.get("DV3_FUSE_SAMPLE_IN", "1") != "0"  # observe scan: sample(t) + img_in(t+1) in one launch
 _FUSE_CARRY = os.environ.get("DV3_FUSE_CARRY", "1") != "0"  # reverse scan: carry + next straight-through in one launch  # one-hot gather for img_in / head first layers in observe
 
 
@@ -406,6 +407,7 @@ class RSSMEngine:
         # second output of the kernels that produce them at step t (fused when the vector GRU kernel applies).
         ops.reset_blend(v2(action_tm, A), None, first.view(TB), v2(ain, A))
         fuse = ((De % 256 == 0 and De <= 1024) or (De % 1024 == 0 and De <= 4096)) and _FUSE_BLEND
+        fuse_in = fuse and gather and _FUSE_SAMPLE_IN and ops.sample_linear_ln_ok(S, D, Hd) and Hd % 4 == 0
         for t in range(T):
             if t == 0 or not fuse:
                 prev_s = post_stoch[t - 1].view(B, SD) if t > 0 else (None if state0 is None else state0[0])
@@ -414,7 +416,9 @@ class RSSMEngine:
                 if gather:
                     ops.onehot_to_idx(sin[t].view(B, S, D), idx_in[t].view(-1))
             nxt = fuse and t + 1 < T
-            if gather:
+            if fuse_in and t > 0:
+                pass  # x1[t] came out of step t-1's fused sample + img_in launch
+            elif gather:
                 ops.onehot_linear_ln(idx_in[t], D, wt_in, x1pre[t], x2=ain[t], gamma=P.img_in.g, beta=P.img_in.b,
                                      y=x1[t], mean=m1[t], rstd=r1[t])
             else:
@@ -425,11 +429,21 @@ class RSSMEngine:
             ops.gemm(deter[t], P.obs_out.W[:, :De], x3pre[t], accumulate=True)
             ops.ln_act_fwd(x3pre[t], P.obs_out.g, P.obs_out.b, x3[t], m3[t], r3[t], act=True)
             ops.gemm(x3[t], P.obs.W, post_logit[t].view(B, SD), bias=P.obs.b)
-            ops.onehot_sample(post_logit[t], post_stoch[t], noise=None if q_post is None else q_post[t], rng=rng,
-                              unimix=self.unimix,
-                              next_blend=(first[t + 1], s0.view(SD), sin[t + 1].view(B, S, D), init_idx,
-                                          idx_in[t + 1].view(-1)) if nxt else None,
-                              forced=None if f_post is None else f_post[t], flips=flips, idx=post_idx[t].view(-1))
+            if fuse_in and nxt:
+                # the posterior sample of this step and the img_in layer of the next one in one launch
+                ops.onehot_sample_linear_ln(post_logit[t], post_stoch[t], noise=None if q_post is None else q_post[t],
+                                            rng=rng, unimix=self.unimix, idx=post_idx[t].view(-1),
+                                            forced=None if f_post is None else f_post[t], flips=flips,
+                                            next_first=first[t + 1], init=s0.view(SD), init_idx=init_idx,
+                                            next_out=sin[t + 1].view(B, S, D), next_idx=idx_in[t + 1].view(-1),
+                                            WT=wt_in, x2=ain[t + 1], pre=x1pre[t + 1], gamma=P.img_in.g,
+                                            beta=P.img_in.b, y=x1[t + 1], mean=m1[t + 1], rstd=r1[t + 1])
+            else:
+                ops.onehot_sample(post_logit[t], post_stoch[t], noise=None if q_post is None else q_post[t], rng=rng,
+                                  unimix=self.unimix,
+                                  next_blend=(first[t + 1], s0.view(SD), sin[t + 1].view(B, S, D), init_idx,
+                                              idx_in[t + 1].view(-1)) if nxt else None,
+                                  forced=None if f_post is None else f_post[t], flips=flips, idx=post_idx[t].view(-1))
         # prior head for all steps at once
         x2pre, x2 = g("obs.x2pre", (T, B, Hd)), g("obs.x2", (T, B, Hd))
         m2, r2 = g("obs.m2", (T, B)), g("obs.r2", (T, B))

@@ -1119,6 +1119,53 @@ def onehot_linear_ln(idx, D, WT, pre, *, x2=None, base=None, gamma=None, beta=No
     return y if y is not None else pre
 
 
+def sample_linear_ln_ok(S, D, N) -> bool:
+    """Shapes the fused posterior-sample + img_in launch takes (ops.onehot_sample_linear_ln)."""
+    return D == 32 and S <= 32 and N % 256 == 0 and N <= 1024
+
+
+def onehot_sample_linear_ln(logit, out, *, next_first, init, init_idx, next_out, next_idx, WT, x2, pre, gamma, beta, y,
+                            mean, rstd, noise=None, rng=None, idx=None, forced=None, flips=None, unimix=0.01,
+                            mode=False, act=True):
+    """ops.onehot_sample(logit [M,S,32], out, next_blend=(next_first, init, next_out, init_idx, next_idx)) followed by
+    ops.onehot_linear_ln(next_idx, 32, WT, pre, x2=x2, ..., y=y) in one launch (observe scan: the sample of step t and
+    the img_in layer of step t+1)."""
+    if logit.dim() != 3 or logit.shape[2] != 32:
+        raise ValueError("logit must be [M,S,32]")
+    M, S, D = logit.shape
+    Kw, N, ldw = _rows2d(WT, "WT")
+    Mp, Np, ldpre = _rows2d(pre, "pre")
+    My, Ny, ldy = _rows2d(y, "y")
+    Mx, A2, ldx2 = _rows2d(x2, "x2") if x2 is not None else (M, 0, 0)
+    if not sample_linear_ln_ok(S, D, N) or (Mp, Np) != (M, N) or (My, Ny) != (M, N) or Mx != M or Kw != S * D + A2:
+        raise ValueError("onehot_sample_linear_ln shapes mismatch")
+    R = M * S
+    for t, nm, n, dt in ((logit, "logit", R * D, F32), (out, "out", R * D, F32), (noise, "noise", R * D, F32),
+                         (idx, "idx", R, torch.int32), (forced, "forced", R, torch.int32),
+                         (flips, "flips", 1, torch.int32), (next_first, "next_first", M, F32),
+                         (init, "init", S * D, F32), (init_idx, "init_idx", S, torch.int32),
+                         (next_out, "next_out", R * D, F32), (next_idx, "next_idx", R, torch.int32),
+                         (gamma, "gamma", N, F32), (beta, "beta", N, F32), (mean, "mean", M, F32),
+                         (rstd, "rstd", M, F32)):
+        if t is None:
+            continue
+        _contig(t, nm, dt)
+        if t.numel() != n:
+            raise ValueError(nm + " size mismatch")
+    rng_state, rng_off = None, 0
+    if not mode and noise is None:
+        if rng is None:
+            raise ValueError("sampling needs noise or an RngStream")
+        rng_state, rng_off = rng.state, rng.take(R * D)
+    _call("dv3_onehot_sample_linear_ln_fwd", _ptr(logit), _ptr(noise), _ptr(rng_state), int(rng_off), _ptr(out),
+          _ptr(idx), _ptr(forced), _ptr(flips), float(unimix), int(mode), _ptr(next_first), _ptr(init), _ptr(init_idx),
+          _ptr(next_out), _ptr(next_idx), S, _ptr(x2), ldx2, A2, _ptr(WT), ldw, _ptr(pre), ldpre, _ptr(gamma),
+          _ptr(beta), _ptr(y), ldy, _ptr(mean), _ptr(rstd), M, N, int(act), _stream(),
+          key="dv3_onehot_sample_linear_ln_fwd" + (f"[{M}x{N},S={S}]" if PROFILE.by_shape else ""),
+          flops=2.0 * M * N * (S * D + A2), nbytes=4.0 * M * N * (S + 2))
+    return out
+
+
 def actor_head(pre, gamma, beta, y, mean, rstd, Wm, bm, Ws, bs, out_m, out_s, action, entropy, *, noise=None,
                rng=None, eps_out=None, act_idx=None, forced=None, flips=None, min_std=0.1, max_std=1.0, unimix=0.01,
                onehot=False):

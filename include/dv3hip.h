@@ -321,6 +321,18 @@ int dv3_quantile2_ema(const float* x, long n, double q0, double q1, float* ema, 
  * models.py:412-414 read (target - ema[0]) / (ema[1] - ema[0] clipped) without materialising it. */
 int dv3_tensorstats(const float* x, long n, const float* shift, const float* scale, float* out4, void* stream);
 
+/* dv3_onehot_sample_fwd_ex (D = 32, with the next observe step's reset blend: next_first [M], init [S][32], init_idx [S]
+ * -> next_out [M][S][32], next_idx [M][S]) followed by dv3_onehot_linear_ln_fwd on the blended indices, in ONE launch:
+ * the posterior sample of obs_step t (networks.py:199-204) and the _img_in_layers of obs_step t+1 (networks.py:216-218).
+ * Same draws as the stand-alone sampler (bit-equal).  N % 256 == 0, N <= 1024, S <= 32. */
+int dv3_onehot_sample_linear_ln_fwd(const float* logit, const float* noise, const unsigned long long* rng_state,
+                                    unsigned long long rng_offset, float* onehot, int* idx, const int* forced,
+                                    unsigned int* flips, float unimix, int mode, const float* next_first,
+                                    const float* init, const int* init_idx, float* next_out, int* next_idx, int S,
+                                    const float* x2, long ldx2, int A2, const float* WT, long ldw, float* pre,
+                                    long ldpre, const float* gamma, const float* beta, float* y, long ldy, float* mean,
+                                    float* rstd, long M, int N, int act, void* stream);
+
 /* ---- row-fused layers of the imagination step (csrc/fusedops.hip) -----------------------------------
  * dv3_onehot_linear_ln_fwd: pre[M,N] = base + sum_s WT[s*D + idx[m][s]] + sum_a x2[m][a] * WT[S*D + a], then
  * y = act(LN(pre)) (y == NULL: pre only).  The Linear + LayerNorm + SiLU whose input is cat[stoch.flat, tail]

@@ -943,6 +943,49 @@ def test_im2col_then_gemm_is_the_same_pad_stride2_conv(ops, N, H, Ci, Co):
     assert_close(y.view(N, OH, OH, Co), ref, tol=2e-5, what="conv via im2col")
 
 
+@pytest.mark.parametrize("M,S,N,A", [(16, 32, 512, 6), (5, 7, 256, 0), (32, 32, 1024, 18)])
+@pytest.mark.parametrize("use_rng", [False, True])
+def test_sample_plus_img_in_launch_equals_sample_then_gather(ops, M, S, N, A, use_rng):
+    """Observe scan: dv3_onehot_sample_linear_ln_fwd == dv3_onehot_sample_fwd_ex (with the reset blend of the next
+    step) followed by dv3_onehot_linear_ln_fwd, bit for bit (samples, indices, blended state, LayerNorm output)."""
+    g = torch.Generator().manual_seed(M + S + N)
+    D = 32
+    logit = dev(torch.randn(M, S, D, generator=g) * 2)
+    q = dev(torch.empty(M, S, D).exponential_(1.0, generator=g).clamp_min(1e-20))
+    nf = dev((torch.rand(M, generator=g) < 0.3).float())
+    init_idx = torch.randint(0, D, (S,), generator=g)
+    init = dev(F.one_hot(init_idx, D).float().view(-1))
+    init_idx = init_idx.int().cuda()
+    WT = dev(torch.randn(S * D + A, N, generator=g) / math.sqrt(S))
+    x2 = dev(torch.randn(M, A, generator=g)) if A else None
+    gamma, beta = dev(1 + 0.1 * torch.randn(N, generator=g)), dev(0.1 * torch.randn(N, generator=g))
+    forced = torch.randint(0, D, (M * S,), dtype=torch.int32, generator=g).cuda()
+    res = []
+    for fused in (False, True):
+        for force in (False, True):
+            rng = ops.RngStream("cuda", seed=11)
+            out, nout = torch.empty(M, S, D, device="cuda"), torch.empty(M, S, D, device="cuda")
+            idx = torch.empty(M * S, dtype=torch.int32, device="cuda")
+            nidx = torch.empty(M, S, dtype=torch.int32, device="cuda")
+            pre, y = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+            mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+            flips = torch.zeros(1, dtype=torch.int32, device="cuda")
+            kw = dict(noise=None if use_rng else q, rng=rng if use_rng else None, idx=idx,
+                      forced=forced if force else None, flips=flips if force else None)
+            if fused:
+                ops.onehot_sample_linear_ln(logit, out, next_first=nf, init=init, init_idx=init_idx, next_out=nout,
+                                            next_idx=nidx.view(-1), WT=WT, x2=x2, pre=pre, gamma=gamma, beta=beta, y=y,
+                                            mean=mean, rstd=rstd, **kw)
+            else:
+                ops.onehot_sample(logit, out, next_blend=(nf, init, nout, init_idx, nidx.view(-1)), **kw)
+                ops.onehot_linear_ln(nidx, D, WT, pre, x2=x2, gamma=gamma, beta=beta, y=y, mean=mean, rstd=rstd)
+            res.append((out, nout, idx, nidx, pre, y, mean, rstd, flips, torch.tensor(rng.cursor)))
+    for a, b in ((res[0], res[2]), (res[1], res[3])):
+        for x, z in zip(a, b):
+            assert torch.equal(x.cpu(), z.cpu())
+    assert torch.equal(res[3][2].cpu(), forced.cpu())
+
+
 @pytest.mark.parametrize("B,S,D,De", [(16, 32, 32, 512), (5, 3, 7, 20), (32, 32, 32, 1024)])
 def test_obs_carry_st_bwd_equals_blend_bwd_then_st_bwd(ops, B, S, D, De):
     """Reverse observe scan: the fused carry + straight-through launch == dv3_obs_blend_bwd followed by

@@ -1,9 +1,8 @@
 #!/bin/bash
-mkdir -p gpurun_out/r03d
-timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py tests/test_path_gpu.py tests/test_fullsize_gpu.py -q -m gpu -x -k "carry or path or fullsize or update or world" > gpurun_out/r03d/t.log 2>&1; tail -3 gpurun_out/r03d/t.log
-for r in 1 2; do
-DV3_FUSE_CARRY=0 timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/r03d/bench_off.log 2>&1 || exit 1
-echo "off: $(tail -1 gpurun_out/r03d/bench_off.log | cut -c130-175)"
-timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/r03d/bench_on.log 2>&1 || exit 1
-echo "on : $(tail -1 gpurun_out/r03d/bench_on.log | cut -c130-175)"
-done
+mkdir -p gpurun_out/r03f
+timeout -k 10 900 python -m pytest tests/ -q -m gpu -x > gpurun_out/r03f/t.log 2>&1; tail -4 gpurun_out/r03f/t.log
+timeout -k 10 400 python bench.py > gpurun_out/r03f/bench.log 2>&1 || exit 1
+tail -1 gpurun_out/r03f/bench.log | cut -c1-220
+timeout -k 10 300 python tools/imag_bench.py --json gpurun_out/r03f/imag.json > gpurun_out/r03f/imag.log 2>&1; grep -v amdgpu gpurun_out/r03f/imag.log | head -16
+timeout -k 10 300 python tools/policy_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/r03f/policy.log
+timeout -k 10 200 python tools/scan_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/r03f/scan.log

@@ -45,9 +45,9 @@ def replay_ms(fn, reps=20):
 def main():
     from dv3hip import ops
 
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    name = args[0] if args else "cfg2"
     out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    args = [a for a in sys.argv[1:] if not a.startswith("--") and a != out_json]
+    name = args[0] if args else "cfg2"
     cfg, wm, beh = Hh.build_models(name)
     s = common.SHAPES[name]
     H = s["H"]
