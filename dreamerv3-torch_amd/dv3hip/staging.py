@@ -2,9 +2,14 @@
 
 The reference expands the uint8 replay images to float32 on the host and copies 50 MB per cfg-2 batch
 synchronously from pageable memory (models.py:176-180).  Here the batch crosses PCIe as it is stored --
-uint8 images (12.6 MB), bool flags as one byte -- from PINNED buffers on a copy stream, double-buffered, so
-that the copy of batch i+1 overlaps the update on batch i; /255, -0.5 and the float conversion happen inside
-the first kernels that read the data (dv3_image_to_f32 / dv3_mse_image).
+uint8 images (12.6 MB), bool flags as one byte -- from PINNED buffers, double-buffered (the host fills batch i+1
+while the update on batch i runs); /255, -0.5 and the float conversion happen inside the first kernels that read
+the data (dv3_image_to_f32 / dv3_mse_image).
+
+The uploads go onto the update's OWN stream by default (overlap=False): measured at cfg 2 (tools/_stage_probe.py, r02)
+an update with its batch resident takes 18.13 ms, 18.45 ms with the upload in front of it on the same stream, and
+19.49 ms with the upload on a second stream "overlapping" the previous update -- a second active queue slows the
+update's ~3000 dependent launches by more than the 0.3 ms the upload costs.
 """
 from __future__ import annotations
 
@@ -21,7 +26,7 @@ class BatchStager:
     passed the point where the previous occupant was handed out (recorded with an event), so a captured graph
     may still be reading batch i while batch i+1 is in flight."""
 
-    def __init__(self, device, depth: int = 2):
+    def __init__(self, device, depth: int = 2, overlap: bool = False):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("BatchStager stages into HBM: it needs a GPU device")
@@ -31,7 +36,8 @@ class BatchStager:
         self._h2d = [None] * depth   # event on the copy stream: the slot's previous upload has finished
         self._last = None
         self._i = 0
-        self._copy = torch.cuda.Stream(self.device)
+        # overlap=False: uploads go onto the consumer's own stream (serialised with the update, no second queue)
+        self._copy = torch.cuda.Stream(self.device) if overlap else None
 
     @staticmethod
     def _wire_dtype(k: str, v: np.ndarray):
@@ -50,12 +56,13 @@ class BatchStager:
             rel.record(cur)
             self._free[self._last] = rel
         slot = self._slots[self._i]
-        if self._free[self._i] is not None:
-            self._copy.wait_event(self._free[self._i])
+        copy = self._copy if self._copy is not None else cur
+        if self._free[self._i] is not None and copy is not cur:
+            copy.wait_event(self._free[self._i])
         if self._h2d[self._i] is not None:
             self._h2d[self._i].synchronize()  # the pinned side is rewritten below: its last upload must be over
         out = {}
-        with torch.cuda.stream(self._copy):
+        with torch.cuda.stream(copy):
             for k, v in batch.items():
                 v = np.asarray(v)
                 wd = self._wire_dtype(k, v)
@@ -70,9 +77,10 @@ class BatchStager:
                 dev.copy_(host, non_blocking=True)
                 out[k] = dev
             done = torch.cuda.Event()
-            done.record(self._copy)
+            done.record(copy)
         self._h2d[self._i] = done
-        cur.wait_event(done)
+        if copy is not cur:
+            cur.wait_event(done)
         # flags / scalars become float32 on the device (what the kernels take); images stay uint8
         res = {k: (t if k == "image" else t.to(torch.float32)) for k, t in out.items()}
         self._last = self._i

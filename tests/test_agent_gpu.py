@@ -234,13 +234,15 @@ def test_video_pred_matches_reference_golden(name):
     assert abs(got[0] - ref[0]) <= 1e-4 * ref[1] and abs(got[1] - ref[1]) <= 1e-4 * ref[1]
 
 
-def test_batch_stager_matches_direct_upload_and_trains():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_batch_stager_matches_direct_upload_and_trains(overlap):
     """Pinned double-buffered staging: what lands in HBM is the host batch (uint8 images, flags
-    as float), slots are recycled, and an update on a staged batch equals the update on the host batch."""
+    as float), slots are recycled, and an update on a staged batch equals the update on the host batch -- with the
+    uploads on the update's own stream (default) and on a separate copy stream."""
     from dv3hip.staging import BatchStager
 
     name = "tiny"
-    stager = BatchStager("cuda:0", depth=2)
+    stager = BatchStager("cuda:0", depth=2, overlap=overlap)
     batches = [common.make_batch(name, seed=s) for s in range(3)]
     for b in batches:  # 3 batches through 2 slots
         d = stager.stage(b)
