@@ -639,6 +639,7 @@ struct WgradParams {
   float* dw;        // packed [Co][(ky,kx,ci)] scratch, accumulated with atomics
   int Nimg, H, W, Ci, Co;
   int tiles_m, tiles_n, splits, chunk;  // chunk: reduction rows per split (multiple of BK)
+  int xcd_group;  // grid = tiles * ceil8(splits): all output tiles of one K-split run on ONE XCD (see the kernel)
 };
 
 // dw_packed[co][(ky,kx,ci)] += sum_m dy[m][co] * x[n,2oy+ky-1,2ox+kx-1,ci]
@@ -653,7 +654,21 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradParams p) {
   WgradB bop{p.x, p.H, p.W, p.Ci, OH, OW, rows, 16 * p.Ci, FastDiv::make(OW), FastDiv::make(OH),
              FastDiv::make(p.Ci), FastDiv::make(4 * p.Ci)};
   const int tiles = p.tiles_m * p.tiles_n;
-  const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+  // Every output tile of a K-split reads the same dy rows and the same x pixels.  Workgroup ids go round-robin to the
+  // 8 XCDs, so with tile-major ids each XCD's L2 pulls EVERY split's operands (8 copies through the fabric, and at
+  // crafter widths gigabytes from HBM: 12 column tiles x 2 row tiles re-read each chunk).  xcd_group: the tiles of
+  // split s all get ids = s mod 8 (mod 8), dispatched back to back -- they run together on one XCD and share the
+  // chunk through its L2.
+  int tile, split;
+  if (p.xcd_group) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    split = (j / tiles) * 8 + xcd;
+    tile = j % tiles;
+    if (split >= p.splits) return;  // padding workgroups of the last round (whole workgroup, before any barrier)
+  } else {
+    tile = blockIdx.x % tiles;
+    split = blockIdx.x / tiles;
+  }
   const int m0 = (tile / p.tiles_n) * TS::BM, n0 = (tile % p.tiles_n) * TS::BN;
   const long kb = (long)split * p.chunk;
   long ke = kb + p.chunk;
@@ -853,6 +868,7 @@ __global__ __launch_bounds__(256) void convT_s2_c3_kernel(const float* __restric
 }
 
 using C128 = TileShape<2, 2, 2, 2, 16>;    // 128 x 128
+using C128K32 = TileShape<2, 2, 2, 2, 32>;  // 128 x 128, BK 32 (twice the loads in flight per barrier)
 using C64 = TileShape<2, 2, 1, 1, 32>;     // 64 x 64
 using C128x32 = TileShape<4, 1, 1, 1, 32>;  // 128 x 32 (narrow channel counts)
 using C32x64S = TileShape<1, 2, 1, 1, 64, 2>;  // 32 x 64, K split over two wave-groups (first/last layer wgrad)
@@ -1144,7 +1160,8 @@ extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* 
   if (!coarse || !fine || !dw || !dw_packed || Cfine <= 0 || Ccoarse <= 0 || !pow2_spatial(H, W)) return DV3_ERR_ARG;
   const long rows = (long)Nimg * (H / 2) * (W / 2);
   if (rows > 0x7fffffffL - 4096) return DV3_ERR_ARG;
-  WgradParams p{coarse, fine, dw_packed, Nimg, H, W, Cfine, Ccoarse, 0, 0, 0, 0};
+  WgradParams p{coarse, fine, dw_packed, Nimg, H, W, Cfine, Ccoarse, 0, 0, 0, 0, 0};
+  static const int env_group = getenv("DV3_WGRAD_XCD") ? atoi(getenv("DV3_WGRAD_XCD")) : 1;
   auto go = [&](auto ts, long target_wgs) {
     using TS = decltype(ts);
     p.tiles_m = (Ccoarse + TS::BM - 1) / TS::BM;
@@ -1160,11 +1177,27 @@ extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* 
     splits = (rows + chunk - 1) / chunk;
     p.splits = (int)splits;
     p.chunk = (int)chunk;
-    if (Cfine == 3) hipLaunchKernelGGL((conv_wgrad_kernel<TS, true>), dim3((unsigned)(tiles * splits)), dim3(kThreads), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<TS, false>), dim3((unsigned)(tiles * splits)), dim3(kThreads), 0, (hipStream_t)stream, p);
+    p.xcd_group = (env_group && splits >= 8) ? 1 : 0;
+    const long gsplits = p.xcd_group ? (splits + 7) / 8 * 8 : splits;
+    if (Cfine == 3) hipLaunchKernelGGL((conv_wgrad_kernel<TS, true>), dim3((unsigned)(tiles * gsplits)), dim3(kThreads), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<TS, false>), dim3((unsigned)(tiles * gsplits)), dim3(kThreads), 0, (hipStream_t)stream, p);
   };
   // 128x128 tiles halve the L2->LDS traffic per flop; they need >= 128 output channels to fill their rows
-  if (Ccoarse >= 128) go(C128{}, 512);
+  // Measured (tools/conv_bench.py --only conv_wgrad; r02): BK 32 instead of 16 (twice the gathers in flight per
+  // barrier) -4 % at cfg-2 sizes, -8 % at crafter widths; more K-splits at long reductions (a split of ~3k rows
+  // instead of 512 workgroups in total): 4096 frames, depth 96: 15.0 / 10.4 / 10.3 ms -> 8.6 / 6.5 / 6.7 ms
+  // (41-60 -> 72-95 TFLOP/s) -- with 1-2 workgroups per CU each marching through 12k rows of HBM-resident operands
+  // the gathers' latency was exposed; cfg-2 sizes are unchanged by the rule (their splits are already ~1k rows).
+  static const int env_k32 = getenv("DV3_WGRAD_K32") ? atoi(getenv("DV3_WGRAD_K32")) : 1;
+  static const int env_wgs = getenv("DV3_WGRAD_WGS") ? atoi(getenv("DV3_WGRAD_WGS")) : 0;
+  auto target128 = [&](int bm, int bn) {
+    if (env_wgs > 0) return (long)env_wgs;
+    const long tiles = (long)((Ccoarse + bm - 1) / bm) * ((16 * Cfine + bn - 1) / bn);
+    const long by_rows = tiles * ((rows + 3071) / 3072);
+    return by_rows > 512 ? by_rows : 512L;
+  };
+  if (Ccoarse >= 128 && env_k32) go(C128K32{}, target128(128, 128));
+  else if (Ccoarse >= 128) go(C128{}, target128(128, 128));
   else if (Ccoarse <= 32) go(C32x64S{}, 1024);  // image-side layers: 32 output channels x 48 (ky,kx,ci) columns
   else go(C64{}, 1024);
   const long total = 16L * Ccoarse * Cfine;

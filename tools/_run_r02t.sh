@@ -1,8 +1,11 @@
 #!/bin/bash
-mkdir -p gpurun_out/r03f
-timeout -k 10 900 python -m pytest tests/ -q -m gpu -x > gpurun_out/r03f/t.log 2>&1; tail -4 gpurun_out/r03f/t.log
-timeout -k 10 400 python bench.py > gpurun_out/r03f/bench.log 2>&1 || exit 1
-tail -1 gpurun_out/r03f/bench.log | cut -c1-220
-timeout -k 10 300 python tools/imag_bench.py --json gpurun_out/r03f/imag.json > gpurun_out/r03f/imag.log 2>&1; grep -v amdgpu gpurun_out/r03f/imag.log | head -16
-timeout -k 10 300 python tools/policy_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/r03f/policy.log
-timeout -k 10 200 python tools/scan_bench.py 2>&1 | grep -v amdgpu | tee gpurun_out/r03f/scan.log
+mkdir -p gpurun_out/r03h
+timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "conv" > gpurun_out/r03h/t.log 2>&1; tail -2 gpurun_out/r03h/t.log
+timeout -k 10 300 python tools/conv_bench.py --only conv_wgrad --no-dense --depth 96 --frames 4096 --reps 3 2>&1 | grep "wgrad"
+timeout -k 10 300 python tools/conv_bench.py --only conv_wgrad --no-dense 2>&1 | grep "wgrad"
+timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/r03h/bench.log 2>&1 || exit 1
+tail -1 gpurun_out/r03h/bench.log | cut -c95-180
+timeout -k 10 500 python bench.py --no-cpu-baseline --config cfg4 --steps 5 --warmup 2 > gpurun_out/r03h/bench_cfg4.log 2>&1 || exit 1
+tail -1 gpurun_out/r03h/bench_cfg4.log | cut -c95-180
+timeout -k 10 500 python bench.py --no-cpu-baseline --config cfg5 --steps 5 --warmup 2 > gpurun_out/r03h/bench_cfg5.log 2>&1 || exit 1
+tail -1 gpurun_out/r03h/bench_cfg5.log | cut -c95-180

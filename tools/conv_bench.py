@@ -42,11 +42,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--depth", type=int, default=32, help="cnn_depth: 32 (cfg 2) or 96 (cfg 4 / 5)")
+    ap.add_argument("--only", default="", help="substring of the op name (conv_s2, convT_s2, conv_wgrad)")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-GEMM comparison column")
     args = ap.parse_args()
     N = args.frames
     r = lambda *s: torch.randn(*s, device="cuda")
     # (H = fine grid side, C fine, C coarse): encoder conv fine->coarse; decoder convT coarse->fine
-    layers = [(64, 3, 32), (32, 32, 64), (16, 64, 128), (8, 128, 256)]
+    d = args.depth
+    layers = [(64, 3, d), (32, d, 2 * d), (16, 2 * d, 4 * d), (8, 4 * d, 8 * d)]
     print(f"{'op':28s} {'M':>8s} {'N':>5s} {'K':>5s} {'us':>8s} {'TF/s':>7s} | dense GEMM us  TF/s")
     for H, Cf, Cc in layers:
         fine, coarse = r(N, H, H, Cf), r(N, H // 2, H // 2, Cc)
@@ -54,13 +58,15 @@ def main():
         flops = 2.0 * N * (H // 2) ** 2 * Cc * 16 * Cf
 
         def dense(M, Nn, K, tA=False):
+            if args.no_dense:
+                return 0.0, 0.0
             A = r(K, M) if tA else r(M, K)
             B = r(K, Nn) if tA else r(Nn, K)
             C = torch.zeros(M, Nn, device="cuda")
             us = graph_us(lambda: ops.gemm(A, B, C, transA=tA, transB=not tA, accumulate=tA), args.reps)
             return us, 2.0 * M * Nn * K / us / 1e6
 
-        if Cf != 3:
+        if Cf != 3 and (not args.only or args.only in "conv_s2 convT_s2"):
             wp = torch.empty(Cc, 16 * Cf, device="cuda")
             ops.pack_conv_weight(w, wp, transposed=False)
             y = torch.empty_like(coarse)
@@ -75,6 +81,8 @@ def main():
             M, Nn, K = N * (H // 2) ** 2, Cf, 4 * Cc
             du, dt = dense(M * 4, Nn, K)
             print(f"convT_s2 {H // 2:2d}x{H // 2:<2d} {Cc:3d}->{Cf:<3d} (x4 cls) {M:8d} {Nn:5d} {K:5d} {us:8.1f} {flops / us / 1e6:7.1f} | {du:8.1f} {dt:7.1f}")
+        if args.only and args.only not in "conv_wgrad":
+            continue
         dw = torch.zeros(Cc, Cf, 4, 4, device="cuda")
         us = graph_us(lambda: ops.conv_s2_wgrad(coarse, fine, dw), args.reps)
         M, Nn, K = Cc, 16 * Cf, N * (H // 2) ** 2
