@@ -101,6 +101,41 @@ def oracle_update(name, threads=None, piecewise=False):
     return res
 
 
+def oracle_updates(name, n_updates):
+    """n consecutive full updates in the oracle (fresh batch and noise per update: seeds 0, 1, ...), carrying the three
+    Adam states, the slow critic and the return-normalisation EMA across them as dreamer.py:192-208 does.
+    -> dict(losses=[(model_loss, actor_loss, value_loss)], params_after, ema)."""
+    cfg = common.path_config(name)
+    p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in common.make_weights(name).items()}
+    wkeys = [k for k in p if k.split(".")[0] in WM_PREFIXES]
+    akeys = [k for k in p if k.startswith("actor.")]
+    vkeys = [k for k in p if k.startswith("value.")]
+    mk = lambda keys: dict(step=0, m=[torch.zeros_like(p[k]) for k in keys], v=[torch.zeros_like(p[k]) for k in keys])
+    st_w, st_a, st_v = mk(wkeys), mk(akeys), mk(vkeys)
+    ema = torch.zeros(2)
+    losses = []
+    for i in range(n_updates):
+        n = {k: torch.from_numpy(v) for k, v in common.make_noise(name, seed=i).items()}
+        data = common.make_batch(name, seed=i)
+        out = O.wm_forward(cfg, p, data, n["q_prior"], n["q_post"])
+        grads = torch.autograd.grad(out["model_loss"], [p[k] for k in wkeys])
+        start = {k: v.detach() for k, v in out["post"].items()}
+        with torch.no_grad():
+            O.clip_and_adam([p[k] for k in wkeys], list(grads), st_w, lr=1e-4, eps=1e-8, clip=1000.0)
+            for k in list(p):
+                if k.startswith("value."):
+                    sk = "_slow_value." + k[len("value."):]
+                    p[sk].copy_(cfg.slow_target_fraction * p[k] + (1 - cfg.slow_target_fraction) * p[sk])
+        bout = O.behavior_forward(cfg, p, start, n["act"], n["q_img"], ema)
+        ga = torch.autograd.grad(bout["actor_loss"], [p[k] for k in akeys], retain_graph=True)
+        gv = torch.autograd.grad(bout["value_loss"], [p[k] for k in vkeys])
+        with torch.no_grad():
+            O.clip_and_adam([p[k] for k in akeys], list(ga), st_a, lr=3e-5, eps=1e-5, clip=100.0)
+            O.clip_and_adam([p[k] for k in vkeys], list(gv), st_v, lr=3e-5, eps=1e-5, clip=100.0)
+        losses.append(tuple(float(x.detach()) for x in (out["model_loss"], bout["actor_loss"], bout["value_loss"])))
+    return dict(losses=losses, params_after={k: v.detach() for k, v in p.items()}, ema=ema.clone())
+
+
 def onehot_index(x):
     """one-hot [..., D] -> int32 class index [...] (contiguous, for teacher forcing)."""
     return x.detach().argmax(-1).to(torch.int32).contiguous()

@@ -30,9 +30,9 @@ def adam_close(got, ref, lr, what):
     assert float((d > 1e-6).double().mean()) <= 1e-3, f"{what}: {float((d > 1e-6).double().mean()):.3e} outliers"
 
 
-def gpu_noise(name):
+def gpu_noise(name, seed=0):
     s = common.SHAPES[name]
-    n = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(name).items()}
+    n = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(name, seed=seed).items()}
     wm_noise = dict(q_prior=n["q_prior"].contiguous(), q_post=n["q_post"].contiguous())
     im_noise = dict(act=Hh.to_time_major_rows(n["act"], s["B"], s["T"]).contiguous(),
                     q_img=Hh.to_time_major_rows(n["q_img"], s["B"], s["T"]).contiguous())
@@ -149,3 +149,38 @@ def test_imagination_on_identical_weights(tiny_run):
     params = dict(beh.named_parameters())
     for k, g in list(exp["actor_grads0"].items()) + list(exp["value_grads0"].items()):
         close(params[k].grad, g, tol=3e-4, what="grad " + k)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_onehot"])
+def test_three_consecutive_updates_match_the_oracle(name):
+    """State carried ACROSS updates (dreamer.py:192-208): Adam moments and step counts of the three optimizers, the
+    slow critic's EMA, the return-normalisation EMA, and every reused workspace -- three updates on three different
+    batches / noise draws against the oracle doing the same: the losses of each update and the parameters after the
+    third.  (Later updates see parameters that already differ by Adam's rounding: tolerances as in adam_close, scaled
+    by the number of steps.)"""
+    n_up = 3
+    exp = Hh.oracle_updates(name, n_up)
+    cfg, wm, beh = Hh.build_models(name)
+    for i in range(n_up):
+        wm_noise, im_noise = gpu_noise(name, seed=i)
+        post, _, m1 = wm._train(common.make_batch(name, seed=i), noise=wm_noise)
+        post = {k: v.clone() for k, v in post.items()}
+        m2 = beh._train(post, None, noise=im_noise)[-1]
+        ml, al, vl = exp["losses"][i]
+        tol = 1e-5 if i == 0 else 5e-4
+        close(torch.tensor(float(m1["model_loss"])), torch.tensor(ml), tol=tol, what=f"model_loss, update {i}")
+        close(torch.tensor(float(m2["actor_loss"])), torch.tensor(al), tol=tol, what=f"actor_loss, update {i}")
+        close(torch.tensor(float(m2["value_loss"])), torch.tensor(vl), tol=tol, what=f"value_loss, update {i}")
+    close(beh.ema_vals, exp["ema"], tol=1e-4, what="return EMA after three updates")
+    sd = {**{k: v for k, v in wm.state_dict().items()}, **{k: v for k, v in beh.state_dict().items()}}
+    checked = 0
+    for k, ref in exp["params_after"].items():
+        got = sd.get(k)
+        if got is None:
+            continue
+        lr = 1e-4 if k.split(".")[0] in Hh.WM_PREFIXES else 3e-5
+        d = (got.detach().cpu().double() - ref.double()).abs()
+        assert float(d.max()) <= 2.1 * lr * n_up, f"{k}: max {float(d.max()):.3e}"
+        assert float((d > 3e-6).double().mean()) <= 5e-3, f"{k}: {float((d > 3e-6).double().mean()):.3e} outliers"
+        checked += 1
+    assert checked >= 20
