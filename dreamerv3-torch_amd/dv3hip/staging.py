@@ -6,7 +6,7 @@ uint8 images (12.6 MB), bool flags as one byte -- from PINNED buffers, double-bu
 while the update on batch i runs); /255, -0.5 and the float conversion happen inside the first kernels that read
 the data (dv3_image_to_f32 / dv3_mse_image).
 
-The uploads go onto the update's OWN stream by default (overlap=False): measured at cfg 2 (tools/_stage_probe.py, r02)
+The uploads go onto the update's OWN stream by default (overlap=False): measured at cfg 2 (tools/stage_probe.py, r02)
 an update with its batch resident takes 18.13 ms, 18.45 ms with the upload in front of it on the same stream, and
 19.49 ms with the upload on a second stream "overlapping" the previous update -- a second active queue slows the
 update's ~3000 dependent launches by more than the 0.3 ms the upload costs.
