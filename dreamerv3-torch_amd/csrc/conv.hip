@@ -1087,12 +1087,19 @@ extern "C" int dv3_conv_s2_fwd(const float* x, const float* w_packed, float* y, 
   // the k-major 32x32x2 tiles / the register-direct kernel
   static const int env_l16 = getenv("DV3_CONV_L16") ? atoi(getenv("DV3_CONV_L16")) : 1;
   if (env_l16 && (Ci % 32) == 0 && Co >= 64 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0) {
-    const bool wide = (env_l16 != 3) && (Co % 128) == 0;
-    const int bn = wide ? 128 : 64;
-    p.tiles_m = (int)((M + 63) / 64);
+    // column tile: 128 where Co is a multiple of it, 96 for the crafter widths (96 / 192: cnn_depth 96), else 64; row
+    // tile 128 once that still gives every CU ~2 workgroups.  Measured (tools/conv_bench.py, us): 4096 frames depth 96,
+    // 192->384: 64x128 5519, 128x128 5221; 1024 frames 64->128: 179 -> 169, 128->256 (256 tiles of 128x128): 159 -> 168.
+    const int bn = (env_l16 != 3 && (Co % 128) == 0) ? 128 : (env_l16 != 3 && (Co % 96) == 0) ? 96 : 64;
+    const bool big = bn != 64 && (env_l16 == 4 || (env_l16 == 1 && ((M + 127) / 128) * (Co / bn) >= 448));
+    const int bm = big ? 128 : 64;
+    p.tiles_m = (int)((M + bm - 1) / bm);
     p.tiles_n = (Co + bn - 1) / bn;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-    if (wide) hipLaunchKernelGGL((conv_s2_l16_kernel<64, 128, false>), grid, dim3(256), 0, s, p);
+    if (bn == 128 && big) hipLaunchKernelGGL((conv_s2_l16_kernel<128, 128, false>), grid, dim3(256), 0, s, p);
+    else if (bn == 128) hipLaunchKernelGGL((conv_s2_l16_kernel<64, 128, false>), grid, dim3(256), 0, s, p);
+    else if (bn == 96 && big) hipLaunchKernelGGL((conv_s2_l16_kernel<128, 96, false>), grid, dim3(256), 0, s, p);
+    else if (bn == 96) hipLaunchKernelGGL((conv_s2_l16_kernel<64, 96, false>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_s2_l16_kernel<64, 64, false>), grid, dim3(256), 0, s, p);
     return (int)hipGetLastError();
   }
@@ -1128,14 +1135,21 @@ extern "C" int dv3_convT_s2_fwd(const float* x, const float* w_packed, const flo
   // measured (tools/conv_bench.py, 1024 frames, us): Co 32: direct 247 / l16 278; Co 64: 195 / 195; Co 128: 183 / 178 --
   // the register-direct kernels keep the narrow layers, the LDS tile takes Co >= 128 (and everything wider, which
   // used to run on the k-major 32x32x2 tiles)
-  if (env_l16 && (Ci % 32) == 0 && Co >= (env_l16 == 2 ? 32 : 128) && ((uintptr_t)x % 16) == 0 &&
-      ((uintptr_t)w_packed % 16) == 0) {
-    const int bn = (Co % 128) == 0 && env_l16 != 3 ? 128 : (Co % 64) == 0 ? 64 : 32;
-    const int bm = bn == 32 ? 128 : 64;
+  // (r02, crafter widths, 4096 frames: Co 96 on a 128x96 tile against the register-direct kernel)
+  const bool co96 = (Co % 96) == 0 && (Co % 128) != 0 && env_l16 != 3;
+  if (env_l16 && (Ci % 32) == 0 && (Co >= (env_l16 == 2 ? 32 : 128) || (co96 && env_l16 != 5)) &&
+      ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0) {
+    const int bn = (Co % 128) == 0 && env_l16 != 3 ? 128 : co96 ? 96 : (Co % 64) == 0 ? 64 : 32;
+    // rows per class M; 128-row tiles once the four classes together still give every CU ~2 workgroups
+    const bool big = (bn == 128 || bn == 96) && ((M + 127) / 128) * (Co / bn) * 4 >= 448;
+    const int bm = (bn == 32 || big) ? 128 : 64;
     p.tiles_m = (int)((M + bm - 1) / bm);
     p.tiles_n = (Co + bn - 1) / bn;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 4);
-    if (bn == 128) hipLaunchKernelGGL((conv_s2_l16_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
+    if (bn == 128 && big) hipLaunchKernelGGL((conv_s2_l16_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
+    else if (bn == 128) hipLaunchKernelGGL((conv_s2_l16_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
+    else if (bn == 96 && big) hipLaunchKernelGGL((conv_s2_l16_kernel<128, 96, true>), grid, dim3(256), 0, s, p);
+    else if (bn == 96) hipLaunchKernelGGL((conv_s2_l16_kernel<64, 96, true>), grid, dim3(256), 0, s, p);
     else if (bn == 64) hipLaunchKernelGGL((conv_s2_l16_kernel<64, 64, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_s2_l16_kernel<128, 32, true>), grid, dim3(256), 0, s, p);
     return (int)hipGetLastError();

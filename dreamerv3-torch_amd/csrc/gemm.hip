@@ -869,7 +869,8 @@ static bool l16_ok(const GemmParams& p, int transA, int transB) {
          (!p.A2 || ((uintptr_t)p.A2 % 16) == 0) && ((uintptr_t)p.B % 16) == 0;
 }
 
-// tile shape: measured (gpurun_out/r02t), 1024 x 1536 x 1024: 32x64 35.9 us (768 workgroups, three per CU: one
+// tile shape: measured (tools/gemm_bench.py; 128 x 128: 4096^3 1059 us = 130 TFLOP/s against 1228 on the k-major
+// 128x128x32 tile), 1024 x 1536 x 1024: 32x64 35.9 us (768 workgroups, three per CU: one
 // workgroup's barrier / LDS-fill bubbles are covered by the MFMAs of the others), 64x96 39.8 (one per CU), 64x64 44.3,
 // register-direct 44.0; 4096^3: 64x64 and 64x96 115-119 TFLOP/s.  Prefetch distance 1 / 2 / 4 measured equal.
 static void launch_l16(const GemmParams& p0, int force, hipStream_t s) {
@@ -877,7 +878,8 @@ static void launch_l16(const GemmParams& p0, int force, hipStream_t s) {
   auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   int sel = wgs(64, 64) >= 512 ? 2 : 3;  // explicit tile 11: 64 x 64 from 512 tiles up, else 32 x 64
   if (force >= 1 && force <= 3) sel = force;
-  const int bm = sel == 3 ? 32 : 64, bn = sel == 1 ? 96 : 64;
+  if (force == 4) sel = 4;  // 128 x 128 (tile 15)
+  const int bm = sel == 3 ? 32 : sel == 4 ? 128 : 64, bn = sel == 1 ? 96 : sel == 4 ? 128 : 64;
   p.tiles_m = (p.M + bm - 1) / bm;
   p.tiles_n = (p.N + bn - 1) / bn;
   pick_xcd_grid(p);
@@ -887,6 +889,7 @@ static void launch_l16(const GemmParams& p0, int force, hipStream_t s) {
   do {                                                                                          \
     if (sel == 1) hipLaunchKernelGGL((gemm_l16_kernel<64, 96, PFV>), grid, block, 0, s, p);      \
     else if (sel == 2) hipLaunchKernelGGL((gemm_l16_kernel<64, 64, PFV>), grid, block, 0, s, p); \
+    else if (sel == 4) hipLaunchKernelGGL((gemm_l16_kernel<128, 128, PFV>), grid, block, 0, s, p); \
     else hipLaunchKernelGGL((gemm_l16_kernel<32, 64, PFV>), grid, block, 0, s, p);               \
   } while (0)
   if (pf == 2) DV3_L16_LAUNCH(2);
@@ -1198,10 +1201,10 @@ static int pick_tile(int M, int N, int K, int accumulate) {
   const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
   if (t64 <= 128) return 9;
   // y = x W^T by output size: see dv3hip/ops.py pick_gemm_tile for the measurements behind the thresholds
+  if ((long)((M + 127) / 128) * ((N + 127) / 128) >= 448) return 15;
   if (t64 < 512) return 14;
   if (t64 <= 1024) return 13;
-  if (t64 <= 2048 && N >= 3072) return 14;
-  if (t64 >= 4096 && N >= 4096 && (N % 96) == 0) return 12;
+  if (t64 <= 2048 && (N >= 3072 || N <= 512)) return 14;
   return legacy_tile(M, N);
 }
 
@@ -1239,7 +1242,7 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   }
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
-  int t = ((tile >= 0 && tile <= 6) || (tile >= 8 && tile <= 14)) ? tile : pick_tile(M, N, K, accumulate);
+  int t = ((tile >= 0 && tile <= 6) || (tile >= 8 && tile <= 15)) ? tile : pick_tile(M, N, K, accumulate);
   if (t >= 11 && tile < 0 && !l16_ok(p, transA, transB)) t = legacy_tile(M, N);
   if (t == 9 && tile < 0 && (transA || (A2 && (K1 % 16) != 0))) t = ((long)M * N <= 512L * 1024) ? 8 : 6;
   if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6 || t == 8)) t = 1;
@@ -1268,7 +1271,7 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   }
   if (t >= 11) {
     // k-contiguous LDS tiles, 16x16x4 MFMA: y = x W^T only, K and the segment edge on 32-k tile boundaries
-    // (11: tile shape by size; 12 / 13 / 14: 64x96 / 64x64 / 32x64)
+    // (11: tile shape by size; 12 / 13 / 14 / 15: 64x96 / 64x64 / 32x64 / 128x128)
     if (!l16_ok(p, transA, transB)) return DV3_ERR_ARG;
     launch_l16(p, t - 11, s);
     return (int)hipGetLastError();

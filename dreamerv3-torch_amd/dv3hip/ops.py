@@ -90,7 +90,7 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
 
 _TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2", 7: "narrowN",
                8: "32x32x64s4", 9: "direct32x64", 10: "directTN32x64", 11: "l16", 12: "l16_64x96", 13: "l16_64x64",
-               14: "l16_32x64"}
+               14: "l16_32x64", 15: "l16_128x128"}
 
 
 _TILE_TEMPLATES = {0: "2, 2, 2, 2, 16, 1", 1: "2, 2, 1, 1, 32, 1", 2: "1, 4, 1, 1, 32, 1", 4: "2, 2, 2, 2, 32, 1",
@@ -118,7 +118,8 @@ def kernel_symbol(key: str) -> str:
             return "void dv3::gemm_direct_tn_kernel<4, 1>(dv3::GemmParams)"
         if tile >= 11:
             return {12: "void dv3::gemm_l16_kernel<64, 96, 1, 0>(dv3::GemmParams)",
-                    13: "void dv3::gemm_l16_kernel<64, 64, 1, 0>(dv3::GemmParams)"}.get(
+                    13: "void dv3::gemm_l16_kernel<64, 64, 1, 0>(dv3::GemmParams)",
+                    15: "void dv3::gemm_l16_kernel<128, 128, 1, 0>(dv3::GemmParams)"}.get(
                         tile, "void dv3::gemm_l16_kernel<32, 64, 1, 0>(dv3::GemmParams)")
         return f"void dv3::gemm_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, {ta}, {tb}>(dv3::GemmParams)"
     m = re.match(r"conv_wgrad_kernel<([^,>]+)(,c3)?>", key)
@@ -163,8 +164,9 @@ def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
       t64 <= 128            register-direct 32 x 64 (9)                1024 x 512 x 512: 9.3 us vs 10.2 (l16)
       t64 <  512            k-contiguous LDS tile 32 x 64 (14)         1024 x 1536 x 1024: 35.9 vs 44.0 (9)
       512 <= t64 <= 1024    k-contiguous LDS tile 64 x 64 (13)         2048 x 1024 x 1024: 46.6 vs 54.7 (1); 4096 x 1024 x 1024: 87.6 vs 96.8 (4)
-      wide, t64 <= 2048     32 x 64 again (14)                         2048 x 3072 x 1536: 208 vs 254 (1)
-      N % 96 == 0, >= 4096  k-contiguous LDS tile 64 x 96 (12)         4096 x 12288 x 5120: 4286 vs 4395 (4)
+      wide / tall, <= 2048  32 x 64 again (14)                         2048 x 3072 x 1536: 208 vs 254 (1); 15360 x 512 x 512: 91 vs 97 (4)
+      >= 448 128x128 tiles  k-contiguous LDS tile 128 x 128 (15)       4096^3: 1059 us = 130 TFLOP/s (83 %) vs 1228 (4); 4096 x 12288 x 5120:
+                                                                       3891 (132 TFLOP/s) vs 4299 (12) / 4415 (4); 15360 x 512 x 1536: 224 vs 259 (4)
       otherwise             k-major 32x32x2 tiles, 64 x 64 (1) or 128 x 128 (4) by waves of workgroups."""
     if M <= 32:
         return 2
@@ -177,14 +179,14 @@ def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
         return _SMALL_TILE
     if _MID_TILE != 11:  # development switch: one tile for every mid-size shape
         return _MID_TILE if t64 <= 512 else _legacy_tile(M, N)
+    if -(-M // 128) * -(-N // 128) >= 448:
+        return 15
     if t64 < 512:
         return 14
     if t64 <= 1024:
         return 13
-    if t64 <= 2048 and N >= 3072:
+    if t64 <= 2048 and (N >= 3072 or N <= 512):
         return 14
-    if t64 >= 4096 and N >= 4096 and N % 96 == 0:
-        return 12
     return _legacy_tile(M, N)
 
 

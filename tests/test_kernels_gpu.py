@@ -122,12 +122,12 @@ def test_gemm_register_direct_kernel(ops, M, N, K1, K2, transB, acc):
 @pytest.mark.parametrize("M,N,K1,K2", [(1024, 1536, 512, 512), (1024, 1024, 512, 0), (1024, 512, 512, 1024),
                                        (2048, 1536, 1024, 0), (77, 100, 64, 32), (130, 200, 96, 0), (4096, 3072, 2048, 0)])
 @pytest.mark.parametrize("acc", [False, True])
-@pytest.mark.parametrize("tile", [11, 12, 13, 14])
+@pytest.mark.parametrize("tile", [11, 12, 13, 14, 15])
 def test_gemm_kcontiguous_lds_tile(ops, M, N, K1, K2, acc, tile):
-    """tiles 11-14 (both operands k-contiguous in LDS, ds_read_b128 fragments, 16x16x4 MFMA): y = [A | A2] W^T + b,
-    accumulate, ragged M / N; 11 picks the tile shape by size, 12 / 13 / 14 force 64x96 / 64x64 / 32x64."""
-    if tile != 11 and M * N * (K1 + K2) > 5e9:
-        pytest.skip("large shape: default tile only")
+    """tiles 11-15 (both operands k-contiguous in LDS, ds_read_b128 fragments, 16x16x4 MFMA): y = [A | A2] W^T + b,
+    accumulate, ragged M / N; 11 picks the tile shape by size, 12 / 13 / 14 / 15 force 64x96 / 64x64 / 32x64 / 128x128."""
+    if tile not in (11, 15) and M * N * (K1 + K2) > 5e9:
+        pytest.skip("large shape: default and 128x128 tiles only")
     g = torch.Generator().manual_seed(M + N + K1 + K2)
     K = K1 + K2
     A, A2 = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g)

@@ -1,0 +1,5 @@
+mkdir -p gpurun_out/r03k
+timeout -k 10 1000 python -m pytest tests/ -q -m gpu > gpurun_out/r03k/t.log 2>&1; tail -4 gpurun_out/r03k/t.log
+timeout -k 10 400 python bench.py > gpurun_out/r03k/bench.log 2>&1 || exit 1
+tail -1 gpurun_out/r03k/bench.log | cut -c1-200
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

@@ -36,6 +36,11 @@ SHAPES = [
     (1024, 512, 512, 0, 0, "imagine dgrad"),
     (1024, 1536, 1024, 0, 0, "imagine dgrad gru"),
     (4096, 4096, 4096, 0, 1, "square 4k"),
+    (15360, 512, 512, 0, 1, "beh: head L1 fwd"),
+    (14336, 512, 512, 0, 0, "beh: head dgrad [K][N]"),
+    (14336, 1024, 512, 0, 0, "beh: head dgrad to stoch [K][N]"),
+    (14336, 1024, 512, 0, 1, "beh: head dgrad to stoch, W^T"),
+    (15360, 255, 512, 0, 1, "beh: head out fwd"),
     (2048, 3072, 1536, 0, 1, "big: cfg3 GRU fwd"),
     (2048, 1024, 1024, 0, 1, "big: cfg3 stacked"),
     (4096, 1024, 1024, 0, 1, "big: cfg5 hidden"),
