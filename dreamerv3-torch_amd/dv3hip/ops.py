@@ -147,6 +147,20 @@ def l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb) -> bool:
             and (A2 is None or (lda2 % 4 == 0 and A2.data_ptr() % 16 == 0)))
 
 
+_BT_MIN_FLOPS = float(os.environ.get("DV3_BT_MIN_FLOPS", "1.4e10"))
+_BT = {}
+
+
+def _bt_scratch(K, N, device):
+    """[N, K] scratch for the transposed copy of a [K, N] operand (persistent: graph replays read the same buffer)."""
+    key = (K, N, str(device))
+    t = _BT.get(key)
+    if t is None:
+        t = torch.empty(N, K, device=device, dtype=F32)
+        _BT[key] = t
+    return t
+
+
 def _legacy_tile(M: int, N: int) -> int:
     """Tile for y = x W^T shapes the k-contiguous LDS kernel cannot take (alignment, K % 32, transposed operands)."""
     t64 = -(-M // 64) * -(-N // 64)
@@ -228,6 +242,13 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         gemm(A, Bv1, C, transA=False, transB=transB, bias=bias, accumulate=accumulate, tile=tile)
         gemm(A2, Bv2, C, transA=False, transB=transB, accumulate=accumulate or True, tile=tile)
         return C
+    if (tile < 0 and not transA and not transB and A2 is None and 2.0 * M * N * K >= _BT_MIN_FLOPS
+            and pick_gemm_tile(M, N, False, K) >= 11 and K % 32 == 0 and lda % 4 == 0 and A.data_ptr() % 16 == 0):
+        # big data gradient against a [K][N] weight: a transposed copy (2 K N floats of traffic, < 1 % of the product)
+        # puts it in the y = x B^T form of the k-contiguous LDS tiles (14336 x 1024 x 512: 155 + 5 us against 177)
+        Bt = _bt_scratch(K, N, B.device)
+        transpose2d(B, Bt)
+        return gemm(A, Bt, C, transA=False, transB=True, bias=bias, accumulate=accumulate)
     if tile < 0:
         tile = pick_gemm_tile(M, N, bool(transA), K)
         if M <= 32 and not transA:

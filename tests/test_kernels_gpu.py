@@ -140,6 +140,21 @@ def test_gemm_kcontiguous_lds_tile(ops, M, N, K1, K2, acc, tile):
     assert_close(C, want, what=f"gemm tile {tile}")
 
 
+@pytest.mark.parametrize("acc", [False, True])
+def test_gemm_big_data_gradient_takes_the_transposed_copy_path(ops, acc):
+    """C (+)= A @ B with B [K][N] and >= 1.4e10 flops: ops.gemm transposes B into scratch and runs the k-contiguous LDS
+    tile; B a row slice of a wider weight (as the heads pass it)."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 8192, 1024, 1024
+    A = torch.randn(M, K, generator=g)
+    Wfull = torch.randn(K + 64, N, generator=g) / math.sqrt(K)
+    C0 = torch.randn(M, N, generator=g)
+    C = dev(C0.clone())
+    Wd = dev(Wfull)
+    ops.gemm(dev(A), Wd[64:], C, transB=False, accumulate=acc)
+    assert_close(C, A @ Wfull[64:] + (C0 if acc else 0), tol=2e-5, what="big NN gemm")
+
+
 @pytest.mark.parametrize("M,n1,n2,K", [(1024, 512, 512, 1536), (200, 48, 80, 64), (77, 16, 100, 96)])
 def test_gemm_split_output(ops, M, n1, n2, K):
     """dv3_gemm_split_f32: one product, columns [0, n1) overwrite C, columns [n1, n1+n2) accumulate into a strided C2."""
