@@ -258,6 +258,13 @@ __device__ __forceinline__ void xcd_tile(const GemmParams& p, int id, int& tm, i
 
 static void pick_xcd_grid(GemmParams& p) {
   p.xcd_m = p.xcd_n = 0;
+  static const int env_xm = getenv("DV3_XCD_M") ? atoi(getenv("DV3_XCD_M")) : 0;  // development: force the grid
+  if (env_xm == -1) return;  // linear tile order
+  if (env_xm > 0 && 8 % env_xm == 0 && p.tiles_m % env_xm == 0 && p.tiles_n % (8 / env_xm) == 0) {
+    p.xcd_m = env_xm;
+    p.xcd_n = 8 / env_xm;
+    return;
+  }
   const double a = (double)p.M * p.K, b = (double)p.N * p.K;
   double best = 0.0;
   for (int xm = 8; xm >= 1; xm >>= 1) {
@@ -876,7 +883,8 @@ static bool l16_ok(const GemmParams& p, int transA, int transB) {
 static void launch_l16(const GemmParams& p0, int force, hipStream_t s) {
   GemmParams p = p0;
   auto wgs = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-  int sel = wgs(64, 64) >= 512 ? 2 : 3;  // explicit tile 11: 64 x 64 from 512 tiles up, else 32 x 64
+  // tile 11 / the split-output entry: by size, as pick_tile does (128 x 128 from 448 such tiles, 64 x 64 from 512, else 32 x 64)
+  int sel = wgs(128, 128) >= 448 ? 4 : wgs(64, 64) >= 512 ? 2 : 3;
   if (force >= 1 && force <= 3) sel = force;
   if (force == 4) sel = 4;  // 128 x 128 (tile 15)
   const int bm = sel == 3 ? 32 : sel == 4 ? 128 : 64, bn = sel == 1 ? 96 : sel == 4 ? 128 : 64;

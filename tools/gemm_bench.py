@@ -47,6 +47,7 @@ SHAPES = [
     (4096, 2048, 2048, 0, 1, "big: cfg5 stacked"),
     (4096, 6144, 3072, 0, 1, "big: cfg5 GRU fwd"),
     (4096, 12288, 5120, 0, 1, "big: cfg4 GRU fwd"),
+    (4096, 5120, 12288, 0, 1, "big: cfg4 GRU dgrad (W^T)"),
 ]
 
 
@@ -55,8 +56,9 @@ ZEROS = False
 
 def bench(M, N, K, tA, tB, tile, reps):
     dev = "cuda"
-    A = torch.randn((K, M) if tA else (M, K), device=dev)
-    B = torch.randn((N, K) if tB else (K, N), device=dev)
+    pad = int(os.environ.get("DV3_BENCH_PAD", "0"))  # extra floats per row (leading-dimension experiment)
+    A = torch.randn((K, M + pad) if tA else (M, K + pad), device=dev)[:, :(M if tA else K)]
+    B = torch.randn((N, K + pad) if tB else (K, N + pad), device=dev)[:, :(K if tB else N)]
     if ZEROS:  # clock check: zero operands draw less power, the chip holds a higher clock (MI355X_MICROARCH, DVFS)
         A.zero_()
         B.zero_()
