@@ -436,15 +436,30 @@ __global__ __launch_bounds__(kThreads) void convT_s2_kernel(ConvParams p) {
 // ~80 registers, so many waves per SIMD hide the gather latency.  Ci % 4 == 0.
 // grid = (ceil(M / 128), 4 parity classes), 4 waves per workgroup (4 consecutive 32-row groups).
 // ------------------------------------------------------------------------------------------------
+// The four parity classes of a transposed convolution read the SAME input pixels.  With the class as grid.y the chip
+// sweeps the whole input once per class (4 x the input through the fabric: convT_s2_direct<2> 656 MB per launch against
+// 200 MB algorithmic).  1-D grid instead: workgroup ids go round-robin to the 8 XCDs, so ids id, id+8, id+16, id+24
+// land on the same XCD back to back -- they are made the four classes of ONE pixel tile, which then comes out of that
+// XCD's L2 three times out of four.  grid.x = ceil8(tiles) * 4; returns false for the padding workgroups.
+__device__ __forceinline__ bool convT_tile_class(int tiles, int& tile, int& cls) {
+  const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+  cls = j & 3;
+  tile = (j >> 2) * 8 + xcd;
+  return tile < tiles;
+}
+static unsigned convT_grid(long tiles) { return (unsigned)((tiles + 7) / 8 * 8 * 4); }
+
 typedef float f32x4n __attribute__((ext_vector_type(4)));
 template <int RN>  // 16*RN output channels per wave
 __global__ __launch_bounds__(256) void convT_s2_direct_kernel(ConvParams p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 15, q = lane >> 4;
-  const int cls = blockIdx.y, py = cls >> 1, px = cls & 1;
   const long M = (long)p.Nimg * p.H * p.W;
+  int tile, cls;
+  if (!convT_tile_class((int)((M + 127) / 128), tile, cls)) return;
+  const int py = cls >> 1, px = cls & 1;
   const int K = 4 * p.Ci;
-  const long row0 = (long)blockIdx.x * 128 + wave * 32;
+  const long row0 = (long)tile * 128 + wave * 32;
   if (row0 >= M) return;
   const FastDiv dW = FastDiv::make(p.W), dH = FastDiv::make(p.H), dC = FastDiv::make(p.Ci);
   // the two rows (input pixels) this lane gathers for: row0 + 16 t + i
@@ -915,13 +930,17 @@ __global__ __launch_bounds__(256) void conv_s2_l16_kernel(ConvParams p) {
   const int i = lane & 15, q = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
   static_assert(WM * WN == 4, "four waves");
-  const int cls = TR ? blockIdx.y : 0, py = cls >> 1, px = cls & 1;
+  int cls = 0, lin = blockIdx.x;
+  if constexpr (TR) {
+    if (!convT_tile_class(p.tiles_m * p.tiles_n, lin, cls)) return;  // whole workgroup, before any barrier
+  }
+  const int py = cls >> 1, px = cls & 1;
   const int RH = TR ? p.H : (p.H >> 1), RW = TR ? p.W : (p.W >> 1);  // the grid of pixels the rows enumerate
   const long M = (long)p.Nimg * RH * RW;
   const int K = (TR ? 4 : 16) * p.Ci;
-  // an XCD owns a contiguous range of pixel tiles (its share of x is private to its L2; the weights are small)
-  int lin = blockIdx.x;
-  {
+  // conv: an XCD owns a contiguous range of pixel tiles (its share of x is private to its L2; the weights are small);
+  // convT: the four classes of a tile share an XCD (convT_tile_class)
+  if constexpr (!TR) {
     const int tiles = p.tiles_m * p.tiles_n;
     if ((p.tiles_m & 7) == 0) lin = (blockIdx.x & 7) * (tiles >> 3) + (blockIdx.x >> 3);
   }
@@ -1145,7 +1164,7 @@ extern "C" int dv3_convT_s2_fwd(const float* x, const float* w_packed, const flo
     const int bm = (bn == 32 || big) ? 128 : 64;
     p.tiles_m = (int)((M + bm - 1) / bm);
     p.tiles_n = (Co + bn - 1) / bn;
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 4);
+    const dim3 grid(convT_grid((long)p.tiles_m * p.tiles_n));
     if (bn == 128 && big) hipLaunchKernelGGL((conv_s2_l16_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
     else if (bn == 128) hipLaunchKernelGGL((conv_s2_l16_kernel<64, 128, true>), grid, dim3(256), 0, s, p);
     else if (bn == 96 && big) hipLaunchKernelGGL((conv_s2_l16_kernel<128, 96, true>), grid, dim3(256), 0, s, p);
@@ -1156,7 +1175,7 @@ extern "C" int dv3_convT_s2_fwd(const float* x, const float* w_packed, const flo
   }
   static const int env_direct = getenv("DV3_CONVT_DIRECT") ? atoi(getenv("DV3_CONVT_DIRECT")) : 128;
   if ((Ci & 3) == 0 && Co <= env_direct && Co <= 128) {
-    const dim3 grid((unsigned)((M + 127) / 128), 4);
+    const dim3 grid(convT_grid((M + 127) / 128));
     if (Co <= 32) hipLaunchKernelGGL(convT_s2_direct_kernel<2>, grid, dim3(256), 0, s, p);
     else if (Co <= 64) hipLaunchKernelGGL(convT_s2_direct_kernel<4>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(convT_s2_direct_kernel<8>, grid, dim3(256), 0, s, p);
