@@ -632,17 +632,18 @@ static void launch_direct(const GemmParams& p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-tiled y = [A|A2] W^T (+ bias) for the 1024-row imagination GEMMs, v_mfma_f32_16x16x4_f32 with BOTH operands
-// kept k-contiguous in LDS: a lane's MFMA fragment for four consecutive k steps is one ds_read_b128 (row i = l & 15,
-// k = 16 kk + 4 (l >> 4) .. +3) and a staged float4 is one ds_write_b128 -- a quarter of the LDS instructions of
-// the k-major 32x32x2 tile engine, and every loaded element is reused BN/32 (A) or BM/32 (B) times from registers.
+// LDS-tiled y = [A|A2] W^T (+ bias) -- tiles 11-15: the mid-size and large products of the path (the 1024-row
+// imagination GEMMs up to 4096 x 12288 x 5120) -- v_mfma_f32_16x16x4_f32 with BOTH operands kept k-contiguous in LDS:
+// a lane's MFMA fragment for four consecutive k steps is one ds_read_b128 (row i = l & 15, k = 16 kk + 4 (l >> 4) .. +3)
+// and a staged float4 is one ds_write_b128 -- a quarter of the LDS instructions of the k-major 32x32x2 tile engine (no
+// transposing ds_write_b32), and every loaded element is reused BN/32 (A) or BM/32 (B) times from registers.
 // Row stride 40 floats: the 16 lanes a ds_read_b128 serves together (0-3, 12-15, 20-27 | ...) then cover all 64
 // banks exactly once (i*40 + 4q mod 64 is a permutation of the 16 four-bank windows), and the 8 lanes of a
 // ds_write_b128 group write 128 contiguous bytes.  One workgroup = 4 waves (2 x 2) = one BM x BN tile, BK = 32,
 // double-buffered: global loads of K-tile t+1 are issued before the MFMAs of tile t, one barrier per K-tile.
-// The tile is chosen so that M/BM * N/BN = 256 workgroups = one per CU (1024 x 1536: 64 x 96; 1024 x 1024: 64 x 64;
-// 1024 x 512: 32 x 64).  Tile order: xcd_tile (each XCD owns a block of tiles chosen by operand bytes).
-// Requires K % 32 == 0, K1 % 32 == 0, lda/lda2/ldb % 4 == 0 (checked by the launcher).
+// Tile shapes 32x64 / 64x64 / 64x96 / 128x128, picked by output size (launch_l16 / pick_tile; measurements in
+// dv3hip/ops.py pick_gemm_tile).  Tile order: xcd_tile (each XCD owns a block of tiles chosen by operand bytes).
+// Requires K % 32 == 0, K1 % 32 == 0, lda/lda2/ldb % 4 == 0, 16-byte aligned operands (l16_ok).
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int PF, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_l16_kernel(GemmParams p) {
@@ -676,8 +677,8 @@ __global__ __launch_bounds__(256) void gemm_l16_kernel(GemmParams p) {
     const int col = n0 + ((tid + 256 * j) >> 3);
     bsrc[j] = p.B + (long)(col < p.N ? col : 0) * p.ldb + c4;
   }
-  // PF register sets: the loads of K-tile t + PF are in flight while tile t is multiplied (a tile's MFMAs take
-  // ~0.6 us, a load from the Infinity Cache / HBM under contention longer: PF = 1 leaves the wave waiting on it)
+  // PF register sets: the loads of K-tile t + PF are in flight while tile t is multiplied.  Measured (1024-row
+  // shapes): PF 2 / 4 equal PF 1 within noise -- the default; the template parameter stays for longer-latency operands.
   f32x4 ra[PF][NA], rb[PF][NB];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto gload = [&](f32x4 (&xa)[NA], f32x4 (&xb)[NB], int k0) {

@@ -106,7 +106,7 @@ class Dreamer(nn.Module):
 
     def _train(self, data):
         """dreamer.py:192-208.  One update = WorldModel._train + ImagBehavior._train on the updated world model; the
-        launch sequence is replayed from hipGraphs (dv3hip.graph.UpdateRunner, ~3000 launches per update) once it has
+        launch sequence is replayed from hipGraphs (dv3hip.graph.UpdateRunner, ~1750 launches per update) once it has
         been captured, with the host batch staged through pinned buffers (dv3hip.staging.BatchStager).  Metrics stay
         on the device: one running sum per key, read back once per log interval (see _flush_metrics)."""
         if self._runner is None:

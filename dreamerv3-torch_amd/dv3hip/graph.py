@@ -1,6 +1,6 @@
-"""hipGraph replay of the training update.
+"""hipGraph replay of the training update and of the acting step.
 
-One update is ~3000 short kernel launches (two sequential scans of small GEMMs); launched eagerly
+One update is ~1750 short kernel launches (two sequential scans of small GEMMs); launched eagerly
 from Python it is host-bound.  The launch sequence is static (fixed shapes, no host reads, RNG and
 Adam step counters live in device memory), so it is captured once into HIP graphs and replayed:
 MI355X-native replacement for the reference's (inert) torch.compile switch (dreamer.py:75-79).
@@ -96,11 +96,12 @@ class UpdateRunner:
 
 class PolicyRunner:
     """hipGraph replay of the acting step (Dreamer._policy: preprocess -> encoder -> obs_step -> actor; SURVEY 8(f)
-    N1).  Eager, the step is ~50 launches and host-bound (0.8 ms at 1-16 envs); its launch sequence is static for a
-    given (number of envs, training flag), so it is captured once per signature and replayed.  Inputs are copied into
-    static device buffers (host observations through one pinned staging buffer per key), the outputs of a replay are
-    packed into one buffer inside the graph and leave it with a single clone, so what the caller gets back are fresh
-    tensors exactly as from the eager path."""
+    N1).  Eager, the step is ~45 launches and host-bound (0.8 ms at 1-16 envs); its launch sequence is static for a
+    given (number of envs, training flag), so it is captured once per signature and replayed (0.23 ms at 1 env).  Inputs
+    are copied into static device buffers (host observations through one pinned staging buffer per key), the outputs
+    of a replay are packed into one buffer by one launch inside the graph and leave it with a single clone, so what
+    the caller gets back are fresh tensors exactly as from the eager path; the carried state the graph reads IS that
+    packed buffer, so a caller that hands back what it was given pays no copy-in (see _is_last_output)."""
 
     def __init__(self, agent):
         self.agent = agent
