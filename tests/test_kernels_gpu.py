@@ -140,6 +140,56 @@ def test_gemm_kcontiguous_lds_tile(ops, M, N, K1, K2, acc, tile):
     assert_close(C, want, what=f"gemm tile {tile}")
 
 
+def test_gemm_kcontiguous_lds_tiles_random_shapes(ops):
+    """Seeded sweep of ragged shapes over the five k-contiguous LDS tile shapes (11-15): M, N anything, K and the
+    [A | A2] seam multiples of 32, operands as row slices of wider buffers, accumulate on and off."""
+    rs = np.random.RandomState(123)
+    g = torch.Generator().manual_seed(123)
+    for case in range(40):
+        tile = int(rs.choice([11, 12, 13, 14, 15]))
+        M, N = int(rs.randint(1, 400)), int(rs.randint(1, 400))
+        K1, K2 = 32 * int(rs.randint(1, 9)), 32 * int(rs.randint(0, 5))
+        K = K1 + K2
+        pad = 4 * int(rs.randint(0, 3))
+        Aw, A2w = torch.randn(M, K1 + pad, generator=g), torch.randn(M, max(K2, 4) + pad, generator=g)
+        W = torch.randn(N, K, generator=g) / math.sqrt(K)
+        b = torch.randn(N, generator=g) if rs.rand() < 0.5 else None
+        acc = bool(rs.rand() < 0.5)
+        C0 = torch.randn(M, N, generator=g)
+        C = dev(C0.clone())
+        Ad, A2d = dev(Aw)[:, :K1], (dev(A2w)[:, :K2] if K2 else None)
+        ops.gemm(Ad, dev(W), C, A2=A2d, bias=None if b is None else dev(b), accumulate=acc, tile=tile)
+        want = torch.cat([Aw[:, :K1], A2w[:, :K2]], -1) @ W.t() + (0 if b is None else b) + (C0 if acc else 0)
+        assert_close(C, want, what=f"case {case}: tile {tile} {M}x{N}x{K1}+{K2} pad {pad} acc {acc}")
+
+
+def test_conv_kcontiguous_lds_tiles_random_shapes(ops):
+    """Seeded sweep for the implicit-GEMM convolutions on the k-contiguous LDS tiles (conv_s2 with Co >= 64, convT_s2
+    with Co >= 128 or a multiple of 96; Ci a multiple of 32) against torch's conv2d / conv_transpose2d."""
+    rs = np.random.RandomState(7)
+    g = torch.Generator().manual_seed(7)
+    for case in range(14):
+        Nimg, H = int(rs.randint(1, 6)), int(rs.choice([2, 4, 8, 16]))
+        Ci = 32 * int(rs.randint(1, 5))
+        Co = int(rs.choice([64, 72, 96, 128, 160, 192, 256, 384]))
+        x = torch.randn(Nimg, Ci, H, H, generator=g)
+        w = torch.randn(Co, Ci, 4, 4, generator=g) / math.sqrt(16 * Ci)
+        wp = torch.empty(Co, 16 * Ci, device="cuda")
+        ops.pack_conv_weight(dev(w), wp, transposed=False)
+        y = torch.empty(Nimg, H // 2, H // 2, Co, device="cuda")
+        ops.conv_s2_fwd(dev(nhwc(x)), wp, y, Ci=Ci, Co=Co)
+        assert_close(y, nhwc(F.conv2d(F.pad(x, [1, 1, 1, 1]), w, None, 2)), what=f"case {case}: conv {Nimg}x{H} {Ci}->{Co}")
+        if Co >= 128 or Co % 96 == 0:
+            wt = torch.randn(Ci, Co, 4, 4, generator=g) / math.sqrt(4 * Ci)
+            bias = torch.randn(Co, generator=g)
+            wpt = torch.empty(4, Co, 4 * Ci, device="cuda")
+            ops.pack_conv_weight(dev(wt), wpt, transposed=True)
+            yt = torch.empty(Nimg, 2 * H, 2 * H, Co, device="cuda")
+            ops.convT_s2_fwd(dev(nhwc(x)), wpt, yt, Ci=Ci, Co=Co, bias=dev(bias), out_add=0.5)
+            assert_close(yt, nhwc(F.conv_transpose2d(x, wt, bias, 2, padding=1) + 0.5),
+                         what=f"case {case}: convT {Nimg}x{H} {Ci}->{Co}")
+
+
 @pytest.mark.parametrize("acc", [False, True])
 def test_gemm_big_data_gradient_takes_the_transposed_copy_path(ops, acc):
     """C (+)= A @ B with B [K][N] and >= 1.4e10 flops: ops.gemm transposes B into scratch and runs the k-contiguous LDS
