@@ -147,7 +147,7 @@ def l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb) -> bool:
             and (A2 is None or (lda2 % 4 == 0 and A2.data_ptr() % 16 == 0)))
 
 
-_BT_MIN_FLOPS = float(os.environ.get("DV3_BT_MIN_FLOPS", "1.4e10"))
+_BT_MIN_FLOPS = float(os.environ.get("DV3_BT_MIN_FLOPS", "7e9"))
 _BT = {}
 
 
@@ -245,7 +245,8 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
     if (tile < 0 and not transA and not transB and A2 is None and 2.0 * M * N * K >= _BT_MIN_FLOPS
             and pick_gemm_tile(M, N, False, K) >= 11 and K % 32 == 0 and lda % 4 == 0 and A.data_ptr() % 16 == 0):
         # big data gradient against a [K][N] weight: a transposed copy (2 K N floats of traffic, < 1 % of the product)
-        # puts it in the y = x B^T form of the k-contiguous LDS tiles (14336 x 1024 x 512: 155 + 5 us against 177)
+        # puts it in the y = x B^T form of the k-contiguous LDS tiles (14336 x 1024 x 512: 155 + 5 us against 177;
+        # 14336 x 512 x 512: 81 + 5 against 100)
         Bt = _bt_scratch(K, N, B.device)
         transpose2d(B, Bt)
         return gemm(A, Bt, C, transA=False, transB=True, bias=bias, accumulate=accumulate)
