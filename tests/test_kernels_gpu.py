@@ -140,6 +140,24 @@ def test_gemm_kcontiguous_lds_tile(ops, M, N, K1, K2, acc, tile):
     assert_close(C, want, what=f"gemm tile {tile}")
 
 
+@pytest.mark.parametrize("M", [33, 50, 64, 100, 128])
+@pytest.mark.parametrize("transB", [True, False])
+@pytest.mark.parametrize("acc", [False, True, "atomic"])
+def test_gemm_few_row_kernel_up_to_128_rows(ops, M, transB, acc):
+    """tile 3 beyond 32 rows (row blocks of 32 over grid.z: the acting step's encoder on a few images, replay batch 64):
+    [A | A2] concat, bias, both weight layouts, accumulate modes."""
+    g = torch.Generator().manual_seed(M)
+    K1, K2, N = 96, 48, 300
+    A, A2 = torch.randn(M, K1, generator=g), torch.randn(M, K2, generator=g)
+    W = torch.randn((N, K1 + K2) if transB else (K1 + K2, N), generator=g) / math.sqrt(K1 + K2)
+    b = torch.randn(N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    C = dev(C0.clone())
+    ops.gemm(dev(A), dev(W), C, A2=dev(A2), transB=transB, bias=dev(b), accumulate=acc, tile=3)
+    want = torch.cat([A, A2], -1) @ (W.t() if transB else W) + b + (C0 if acc else 0)
+    assert_close(C, want, what=f"few-row gemm, {M} rows")
+
+
 def test_gemm_kcontiguous_lds_tiles_random_shapes(ops):
     """Seeded sweep of ragged shapes over the five k-contiguous LDS tile shapes (11-15): M, N anything, K and the
     [A | A2] seam multiples of 32, operands as row slices of wider buffers, accumulate on and off."""
