@@ -818,6 +818,105 @@ __global__ __launch_bounds__(256) void conv_s2_c3_kernel(const float* __restrict
   }
 }
 
+// The same layer on the matrix cores: K = 48 = 4 kernel rows x 12 floats, and the 12 floats (kx, c) of one kernel row are
+// CONTIGUOUS in the NHWC image, so a pixel's A row is four 48-byte segments.  A workgroup stages 128 output pixels
+// x 48 (k-contiguous, stride 52) and the CW x 48 weights (reordered to (ky, kx, c) on the way in) in LDS and runs the
+// ds_read_b128 / v_mfma_f32_16x16x4_f32 scheme of gemm_l16_kernel: 3 chunks of 16 k, 48 MFMAs per wave at CW = 32.
+// One thread per (pixel, kernel-row pair); only the first / last output column of an image row needs the scalar path.
+template <int CW>
+__global__ __launch_bounds__(256) void conv_s2_c3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ y, int Nimg, int H, int W,
+                                                              int accumulate) {
+  constexpr int LD = 52, TN = CW / 16;
+  __shared__ __attribute__((aligned(16))) float As[128 * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[CW * LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int OH = H / 2, OW = W / 2;
+  const long total = (long)Nimg * OH * OW;
+  const long p0 = (long)blockIdx.x * 128;
+  for (int e = tid; e < CW * 48; e += 256) {  // w[co][c][ky][kx] -> Bs[co][ky*12 + kx*3 + c]
+    const int co = e / 48, r = e - co * 48;
+    const int c = r >> 4, ky = (r >> 2) & 3, kx = r & 3;
+    Bs[co * LD + ky * 12 + kx * 3 + c] = w[e];
+  }
+  {
+    const int pl = tid >> 1, kyb = (tid & 1) * 2;
+    const long p = p0 + pl;
+    const bool pv = p < total;
+    const long pc = pv ? p : 0;
+    const int ox = (int)(pc % OW);
+    const long t = pc / OW;
+    const int oy = (int)(t % OH);
+    const long n = t / OH;
+    const bool edge = (ox == 0) || (ox == OW - 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ky = kyb + kk;
+      const int iy = 2 * oy - 1 + ky;
+      const bool rowok = pv && iy >= 0 && iy < H;
+      float* dst = &As[pl * LD + ky * 12];
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0;
+      if (rowok) {
+        const float* row = x + ((n * H + iy) * W) * 3;
+        if (!edge) {
+          const float* src = row + (2 * ox - 1) * 3;
+          v0 = *reinterpret_cast<const f32x4u*>(src);
+          v1 = *reinterpret_cast<const f32x4u*>(src + 4);
+          v2 = *reinterpret_cast<const f32x4u*>(src + 8);
+        } else {
+          float tmp[12];
+#pragma unroll
+          for (int j = 0; j < 12; ++j) {
+            const int ix = 2 * ox - 1 + j / 3;
+            tmp[j] = (ix >= 0 && ix < W) ? row[ix * 3 + j % 3] : 0.f;
+          }
+          v0 = (f32x4){tmp[0], tmp[1], tmp[2], tmp[3]};
+          v1 = (f32x4){tmp[4], tmp[5], tmp[6], tmp[7]};
+          v2 = (f32x4){tmp[8], tmp[9], tmp[10], tmp[11]};
+        }
+      }
+      *reinterpret_cast<f32x4*>(dst) = v0;
+      *reinterpret_cast<f32x4*>(dst + 4) = v1;
+      *reinterpret_cast<f32x4*>(dst + 8) = v2;
+    }
+  }
+  __syncthreads();
+  f32x4 acc[2][TN];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    f32x4 af[2], bf[TN];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const f32x4*>(&As[(wave * 32 + 16 * a + i) * LD + 16 * c + 4 * q]);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&Bs[(16 * b + i) * LD + 16 * c + 4 * q]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][g], bf[b][g], acc[a][b], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long p = p0 + wave * 32 + 16 * a + 4 * q + r;
+        if (p < total) {
+          float* o = y + p * CW + 16 * b + i;
+          const float v = acc[a][b][r];
+          *o = accumulate ? (*o + v) : v;
+        }
+      }
+}
+
 // y[n,2y2+py,2x2+px,co<3] = sum_{a,b,ci<CW} x[n,y2+py-a,x2+px-b,ci] * w[ci][co][1-py+2a][1-px+2b] + bias + add
 // (ConvTranspose2d CW -> 3).  One thread per input-grid pixel computes its 2x2 output block.
 template <int CW>
@@ -1250,6 +1349,13 @@ extern "C" int dv3_conv_s2_c3_fwd(const float* x, const float* w, float* y, int 
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 16384) blocks = 16384;
   hipStream_t s = (hipStream_t)stream;
+  static const int env_mfma = getenv("DV3_C3_MFMA") ? atoi(getenv("DV3_C3_MFMA")) : 1;
+  if (env_mfma && (CW == 32 || CW == 96) && total < 0x7fffffffL * 64) {
+    const dim3 grid((unsigned)((total + 127) / 128));
+    if (CW == 32) hipLaunchKernelGGL((conv_s2_c3_mfma_kernel<32>), grid, dim3(256), 0, s, x, w, y, Nimg, H, W, accumulate);
+    else hipLaunchKernelGGL((conv_s2_c3_mfma_kernel<96>), grid, dim3(256), 0, s, x, w, y, Nimg, H, W, accumulate);
+    return (int)hipGetLastError();
+  }
   if (CW == 32) hipLaunchKernelGGL((conv_s2_c3_kernel<32>), dim3(blocks), dim3(256), 0, s, x, w, y, Nimg, H, W, accumulate);
   else if (CW == 96) hipLaunchKernelGGL((conv_s2_c3_kernel<96>), dim3(blocks), dim3(256), 0, s, x, w, y, Nimg, H, W, accumulate);
   else return DV3_ERR_ARG;
