@@ -144,6 +144,37 @@ def phase_timers(wm, beh, data, H, t_upd_ms, reps=10):
             "imagine_fwd_gflop": gflop, "imagine_fwd_tflops": gflop / t_img}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one per GPU, with the
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment torch.distributed.run would give them (the seam is the
+    reference's single optimizer step, tools.py:765-768: one all-reduce per optimizer).  Runs BEFORE anything in this
+    process initialises the GPU; rank 0 prints the JSON line; the exit code is the first non-zero child code."""
+    import socket
+    import subprocess
+
+    ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if n > ndev and os.environ.get("DV3_DIST_BACKEND", "nccl") != "gloo":
+        print(f"[bench] --gpus {n} but only {ndev} device(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        code = p.wait()
+        if code != 0 and rc == 0:
+            rc = code
+            for q in procs:  # a dead rank would leave the others waiting in a collective
+                if q.poll() is None:
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,11 +186,16 @@ def main():
     ap.add_argument("--by-shape", action="store_true", help="roofline leg: key GEMM launches by (M,N,K) too")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))  # one child process per GPU; nothing has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: a line for fewer ranks than asked is never printed")
+    if world > torch.cuda.device_count() and os.environ.get("DV3_DIST_BACKEND", "nccl") != "gloo":
+        raise SystemExit(f"--gpus {world} but {torch.cuda.device_count()} device(s) visible (RCCL needs one device per "
+                         "rank; DV3_DIST_BACKEND=gloo rehearses the N>1 path on fewer)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X hot path has no CPU implementation")
     dev_index = local_rank % max(1, torch.cuda.device_count())
@@ -317,7 +353,8 @@ def main():
         units = world * B * T * H
         out = {
             "metric": METRIC, "value": units * args.steps / elapsed, "unit": "imagination-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() if world > 1 else None), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{name}: {WORKLOADS.get(name, name)}, RSSM deter={shape['deter']} hidden="

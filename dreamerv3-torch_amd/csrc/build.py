@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build libdv3hip.so (gfx950 only) in-tree with hipcc.
 
-    python dreamerv3-torch_amd/csrc/build.py [--force]
+    python dreamerv3-torch_amd/csrc/build.py [--force] [--dev]
 
 Sources: every *.hip in this directory.  Output: ../dv3hip/libdv3hip.so (git-ignored; it
 travels to the GPU box with the gpurun snapshot).  Objects are cached under ./_obj and
@@ -30,7 +30,12 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
+    """dev=True: -DDV3_DEV_SWITCHES (the DV3_* A/B switches of tools/*_bench.py become live) into libdv3hip_dev.so,
+    which dv3hip._lib loads only when DV3HIP_LIB points at it."""
+    global OUT, OBJ
+    if dev:
+        OUT, OBJ = OUT.replace("libdv3hip.so", "libdv3hip_dev.so"), os.path.join(HERE, "_obj_dev")
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(HERE, "*.hip")))
     hdrs = glob.glob(os.path.join(HERE, "*.h")) + glob.glob(
@@ -47,7 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         s, o = job
-        cmd = [cc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [cc] + FLAGS + (["-DDV3_DEV_SWITCHES"] if dev else []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr}")
@@ -73,4 +78,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, dev="--dev" in sys.argv)

@@ -1203,7 +1203,7 @@ extern "C" int dv3_conv_s2_fwd(const float* x, const float* w_packed, float* y, 
   const long tiles128 = ((M + 127) / 128) * ((Co + 127) / 128);
   // measured (tools/conv_bench.py, 1024 frames, us): 32->64 213 -> 193, 64->128 196 -> 163, 128->256 207 -> 159 against
   // the k-major 32x32x2 tiles / the register-direct kernel
-  static const int env_l16 = getenv("DV3_CONV_L16") ? atoi(getenv("DV3_CONV_L16")) : 1;
+  static const int env_l16 = DV3_ENV_INT("DV3_CONV_L16", 1);
   if (env_l16 && (Ci % 32) == 0 && Co >= 64 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0) {
     // column tile: 128 where Co is a multiple of it, 96 for the crafter widths (96 / 192: cnn_depth 96), else 64; row
     // tile 128 once that still gives every CU ~2 workgroups.  Measured (tools/conv_bench.py, us): 4096 frames depth 96,
@@ -1221,7 +1221,7 @@ extern "C" int dv3_conv_s2_fwd(const float* x, const float* w_packed, float* y, 
     else hipLaunchKernelGGL((conv_s2_l16_kernel<64, 64, false>), grid, dim3(256), 0, s, p);
     return (int)hipGetLastError();
   }
-  static const int env_direct = getenv("DV3_CONV_DIRECT") ? atoi(getenv("DV3_CONV_DIRECT")) : 64;
+  static const int env_direct = DV3_ENV_INT("DV3_CONV_DIRECT", 64);
   if ((Ci & 3) == 0 && Co <= env_direct && Co <= 128) {
     const dim3 grid((unsigned)((M + 127) / 128));
     if (Co <= 32) hipLaunchKernelGGL(conv_s2_direct_kernel<2>, grid, dim3(256), 0, s, p);
@@ -1249,7 +1249,7 @@ extern "C" int dv3_convT_s2_fwd(const float* x, const float* w_packed, const flo
     p.tiles_n = (Co + TS::BN - 1) / TS::BN;
     hipLaunchKernelGGL((convT_s2_kernel<TS>), dim3(p.tiles_m * p.tiles_n, 4), dim3(kThreads), 0, s, p);
   };
-  static const int env_l16 = getenv("DV3_CONVT_L16") ? atoi(getenv("DV3_CONVT_L16")) : 1;
+  static const int env_l16 = DV3_ENV_INT("DV3_CONVT_L16", 1);
   // measured (tools/conv_bench.py, 1024 frames, us): Co 32: direct 247 / l16 278; Co 64: 195 / 195; Co 128: 183 / 178 --
   // the register-direct kernels keep the narrow layers, the LDS tile takes Co >= 128 (and everything wider, which
   // used to run on the k-major 32x32x2 tiles)
@@ -1272,7 +1272,7 @@ extern "C" int dv3_convT_s2_fwd(const float* x, const float* w_packed, const flo
     else hipLaunchKernelGGL((conv_s2_l16_kernel<128, 32, true>), grid, dim3(256), 0, s, p);
     return (int)hipGetLastError();
   }
-  static const int env_direct = getenv("DV3_CONVT_DIRECT") ? atoi(getenv("DV3_CONVT_DIRECT")) : 128;
+  static const int env_direct = DV3_ENV_INT("DV3_CONVT_DIRECT", 128);
   if ((Ci & 3) == 0 && Co <= env_direct && Co <= 128) {
     const dim3 grid(convT_grid((M + 127) / 128));
     if (Co <= 32) hipLaunchKernelGGL(convT_s2_direct_kernel<2>, grid, dim3(256), 0, s, p);
@@ -1293,7 +1293,7 @@ extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* 
   const long rows = (long)Nimg * (H / 2) * (W / 2);
   if (rows > 0x7fffffffL - 4096) return DV3_ERR_ARG;
   WgradParams p{coarse, fine, dw_packed, Nimg, H, W, Cfine, Ccoarse, 0, 0, 0, 0, 0};
-  static const int env_group = getenv("DV3_WGRAD_XCD") ? atoi(getenv("DV3_WGRAD_XCD")) : 1;
+  static const int env_group = DV3_ENV_INT("DV3_WGRAD_XCD", 1);
   auto go = [&](auto ts, long target_wgs) {
     using TS = decltype(ts);
     p.tiles_m = (Ccoarse + TS::BM - 1) / TS::BM;
@@ -1320,8 +1320,8 @@ extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* 
   // instead of 512 workgroups in total): 4096 frames, depth 96: 15.0 / 10.4 / 10.3 ms -> 8.6 / 6.5 / 6.7 ms
   // (41-60 -> 72-95 TFLOP/s) -- with 1-2 workgroups per CU each marching through 12k rows of HBM-resident operands
   // the gathers' latency was exposed; cfg-2 sizes are unchanged by the rule (their splits are already ~1k rows).
-  static const int env_k32 = getenv("DV3_WGRAD_K32") ? atoi(getenv("DV3_WGRAD_K32")) : 1;
-  static const int env_wgs = getenv("DV3_WGRAD_WGS") ? atoi(getenv("DV3_WGRAD_WGS")) : 0;
+  static const int env_k32 = DV3_ENV_INT("DV3_WGRAD_K32", 1);
+  static const int env_wgs = DV3_ENV_INT("DV3_WGRAD_WGS", 0);
   auto target128 = [&](int bm, int bn) {
     if (env_wgs > 0) return (long)env_wgs;
     const long tiles = (long)((Ccoarse + bm - 1) / bm) * ((16 * Cfine + bn - 1) / bn);
@@ -1349,7 +1349,7 @@ extern "C" int dv3_conv_s2_c3_fwd(const float* x, const float* w, float* y, int 
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 16384) blocks = 16384;
   hipStream_t s = (hipStream_t)stream;
-  static const int env_mfma = getenv("DV3_C3_MFMA") ? atoi(getenv("DV3_C3_MFMA")) : 1;
+  static const int env_mfma = DV3_ENV_INT("DV3_C3_MFMA", 1);
   if (env_mfma && (CW == 32 || CW == 96) && total < 0x7fffffffL * 64) {
     const dim3 grid((unsigned)((total + 127) / 128));
     if (CW == 32) hipLaunchKernelGGL((conv_s2_c3_mfma_kernel<32>), grid, dim3(256), 0, s, x, w, y, Nimg, H, W, accumulate);

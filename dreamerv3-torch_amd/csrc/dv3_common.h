@@ -6,6 +6,15 @@
 #define DV3_OK 0
 #define DV3_ERR_ARG 10001  // bad shape / pointer / unsupported size; nothing was launched
 
+// Kernel-selection switches for A/B measurements (tools/*_bench.py) exist only in a development build
+// (`build.py --dev` defines DV3_DEV_SWITCHES); the shipped library reads no environment variable.
+#ifdef DV3_DEV_SWITCHES
+#include <stdlib.h>
+#define DV3_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define DV3_ENV_INT(name, dflt) (dflt)
+#endif
+
 namespace dv3 {
 
 constexpr float kLnEps = 1e-3f;  // every LayerNorm on the path: networks.py:55,66,75,631,754,802

@@ -258,7 +258,7 @@ __device__ __forceinline__ void xcd_tile(const GemmParams& p, int id, int& tm, i
 
 static void pick_xcd_grid(GemmParams& p) {
   p.xcd_m = p.xcd_n = 0;
-  static const int env_xm = getenv("DV3_XCD_M") ? atoi(getenv("DV3_XCD_M")) : 0;  // development: force the grid
+  static const int env_xm = DV3_ENV_INT("DV3_XCD_M", 0);  // development: force the grid
   if (env_xm == -1) return;  // linear tile order
   if (env_xm > 0 && 8 % env_xm == 0 && p.tiles_m % env_xm == 0 && p.tiles_n % (8 / env_xm) == 0) {
     p.xcd_m = env_xm;
@@ -595,7 +595,7 @@ static void launch_direct_rn(const GemmParams& p0, int waves, hipStream_t s) {
   const size_t sh = (size_t)waves * 2 * RN * 256 * sizeof(float);
   // one chunk of lookahead (BATCH 1) measured best: ~100 VGPRs keep 4 waves per SIMD resident, which hides more
   // latency than deeper register prefetch at 170-230 VGPRs (DV3_DIRECT_BATCH: development switch)
-  static const int env_batch = getenv("DV3_DIRECT_BATCH") ? atoi(getenv("DV3_DIRECT_BATCH")) : 0;
+  static const int env_batch = DV3_ENV_INT("DV3_DIRECT_BATCH", 0);
   if constexpr (TB && RN == 4) {
     if (p.smp_onehot) {
       if (p.ln_gamma) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 2, 1, 0, 1>), grid, block, sh, s, p);
@@ -605,7 +605,7 @@ static void launch_direct_rn(const GemmParams& p0, int waves, hipStream_t s) {
   }
   // measured (r02e, hipGraph back-to-back, us): y = x W^T shapes 1024x1536x1024 46.1 -> 43.8, 1024x512x512 10.9 -> 10.1,
   // 1024x1024x512 18.1 -> 17.0 with PIPE 0 / BATCH 2; the [K][N] (data-gradient) form is better pipelined (40.8 vs 43.9)
-  static const int env_pipe = getenv("DV3_DIRECT_PIPE") ? atoi(getenv("DV3_DIRECT_PIPE")) : (TB ? 0 : 1);
+  static const int env_pipe = DV3_ENV_INT("DV3_DIRECT_PIPE", (TB ? 0 : 1));
   if (env_pipe == 0) {
     if (env_batch == 4) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 4, 0, 0>), grid, block, sh, s, p);
     else if (env_batch == 1) hipLaunchKernelGGL((gemm_direct_kernel<TB, RN, 1, 0, 0>), grid, block, sh, s, p);
@@ -618,8 +618,8 @@ static void launch_direct_rn(const GemmParams& p0, int waves, hipStream_t s) {
 }
 template <bool TB>
 static void launch_direct(const GemmParams& p, hipStream_t s) {
-  static const int env_waves = getenv("DV3_DIRECT_WAVES") ? atoi(getenv("DV3_DIRECT_WAVES")) : 0;
-  static const int env_rn = getenv("DV3_DIRECT_RN") ? atoi(getenv("DV3_DIRECT_RN")) : 0;
+  static const int env_waves = DV3_ENV_INT("DV3_DIRECT_WAVES", 0);
+  static const int env_rn = DV3_ENV_INT("DV3_DIRECT_RN", 0);
   const int chunks = (p.K + 15) / 16;
   // K over 8 waves once every wave still gets four 16-k chunks (measured: never worse than 4, better at N = 512..1024)
   int waves = chunks >= 32 ? 8 : 4;
@@ -893,7 +893,7 @@ static void launch_l16(const GemmParams& p0, int force, hipStream_t s) {
   p.tiles_n = (p.N + bn - 1) / bn;
   pick_xcd_grid(p);
   const dim3 grid(p.tiles_m * p.tiles_n), block(256);
-  static const int pf = getenv("DV3_L16_PF") ? atoi(getenv("DV3_L16_PF")) : 1;
+  static const int pf = DV3_ENV_INT("DV3_L16_PF", 1);
 #define DV3_L16_LAUNCH(PFV)                                                                     \
   do {                                                                                          \
     if (sel == 1) hipLaunchKernelGGL((gemm_l16_kernel<64, 96, PFV>), grid, block, 0, s, p);      \
@@ -1019,7 +1019,7 @@ static void launch_direct_tn(const GemmParams& p0, hipStream_t s) {
     if (splits < 1) splits = 1;
   }
   const size_t sh = (size_t)WAVES * 2 * RN * 256 * sizeof(float);
-  static const int env_batch = getenv("DV3_DIRECT_BATCH") ? atoi(getenv("DV3_DIRECT_BATCH")) : 0;
+  static const int env_batch = DV3_ENV_INT("DV3_DIRECT_BATCH", 0);
   if (env_batch == 2) hipLaunchKernelGGL((gemm_direct_tn_kernel<RN, 2>), dim3(tiles, splits), dim3(64 * WAVES), sh, s, p);
   else hipLaunchKernelGGL((gemm_direct_tn_kernel<RN, 1>), dim3(tiles, splits), dim3(64 * WAVES), sh, s, p);
 }

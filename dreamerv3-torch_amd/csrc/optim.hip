@@ -315,4 +315,11 @@ extern "C" int dv3_tensorstats(const float* x, long n, const float* shift, const
   return (int)hipGetLastError();
 }
 
-extern "C" int dv3_version(void) { return 2; }
+extern "C" int dv3_version(void) { return 3; }
+extern "C" int dv3_dev_switches(void) {
+#ifdef DV3_DEV_SWITCHES
+  return 1;
+#else
+  return 0;
+#endif
+}

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 from torch import nn
 
+import exploration as expl
 import models
 import tools
 
@@ -34,9 +35,12 @@ class Dreamer(nn.Module):
             raise NotImplementedError("causal world models are outside the accelerated path (SURVEY.md §2 #13-14)")
         self._wm = models.WorldModel(obs_space, act_space, self._step, config)
         self._task_behavior = models.ImagBehavior(config, self._wm)
-        if config.expl_behavior != "greedy":
-            raise NotImplementedError("only expl_behavior='greedy' is on the accelerated path")
-        self._expl_behavior = self._task_behavior
+        reward = lambda f, s, a: self._wm.heads["reward"](f).mean()  # extrinsic term of Plan2Explore (dreamer.py:80)
+        self._expl_behavior = dict(
+            greedy=lambda: self._task_behavior,
+            random=lambda: expl.Random(config, act_space),
+            plan2explore=lambda: expl.Plan2Explore(config, self._wm, reward),
+        )[config.expl_behavior]().to(self._config.device)
         self._runner, self._stager, self._policy_runner = None, None, None
         self._metric_keys, self._metric_sum, self._metric_n = [], None, 0
 
@@ -67,25 +71,32 @@ class Dreamer(nn.Module):
     def _policy(self, obs, state, training, noise=None):
         """Acting step.  With config.hip_graph (default) the launch sequence is replayed from a hipGraph per
         (number of envs, training) signature (dv3hip.graph.PolicyRunner); injected noise (tests) takes the eager path."""
-        if noise is None and bool(getattr(self._config, "hip_graph", True)) and self._policy_runner is not False:
+        # the Random explorer samples from torch's generator: not a static launch sequence
+        random_now = training and self._config.expl_behavior == "random" and self._exploring()
+        if (noise is None and bool(getattr(self._config, "hip_graph", True)) and self._policy_runner is not False
+                and not random_now):
+            from dv3hip.graph import CaptureRefused, PolicyRunner
+
             try:
                 if self._policy_runner is None:
-                    from dv3hip.graph import PolicyRunner
-
                     self._policy_runner = PolicyRunner(self)
                 return self._policy_runner.step(obs, state, training)
-            except Exception as e:  # a runtime that refuses capture: keep acting, launch eagerly
+            except CaptureRefused as e:  # ONLY a runtime that refuses capture; any other failure is a bug and propagates
                 import sys
 
-                print(f"[dv3hip] hipGraph capture of the policy step failed ({type(e).__name__}: {e}); eager launches",
-                      file=sys.stderr)
+                print(f"[dv3hip] hipGraph capture of the policy step was refused ({e}); eager launches", file=sys.stderr)
                 self._policy_runner = False
+                torch.cuda.synchronize()  # surfaces an asynchronous HIP error instead of acting on a poisoned context
         return self._policy_eager(obs, state, training, noise)
 
+    def _exploring(self):
+        """dreamer.py:161: the exploration actor acts while `_should_expl` holds (expl_until 0 = always)."""
+        return self._expl_behavior is not self._task_behavior and bool(self._should_expl(self._step))
+
     def _policy_eager(self, obs, state, training, noise=None):
-        """dreamer.py:116-188 for expl_behavior 'greedy' (expl_until 0 makes _should_expl always true there, so
-        training samples the task actor; the counterfactual branch behind `_best_candidate` is unreachable, SURVEY.md
-        section 0 gotcha 2).  noise (tests): dict(prior, post [n_envs,S,D] ~ Exp(1); act [n_envs,A], N(0,1) or
+        """dreamer.py:116-188: eval -> mode of the task actor; training -> a sample of the exploration actor while
+        `_should_expl` holds (for 'greedy' that IS the task actor), else of the task actor (the counterfactual branch
+        behind `_best_candidate` is unreachable, SURVEY.md section 0 gotcha 2).  noise (tests): dict(prior, post [n_envs,S,D] ~ Exp(1); act [n_envs,A], N(0,1) or
         Exp(1) for the one-hot actor) injected instead of the Philox stream."""
         latent, action = (None, None) if state is None else state
         nz = noise or {}
@@ -95,8 +106,12 @@ class Dreamer(nn.Module):
         if getattr(self._config, "eval_state_mean", False):
             raise NotImplementedError("eval_state_mean needs continuous latents (dyn_discrete: 0)")
         feat = self._wm.dynamics.get_feat(latent)
-        actor = self._task_behavior.actor(feat)
-        action = actor.sample(noise=nz.get("act")) if training else actor.mode()
+        if training and self._exploring():
+            actor = self._expl_behavior.actor(feat)
+            action = actor.sample() if nz.get("act") is None else actor.sample(noise=nz["act"])
+        else:
+            actor = self._task_behavior.actor(feat)
+            action = actor.sample(noise=nz.get("act")) if training else actor.mode()
         logprob = actor.log_prob(action)
         latent = {k: v.detach() for k, v in latent.items()}
         action = action.detach()
@@ -119,7 +134,13 @@ class Dreamer(nn.Module):
         host = all(not isinstance(v, torch.Tensor) for v in data.values())
         self._runner.step(self._stager.stage(data) if host else
                           {k: (v if k == "image" else v.to(torch.float32)) for k, v in data.items()})
-        mets = self._runner.last_metrics
+        mets = dict(self._runner.last_metrics)
+        if self._expl_behavior is not self._task_behavior:
+            # dreamer.py:201-203: the explorer trains on the same posterior states (eagerly: its objective runs torch
+            # autograd, which a hipGraph segment cannot hold)
+            staged = self._runner.last_data
+            xm = self._expl_behavior.train(self._runner.last_post, self._runner.last_context, staged)[-1]
+            mets.update({"expl_" + k: v for k, v in xm.items()})
         dev = [(k, v._t) for k, v in mets.items() if isinstance(v, models.DeviceScalar)]
         if self._metric_keys != [k for k, _ in dev]:
             self._flush_metrics()

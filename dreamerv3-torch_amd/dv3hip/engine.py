@@ -20,27 +20,24 @@ Parameter containers hold torch.nn.Parameters whose .grad are views into a flat 
 """
 from __future__ import annotations
 
-import os
-
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import torch
 
-from . import ops
+from . import _dev, ops
 
 F32 = torch.float32
 
 
-_FUSE_BLEND = os.environ.get("DV3_FUSE_BLEND", "1") != "0"  # development switch (A/B runs)
-_FUSE_SAMPLE = os.environ.get("DV3_FUSE_SAMPLE", "1") != "0"  # sampling in the epilogue of the prior-logit GEMM
-# img_out LayerNorm+SiLU applied on the A-load of the prior-logit GEMM instead of a launch of its own.  OFF: measured
-# (r02j, 1024 rows) the GEMM goes 27 -> 49.5 us -- its 16 column tiles each redo the SiLU of the same A rows and the
-# wave's VALU work (16 exp + 16 div per 64 MFMAs) exceeds its MFMA time -- against the 7 us LayerNorm launch it removes.
-_LN_ON_LOAD = os.environ.get("DV3_LN_ON_LOAD", "0") != "0"
-_GATHER_OBS = os.environ.get("DV3_GATHER_OBS", "1") != "0"
-_FUSE_SAMPLE_IN = os.environ.get("DV3_FUSE_SAMPLE_IN", "1") != "0"  # observe scan: sample(t) + img_in(t+1) in one launch
-_FUSE_CARRY = os.environ.get("DV3_FUSE_CARRY", "1") != "0"  # reverse scan: carry + next straight-through in one launch  # one-hot gather for img_in / head first layers in observe
+# Development switches (A/B runs of tools/*_bench.py): live only with a `build.py --dev` library (dv3hip/_dev.py);
+# the shipped build always takes the defaults.  The non-default forms are exercised at tiny size by
+# tests/test_path_gpu.py::test_dev_switch_variants.
+_FUSE_BLEND = _dev.flag("DV3_FUSE_BLEND", True)  # reset blend of step t+1 as second output of the kernels of step t
+_FUSE_SAMPLE = _dev.flag("DV3_FUSE_SAMPLE", True)  # sampling in the epilogue of the prior-logit GEMM
+_GATHER_OBS = _dev.flag("DV3_GATHER_OBS", True)  # one-hot gather for img_in / head first layers in observe
+_FUSE_SAMPLE_IN = _dev.flag("DV3_FUSE_SAMPLE_IN", True)  # observe scan: sample(t) + img_in(t+1) in one launch
+_FUSE_CARRY = _dev.flag("DV3_FUSE_CARRY", True)  # reverse scan: carry + next straight-through in one launch
 
 
 class SideStream:
@@ -52,7 +49,7 @@ class SideStream:
     # Measured on MI355X at cfg 2 (r01): OFF is faster (27.7 vs 29.8 ms/update).  The heavy side kernels
     # (conv wgrads) take every CU and each of the ~640 latency-critical scan launches then queues behind
     # them.  Kept as a switch: it needs a CU-masked side stream to pay.
-    enabled = os.environ.get("DV3_SIDE_STREAM", "0") != "0"
+    enabled = _dev.flag("DV3_SIDE_STREAM", False)
     _streams: Dict[str, "torch.cuda.Stream"] = {}
 
     def __init__(self, device):
@@ -575,21 +572,16 @@ class RSSMEngine:
         if not head:
             return
         fuse_smp = _FUSE_SAMPLE and ops.gemm_sample_ok(M, self.SD, self.D)
-        # the img_out LayerNorm + SiLU rides on the operand load of the prior-logit GEMM (x2 is then never stored: the
-        # imagination backward needs x2pre and the statistics only)
-        ln_on_load = fuse_smp and _LN_ON_LOAD and self.Hd % 4 == 0 and bufs["x2pre"].stride(0) % 4 == 0
         if wcat is not None:
             ops.gemm(bufs["deter"], wcat, bufs["cat"])
         else:
             ops.gemm(bufs["deter"], P.img_out.W, bufs["x2pre"])
-        if not ln_on_load:
-            ops.ln_act_fwd(bufs["x2pre"], P.img_out.g, P.img_out.b, bufs["x2"], bufs["m2"], bufs["r2"], act=True)
+        ops.ln_act_fwd(bufs["x2pre"], P.img_out.g, P.img_out.b, bufs["x2"], bufs["m2"], bufs["r2"], act=True)
         io = None if idx_out is None else idx_out.view(-1)
         if fuse_smp:
-            ops.gemm_sample(bufs["x2pre"] if ln_on_load else bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD),
-                            bufs["stoch"], bias=P.ims.b, noise=noise, rng=rng, idx=io, forced=forced, flips=flips,
-                            unimix=self.unimix, mode=not sample,
-                            ln=(P.img_out.g, P.img_out.b, bufs["m2"], bufs["r2"]) if ln_on_load else None)
+            ops.gemm_sample(bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD), bufs["stoch"], bias=P.ims.b,
+                            noise=noise, rng=rng, idx=io, forced=forced, flips=flips, unimix=self.unimix,
+                            mode=not sample)
         else:
             ops.gemm(bufs["x2"], P.ims.W, bufs["logit"].view(M, self.SD), bias=P.ims.b)
             ops.onehot_sample(bufs["logit"], bufs["stoch"], noise=noise, rng=rng, unimix=self.unimix, mode=not sample,
@@ -664,7 +656,7 @@ class PConvLayer:
 
 
 # acting path: conv layers with at most this many output pixels (all images) use im2col + GEMM
-_IM2COL_ROWS = int(os.environ.get("DV3_IM2COL_ROWS", "2048"))
+_IM2COL_ROWS = _dev.value("DV3_IM2COL_ROWS", 2048)
 
 
 class ConvEncoderEngine:

@@ -15,7 +15,27 @@ from typing import Dict
 
 import torch
 
-from . import ops
+from . import _lib, ops
+
+
+class CaptureRefused(RuntimeError):
+    """The HIP runtime (or torch) refused stream capture / graph instantiation.  The ONLY condition under which the
+    runners fall back to eager launches; shape bugs, a non-zero return code of a dv3 kernel (DV3Error) or an
+    asynchronous HIP fault propagate to the caller."""
+
+
+def _capture(graph, fn, **kw):
+    """Run fn under stream capture into `graph`; translate a refusal of the capture itself into CaptureRefused."""
+    try:
+        with torch.cuda.graph(graph, capture_error_mode="thread_local", **kw):
+            fn()
+    except _lib.DV3Error:
+        raise
+    except RuntimeError as e:
+        msg = str(e).lower()
+        if "captur" in msg or "graph" in msg:
+            raise CaptureRefused(f"{type(e).__name__}: {e}") from e
+        raise
 
 
 class UpdateRunner:
@@ -28,12 +48,14 @@ class UpdateRunner:
         self._static: Dict[str, torch.Tensor] = {}
         self._graphs = None
         self.last_metrics = {}
+        self.last_post = self.last_context = self.last_data = None  # what a further behaviour (Plan2Explore) trains on
 
     # -- eager reference sequence ----------------------------------------------------------------
     def _eager(self, data):
-        post, _, m1 = self.wm._train(data)
+        post, ctx, m1 = self.wm._train(data)
         m2 = self.beh._train(post, None)[-1]
         self.last_metrics = {**m1, **m2}
+        self.last_post, self.last_context, self.last_data = post, ctx, data
 
     def _load(self, data):
         if not self._static:
@@ -47,22 +69,24 @@ class UpdateRunner:
         wm, beh = self.wm, self.beh
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         pool = torch.cuda.graph_pool_handle()
-        # thread_local: with a process group alive, RCCL's watchdog thread polls events while we capture; the
-        # default (global) mode would treat that as a capture violation
-        mode = dict(capture_error_mode="thread_local")
-        with torch.cuda.graph(g1, pool=pool, **mode):
-            wm.train_fwd_bwd(self._static)
+        # (capture_error_mode thread_local: with a process group alive, RCCL's watchdog thread polls events while we
+        # capture; the default global mode would treat that as a capture violation)
+        res = {}
+        _capture(g1, lambda: wm.train_fwd_bwd(self._static), pool=pool)
         wm._model_opt.bucket.allreduce()
-        with torch.cuda.graph(g2, pool=pool, **mode):
-            post, _, m1 = wm.train_opt(allreduce=False)
-            beh.train_fwd_bwd(post)
+
+        def seg2():
+            res["post"], res["ctx"], res["m1"] = wm.train_opt(allreduce=False)
+            beh.train_fwd_bwd(res["post"])
+
+        _capture(g2, seg2, pool=pool)
         beh._actor_opt.bucket.allreduce()
         beh._value_opt.bucket.allreduce()
         beh.sync_ema()
-        with torch.cuda.graph(g3, pool=pool, **mode):
-            m2 = beh.train_opt(allreduce=False)[-1]
+        _capture(g3, lambda: res.update(m2=beh.train_opt(allreduce=False)[-1]), pool=pool)
         self._graphs = (g1, g2, g3)
-        self.last_metrics = {**m1, **m2}
+        self.last_metrics = {**res["m1"], **res["m2"]}
+        self.last_post, self.last_context, self.last_data = res["post"], res["ctx"], self._static
 
     def step(self, data, eager: bool = False):
         """data: dict of device tensors (image uint8 [B,T,64,64,3], action, reward, is_first, is_terminal ...)."""
@@ -75,13 +99,12 @@ class UpdateRunner:
             torch.cuda.synchronize()
             try:
                 self._capture()  # records only: nothing has executed yet, so fall through and replay
-            except Exception as e:  # e.g. a runtime that refuses capture: keep training, launch eagerly
+            except CaptureRefused as e:  # a runtime that refuses capture: keep training, launch eagerly
                 import sys
 
-                print(f"[dv3hip] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
-                      file=sys.stderr)
+                print(f"[dv3hip] hipGraph capture refused ({e}); falling back to eager launches", file=sys.stderr)
                 self.use_graph, self._graphs = False, None
-                torch.cuda.synchronize()
+                torch.cuda.synchronize()  # an asynchronous HIP error surfaces here instead of being trained over
                 self._eager(data)
                 return
         g1, g2, g3 = self._graphs
@@ -149,8 +172,7 @@ class PolicyRunner:
         rng.state.copy_(saved)  # the warm call is not a step: leave the Philox stream where the caller had it
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            core()
+        _capture(g, core)
         st["graph"] = g
         return st
 
@@ -201,7 +223,10 @@ class PolicyRunner:
 
     def step(self, obs, state, training):
         n = len(obs["is_first"])
-        key = (n, bool(training), tuple(sorted(obs)))
+        # the static buffers are typed and shaped from the observations the graph was built on: another image dtype
+        # (float vs uint8) or shape is another signature, never a silent conversion into the old buffers
+        sig = tuple((k, tuple(torch.as_tensor(obs[k]).shape), str(torch.as_tensor(obs[k]).dtype)) for k in sorted(obs))
+        key = (n, bool(training), bool(training and self.agent._exploring()), sig)
         st = self._sig.get(key)
         if st is None:
             st = self._build(obs, state, training)

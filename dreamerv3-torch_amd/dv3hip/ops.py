@@ -9,11 +9,9 @@ from __future__ import annotations
 
 from typing import Optional
 
-import os
-
 import torch
 
-from . import _lib
+from . import _dev, _lib
 
 F32 = torch.float32
 
@@ -133,11 +131,11 @@ def kernel_symbol(key: str) -> str:
 # <= 512k outputs (1024 imagination rows x 512 columns): the register-direct kernel (tile 9: no LDS staging,
 # 16x16x4 MFMA, 32 x 64 outputs per workgroup, K over its waves).  A/B inside one box, ms per update:
 # 32x64 LDS tile (6) 22.46, 32x32 LDS tile with K over the waves (8) 21.65, direct (9) 21.42.
-_SMALL_TILE = int(os.environ.get("DV3_SMALL_TILE", "9"))
+_SMALL_TILE = _dev.value("DV3_SMALL_TILE", 9)
 # 512k .. 2M outputs (1024 rows x 1024 / 1536 columns): the k-contiguous LDS tile (11: 32 x 64, ds_read_b128
 # fragments): GRU matmul 35.9 us against 44.0 direct (9) and 48.3 on the k-major 32x64 LDS tile (6); 1024x1024x512
 # 14.5 against 16.7.  Falls back to 9 where its alignment preconditions do not hold.
-_MID_TILE = int(os.environ.get("DV3_MID_TILE", "11"))
+_MID_TILE = _dev.value("DV3_MID_TILE", 11)
 
 
 def l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb) -> bool:
@@ -147,13 +145,14 @@ def l16_ok(A, A2, B, transA, transB, K, K1, lda, lda2, ldb) -> bool:
             and (A2 is None or (lda2 % 4 == 0 and A2.data_ptr() % 16 == 0)))
 
 
-_BT_MIN_FLOPS = float(os.environ.get("DV3_BT_MIN_FLOPS", "7e9"))
+_BT_MIN_FLOPS = _dev.value("DV3_BT_MIN_FLOPS", 7e9, float)
 _BT = {}
 
 
 def _bt_scratch(K, N, device):
-    """[N, K] scratch for the transposed copy of a [K, N] operand (persistent: graph replays read the same buffer)."""
-    key = (K, N, str(device))
+    """[N, K] scratch for the transposed copy of a [K, N] operand (persistent: graph replays read the same buffer).
+    One per launch stream: two products of equal (K, N) on different streams (graph branches) must not share it."""
+    key = (K, N, str(device), _stream())
     t = _BT.get(key)
     if t is None:
         t = torch.empty(N, K, device=device, dtype=F32)

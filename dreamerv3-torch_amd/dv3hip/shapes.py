@@ -22,6 +22,16 @@ SHAPES = {
     "tiny_proprio": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
                          actor_dist="normal", imag_gradient="dynamics", encoder="mlp",
                          enc_mlp_units=32, enc_mlp_layers=2),
+    # Plan2Explore (exploration.py:40-135) on the tiny model: defaults (stoch target, log disagreement, no action
+    # conditioning, no extrinsic term) and the action-conditioned variant with an extrinsic term
+    "tiny_p2e": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
+                     actor_dist="normal", imag_gradient="dynamics", encoder="cnn",
+                     p2e=dict(disag_models=3, disag_layers=2, disag_units=16, disag_target="stoch", disag_offset=1,
+                              disag_log=True, disag_action_cond=False, expl_intr_scale=1.0, expl_extr_scale=0.0)),
+    "tiny_p2e_ac": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
+                        actor_dist="normal", imag_gradient="dynamics", encoder="cnn",
+                        p2e=dict(disag_models=4, disag_layers=3, disag_units=24, disag_target="deter", disag_offset=1,
+                                 disag_log=False, disag_action_cond=True, expl_intr_scale=0.7, expl_extr_scale=0.5)),
     "cfg1": dict(stoch=32, discrete=32, deter=512, hidden=512, units=512, A=6, cnn_depth=32, B=16, T=64, H=15,
                  actor_dist="normal", imag_gradient="dynamics", encoder="mlp",
                  enc_mlp_units=1024, enc_mlp_layers=5),
@@ -88,6 +98,8 @@ def make_config(name, device="cuda:0"):
     if s["encoder"] == "mlp":
         for d in (cfg["encoder"], cfg["decoder"]):
             d.update(mlp_units=s["enc_mlp_units"], mlp_layers=s["enc_mlp_layers"])
+    if "p2e" in s:
+        cfg.update(expl_behavior="plan2explore", **s["p2e"])
     return argparse.Namespace(**cfg)
 
 

@@ -12,7 +12,6 @@ Row order: activations are time-major inside (row t*B+b); dict entries handed ba
 from __future__ import annotations
 
 import copy
-import os
 
 import numpy as np
 import torch
@@ -20,22 +19,15 @@ from torch import nn
 
 import networks
 import tools
+from dv3hip import _dev
 from dv3hip import engine as E
 from dv3hip import ops
 from dv3hip.params import ParamBucket
 
 to_np = lambda x: x.detach().cpu().numpy()
-_FUSED_IMAG = os.environ.get("DV3_FUSED_IMAG", "1") != "0"  # development switch (A/B runs), see _imagine_fwd
-_IMAG_CHAINS = int(os.environ.get("DV3_IMAG_CHAINS", "1"))  # row-split imagination rollout on parallel streams
-_STACK_DETER = os.environ.get("DV3_STACK_DETER", "1") != "0"  # img_out + actor layer-0 dense half as one GEMM
-_SIDE = {}
-
-
-def _side_streams(device, n):
-    key = str(device)
-    while len(_SIDE.setdefault(key, [])) < n:
-        _SIDE[key].append(torch.cuda.Stream(device=device))
-    return _SIDE[key][:n]
+# development switches (live only with a `build.py --dev` library, dv3hip/_dev.py; see _imagine_fwd)
+_FUSED_IMAG = _dev.flag("DV3_FUSED_IMAG", True)  # fused launches + one-hot gather in the rollout (off: one launch per op)
+_STACK_DETER = _dev.flag("DV3_STACK_DETER", True)  # img_out + actor layer-0 dense half as one GEMM
 
 
 class DeviceScalar:
@@ -441,7 +433,7 @@ class ImagBehavior(nn.Module):
         """models.py:448-548 (forward only): returns feats [H,N,F], states {[H,N,...]}, actions [H,N,A].
         Row order follows the memory order of `start` (time-major when it comes from WorldModel._train)."""
         if policy is not None and policy is not self.actor:
-            raise NotImplementedError("_imagine: only the behaviour's own actor is a policy on the accelerated path")
+            return self._imagine_generic(start, policy, horizon)
         self._imagine_fwd(start, horizon, noise)
         st = self._im
         S, D = self._world_model.dynamics._stoch, self._world_model.dynamics._discrete
@@ -450,6 +442,22 @@ class ImagBehavior(nn.Module):
                   "logit": st["logit"].view(H, N, S, D).clone()}
         feats = torch.cat([st["stoch"], st["deter"]], -1)
         return feats, states, st["action"].clone()
+
+    def _imagine_generic(self, start, policy, horizon):
+        """models.py:448-548 for a foreign `policy` (any callable feat -> distribution with .sample()): the rollout
+        step by step through the public RSSM methods, i.e. through dv3hip.autograd when gradients are wanted, so the
+        returned feats / states / actions carry a graph exactly as the reference's do.  Rows are b*T+t as there."""
+        dyn = self._world_model.dynamics
+        state = {k: v.reshape((-1,) + tuple(v.shape[2:])) for k, v in start.items()}
+        feats, states, actions = [], [], []
+        for t in range(horizon):
+            feat = dyn.get_feat(state)
+            action = policy(feat.detach()).sample()
+            feats.append(feat), states.append(state), actions.append(action)
+            if t < horizon - 1:  # the H-th successor is discarded by the reference (models.py:546)
+                state = dyn.img_step(state, action)
+        return (torch.stack(feats, 0), {k: torch.stack([s_[k] for s_ in states], 0) for k in states[0]},
+                torch.stack(actions, 0))
 
     def _imagine_fwd(self, start, horizon, noise=None):
         cfg = self._config
@@ -532,53 +540,64 @@ class ImagBehavior(nn.Module):
                                       forced=None if f_img is None else f_img[t][rc], flips=flips,
                                       idx=idx[t][rc] if _FUSED_IMAG else None, idx_out=idx[t + 1][rc], wcat=wcat)
 
-        chains = _IMAG_CHAINS if N % (32 * _IMAG_CHAINS) == 0 else 1
-        if chains == 1:
-            run_chain(slice(0, N))
-        else:
-            # Row-split rollout on parallel streams (graph branches under capture): at 1024 rows every launch of the
-            # chain is latency- rather than throughput-bound, so one half's MFMA work fills the other half's launch
-            # and memory latencies.  Rows are independent; only the Philox counter ranges differ from one chain.
-            main = torch.cuda.current_stream()
-            sides = _side_streams(stoch.device, chains - 1)
-            per = N // chains
-            for st in sides:
-                st.wait_stream(main)
-            run_chain(slice(0, per))
-            for c, st in enumerate(sides):
-                with torch.cuda.stream(st):
-                    run_chain(slice((c + 1) * per, (c + 2) * per))
-            for st in sides:
-                main.wait_stream(st)
+        run_chain(slice(0, N))
         rng.commit()
         self._im = dict(H=H, N=N, stoch=stoch, deter=deter, logit=logit, action=action, ent=ent, eps=eps, step=step,
                         actor=actor_eng, idx=idx)
 
     # ------------------------------------------------------------------------------------------
     def _train(self, start, objective=None, noise=None):
-        """One actor + critic update (models.py:327-446).  The reward is the world model's reward head on the
-        imagined states, which is the `objective` dreamer.py passes (dreamer.py:196-199); a given `objective` is
-        checked against it once (see _check_objective), None skips the check."""
-        self.train_fwd_bwd(start, noise)
-        if objective is not None and not getattr(self, "_objective_checked", False):
-            self._check_objective(objective)
+        """One actor + critic update (models.py:327-446).  `objective(feat, state, action) -> reward [H,N,1]`:
+        * None, or the world model's reward head on the imagined states (what dreamer.py:196-199 passes; recognised on
+          its first use by evaluating it once and comparing with the fused head, then remembered per code object):
+          the fully fused path -- reward head forward and backward in hand-written kernels, hipGraph-capturable;
+        * anything else (exploration.Plan2Explore._intrinsic_reward, exploration.py:108-121): the objective is
+          evaluated under torch autograd on leaf views of the imagined states / actions and its input gradients are
+          injected into the hand-written reverse rollout where the reward head's would enter (see train_fwd_bwd)."""
+        self.train_fwd_bwd(start, noise, objective)
         return self.train_opt()
 
-    def _check_objective(self, objective):
-        """The backward through the reward is hand-derived for the reward HEAD on the imagined states, which is the
-        objective dreamer.py:196-199 passes.  Any other callable would silently train on the wrong signal, so the
-        first update evaluates the caller's objective (forward only, through the public modules) on the imagined
-        trajectory and compares it with the reward the kernels used; a different objective is refused."""
-        (_, imag_state, action, _), _, _ = self._pending
-        feat = self._world_model.dynamics.get_feat(imag_state)
-        got = objective(feat, imag_state, action)
-        want = self._last["reward"]
-        if tuple(got.shape[:2]) != tuple(want.shape) or not torch.allclose(got.reshape(want.shape).to(want.dtype), want,
-                                                                            rtol=1e-4, atol=1e-4):
-            raise NotImplementedError("ImagBehavior._train: `objective` is not the world model's reward head on the "
-                                      "imagined states (dreamer.py:196-199); only that objective has a backward on "
-                                      "the accelerated path")
-        object.__setattr__(self, "_objective_checked", True)
+    @staticmethod
+    def _objective_key(objective):
+        fn = getattr(objective, "__func__", objective)
+        return getattr(fn, "__code__", None) or id(objective)
+
+    def _objective_is_head(self, objective, im, reward):
+        """First use of an `objective`: is it the reward head on the imagined states (then the fused backward is its
+        exact gradient)?  One forward evaluation through the public modules + one host comparison, cached."""
+        kinds = self.__dict__.setdefault("_objective_kinds", {})
+        key = self._objective_key(objective)
+        if key not in kinds:
+            with torch.no_grad():
+                state = self._imag_state(im)
+                got = objective(self._world_model.dynamics.get_feat(state), state, im["action"])
+            same = (isinstance(got, torch.Tensor) and got.numel() == reward.numel()
+                    and bool(torch.allclose(got.reshape(reward.shape).to(reward.dtype), reward, rtol=1e-4, atol=1e-4)))
+            kinds[key] = same
+        return kinds[key]
+
+    def _imag_state(self, im):
+        S, D = self._world_model.dynamics._stoch, self._world_model.dynamics._discrete
+        H, N = im["H"], im["N"]
+        return {"stoch": im["stoch"].view(H, N, S, D), "deter": im["deter"], "logit": im["logit"].view(H, N, S, D)}
+
+    def _eval_objective(self, objective, im, need_grad):
+        """reward = objective(feat, state, action) on leaf views of the imagined trajectory (no copy).  With
+        need_grad the call records an autograd graph whose input gradients train_fwd_bwd later pulls with the
+        upstream d loss / d reward of the lambda-return backward."""
+        st = self._imag_state(im)
+        H, N = im["H"], im["N"]
+        leaves = dict(stoch=st["stoch"].detach().requires_grad_(need_grad),
+                      deter=st["deter"].detach().requires_grad_(need_grad),
+                      action=im["action"].detach().requires_grad_(need_grad))
+        state = {"stoch": leaves["stoch"], "deter": leaves["deter"], "logit": st["logit"].detach()}
+        with torch.enable_grad() if need_grad else torch.no_grad():
+            feat = self._world_model.dynamics.get_feat(state)
+            r = objective(feat, state, leaves["action"])
+        if not isinstance(r, torch.Tensor) or r.numel() != H * N:
+            raise ValueError(f"objective must return one reward per imagined state [H={H}, N={N}, 1]; got "
+                             f"{tuple(getattr(r, 'shape', ()))}")
+        return r, leaves
 
     def sync_ema(self):
         """Data parallel: the return-normalisation EMA is computed from each rank's own imagined returns; average the
@@ -599,7 +618,7 @@ class ImagBehavior(nn.Module):
         metrics.update(self._value_opt.finish(losses[1], allreduce))
         return ret + (_wrap(metrics),)
 
-    def train_fwd_bwd(self, start, noise=None):
+    def train_fwd_bwd(self, start, noise=None, objective=None):
         cfg = self._config
         wm = self._world_model
         dyn = wm.dynamics
@@ -628,8 +647,21 @@ class ImagBehavior(nn.Module):
         if _FUSED_IMAG:
             for e in (reng, ceng, veng, seng):
                 e.pack_onehot(SD)
-        _, r_logits, _ = reng.forward(fs, fd, idx=fidx, D=D)
-        reward = ops.disc_mode_fwd(r_logits, g("bh.reward", (H, N)))
+        use_dyn = cfg.imag_gradient in ("dynamics", "both")
+        reward = g("bh.reward", (H, N))
+        custom = objective is not None and self.__dict__.get("_objective_kinds", {}).get(
+            self._objective_key(objective)) is False
+        r_logits = obj_out = obj_leaves = None
+        if not custom:
+            _, r_logits, _ = reng.forward(fs, fd, idx=fidx, D=D)
+            ops.disc_mode_fwd(r_logits, reward)
+            if objective is not None and not self._objective_is_head(objective, im, reward):
+                custom = True
+        if custom:
+            # a foreign objective: evaluated with torch autograd on leaf views of the trajectory (its own modules run
+            # their kernels through dv3hip.autograd); gradients are pulled out below
+            obj_out, obj_leaves = self._eval_objective(objective, im, need_grad=use_dyn)
+            reward.copy_(obj_out.detach().reshape(H, N))
         _, c_logit, _ = ceng.forward(fs, fd, idx=fidx, D=D)
         _, v_logits, _ = veng.forward(fs, fd, idx=fidx, D=D)
         value = ops.disc_mode_fwd(v_logits, g("bh.value", (H, N)))
@@ -650,7 +682,6 @@ class ImagBehavior(nn.Module):
         # imag_gradient (models.py:663-678): 'dynamics' back-propagates the normalised return through the imagined
         # states; 'reinforce' weights log pi(a) with the detached advantage; 'both' mixes the raw return into the latter
         use_logp = cfg.imag_gradient in ("reinforce", "both")
-        use_dyn = cfg.imag_gradient in ("dynamics", "both")
         reinforce = not use_dyn
         normal = cfg.actor["dist"] == "normal"
         a_mean, a_std = self._actor_heads(im)
@@ -697,10 +728,23 @@ class ImagBehavior(nn.Module):
                                   lam=cfg.discount_lambda)
             gs, gd = g("bh.gs", (H, N, SD)), g("bh.gd", (H, N, De))
             rows = slice(N, HN)  # step 0 is the (detached) start state: no gradient there
-            drl = g("bh.dr_logits", (H1N, 255))
-            ops.disc_mode_bwd(r_logits[rows], dreward.view(HN)[rows], drl)
-            reng.backward(fs[rows], fd[rows], rows, dout=drl, wgrad=False, dx1=gs.view(HN, SD)[rows],
-                          dx2=gd.view(HN, De)[rows])
+            g_act = None
+            if custom:
+                # d loss / d reward -> the objective's own graph -> gradients on the imagined stoch / deter / action
+                # (reward[0] never enters a return, so dreward[0] = 0 and row block 0 receives nothing)
+                g_st, g_dt, g_act = torch.autograd.grad(
+                    obj_out, [obj_leaves["stoch"], obj_leaves["deter"], obj_leaves["action"]],
+                    grad_outputs=dreward.view_as(obj_out), allow_unused=True)
+                for buf, gr, w in ((gs, g_st, SD), (gd, g_dt, De)):
+                    if gr is None:
+                        buf.view(HN, w)[rows].zero_()
+                    else:
+                        buf.view(HN, w)[rows].copy_(gr.reshape(HN, w)[rows])
+            else:
+                drl = g("bh.dr_logits", (H1N, 255))
+                ops.disc_mode_bwd(r_logits[rows], dreward.view(HN)[rows], drl)
+                reng.backward(fs[rows], fd[rows], rows, dout=drl, wgrad=False, dx1=gs.view(HN, SD)[rows],
+                              dx2=gd.view(HN, De)[rows])
             ceng.backward(fs[rows], fd[rows], rows, dout=dcl.view(HN, 1)[rows], wgrad=False,
                           dx1=gs.view(HN, SD)[rows], dx2=gd.view(HN, De)[rows], acc_dx=True)
             Hd = dyn._hidden
@@ -715,7 +759,14 @@ class ImagBehavior(nn.Module):
                 # step 0 is the detached start state: its slot is scratch
                 rssm.img_step_bwd(gs[t], gd[t], deter[t - 1], b, scratch, gs[t - 1], gd[t - 1], daction[t - 1],
                                   accumulate_prev=t > 1, wt=wt_bwd)
-        # ---- actor backward over steps 0..H-2 (the last step's action feeds nothing that is used)
+            if g_act is not None:
+                # an action-conditioned objective: reward_t depends on action_t directly, including the LAST step's
+                # (r_{H-1} enters the return of step H-2), so the actor's backward below covers all H steps
+                daction[H - 1].zero_()
+                ops.axpby(g_act.reshape(H, N, A).contiguous(), daction, 1.0, 1.0)
+                R = HN
+        # ---- actor backward over steps 0..H-2 (the last step's action feeds nothing that is used, unless the
+        # objective reads it: R = HN above; dent / dlogp are zero on the last step)
         dmean, dstd = g("bh.dmean", (R, A)), g("bh.dstd", (R, A))
         if normal:
             ops.actor_normal_bwd(a_mean[:R], a_std[:R], dmean, dstd, eps=im["eps"].view(HN, A)[:R],

@@ -3,10 +3,17 @@ ConvDecoder, MultiEncoder, MultiDecoder, Conv2dSamePad, ImgChLayerNorm) over lib
 
 Modules are parameter containers with the reference's names, shapes and state_dict keys
  plus the reference's methods.  Every method computes with the HIP kernels
-(dv3hip.ops / dv3hip.engine); there is no ATen math path and no CPU path.  The public methods are
-forward-only (acting, logging, open-loop prediction); gradients exist only inside
-models.WorldModel._train / models.ImagBehavior._train, which drive dv3hip.engine's explicit
-backward.  Continuous latents (dyn_discrete: 0) are not implemented: no shipped config uses them.
+(dv3hip.ops / dv3hip.engine); there is no ATen math path and no CPU path.  Two ways in:
+
+* the fused training path -- models.WorldModel._train / models.ImagBehavior._train drive dv3hip.engine's explicit
+  forward + hand-derived backward over whole updates (no autograd graph);
+* the public methods below.  Without gradients (acting, logging, open-loop prediction) they launch the forward
+  kernels only.  When autograd is recording and an input or a parameter requires a gradient they go through
+  dv3hip.autograd's Functions -- the same kernels forward and backward -- so that callers written against the
+  reference's surface with `loss.backward()` (exploration.Plan2Explore, the causal world models)
+  run unchanged.
+
+Continuous latents (dyn_discrete: 0) are not implemented: no shipped config uses them.
 """
 from __future__ import annotations
 
@@ -18,6 +25,7 @@ import torch
 from torch import nn
 
 import tools
+from dv3hip import autograd as AG
 from dv3hip import engine as E
 from dv3hip import ops
 
@@ -55,8 +63,11 @@ class GRUCell(nn.Module):
         return E.PDenseLN(self.layers.GRU_linear.weight, self.layers.GRU_norm.weight, self.layers.GRU_norm.bias)
 
     def forward(self, inputs, state):
-        h = state[0].contiguous()
         p = self.params()
+        if AG.wants_grad(inputs, state[0], p.W, p.g, p.b):
+            out = AG.GRUFn.apply(inputs, state[0], p.W, p.g, p.b)
+            return out, [out]
+        h = state[0].contiguous()
         M = h.shape[0]
         pre = torch.empty(M, 3 * self._size, device=h.device)
         ops.gemm(inputs.contiguous(), p.W, pre, A2=h)
@@ -64,6 +75,26 @@ class GRUCell(nn.Module):
         mean, rstd = torch.empty(M, device=h.device), torch.empty(M, device=h.device)
         ops.gru_fwd(pre, p.g, p.b, h, out, mean, rstd)
         return out, [out]
+
+
+class DenseLNBlock(nn.Sequential):
+    """[Linear(no bias), LayerNorm(eps 1e-3), SiLU] as the reference builds its `_img_in_layers`, `_img_out_layers`
+    and `_obs_out_layers` (networks.py:44-78; same child indices, so the same state_dict keys `0.weight`,
+    `1.weight`, `1.bias`), callable like the nn.Sequential it is there (scm_world_model.py:138, 160, 164): one GEMM +
+    one fused LayerNorm/SiLU launch, through dv3hip.autograd.TrunkFn when gradients are wanted."""
+
+    def __init__(self, inp, hidden):
+        super().__init__(nn.Linear(inp, hidden, bias=False), nn.LayerNorm(hidden, eps=1e-03), nn.SiLU())
+
+    def forward(self, x):
+        W, g, b = self[0].weight, self[1].weight, self[1].bias
+        if AG.wants_grad(x, W, g, b):
+            return AG.TrunkFn.apply(x, W, g, b)
+        x2 = x.reshape(-1, x.shape[-1]).to(torch.float32).contiguous()
+        pre = torch.empty(x2.shape[0], W.shape[0], device=x.device)
+        y = torch.empty_like(pre)
+        E.dense_ln_fwd(E.PDenseLN(W, g, b), x2, None, pre, None, None, y)
+        return y.view(tuple(x.shape[:-1]) + (W.shape[0],))
 
 
 class RSSM(nn.Module):
@@ -80,7 +111,7 @@ class RSSM(nn.Module):
         self._min_std, self._rec_depth, self._initial = min_std, rec_depth, initial
 
         def block(inp):
-            seq = nn.Sequential(nn.Linear(inp, hidden, bias=False), nn.LayerNorm(hidden, eps=1e-03), nn.SiLU())
+            seq = DenseLNBlock(inp, hidden)
             seq.apply(tools.weight_init)
             return seq
 
@@ -119,9 +150,16 @@ class RSSM(nn.Module):
         return tools.default_rng(self.W.device)
 
     # ---- reference API (forward only) ------------------------------------------------------------
+    def _all_params(self):
+        return AG.rssm_param_list(self.params())
+
     def initial(self, batch_size):
-        s0, d0 = self.engine.init_state_fwd()
         S, D = self._stoch, self._discrete
+        if AG.wants_grad(*self._all_params()):  # networks.py:99-123: deter = tanh(W), stoch = mode of the prior head
+            deter = AG.TanhFn.apply(self.W).repeat(batch_size, 1)
+            return dict(logit=torch.zeros(batch_size, S, D, device=deter.device), stoch=self.get_stoch(deter),
+                        deter=deter)
+        s0, d0 = self.engine.init_state_fwd()
         return dict(logit=torch.zeros(batch_size, S, D, device=s0.device),
                     stoch=s0.view(1, S, D).repeat(batch_size, 1, 1), deter=d0.repeat(batch_size, 1))
 
@@ -135,6 +173,10 @@ class RSSM(nn.Module):
 
     def get_stoch(self, deter):
         p = self.params()
+        if AG.wants_grad(deter, *self._all_params()):
+            x = self._img_out_layers(deter)
+            logit = self._suff_stats_layer("ims", x)["logit"]
+            return self.get_dist({"logit": logit}).mode()
         M = deter.shape[0]
         dev = deter.device
         pre, x = torch.empty(M, self._hidden, device=dev), torch.empty(M, self._hidden, device=dev)
@@ -149,6 +191,9 @@ class RSSM(nn.Module):
         if lin is None:
             raise NotImplementedError(name)
         lead = x.shape[:-1]
+        if AG.wants_grad(x, lin.weight, lin.bias):
+            out = AG.LinearFn.apply(x, lin.weight, lin.bias)
+            return {"logit": out.reshape(tuple(lead) + (self._stoch, self._discrete))}
         x2 = x.to(torch.float32).reshape(-1, x.shape[-1]).contiguous()
         out = torch.empty(x2.shape[0], self._stoch * self._discrete, device=x.device)
         ops.gemm(x2, lin.weight, out, bias=lin.bias)
@@ -161,8 +206,22 @@ class RSSM(nn.Module):
                     deter=mk(M, De), x2pre=mk(M, Hd), m2=mk(M), r2=mk(M), x2=mk(M, Hd), logit=mk(M, S, D),
                     stoch=mk(M, S, D))
 
+    def _img_step_grad(self, prev_state, prev_action, sample, noise):
+        """img_step as a chain of autograd nodes (each one a kernel pair): img_in -> GRU -> img_out -> stats -> sample."""
+        st = prev_state["stoch"]
+        x = torch.cat([st.reshape(tuple(st.shape[:-2]) + (self._stoch * self._discrete,)),
+                       prev_action.to(torch.float32)], -1)
+        x = self._img_in_layers(x)
+        deter, _ = self._cell(x, [prev_state["deter"]])
+        logit = self._suff_stats_layer("ims", self._img_out_layers(deter))["logit"]
+        dist = tools.OneHotDist(logit, unimix_ratio=self._unimix_ratio, rng=self._rng())
+        stoch = dist.sample(noise=noise) if sample else dist.mode()
+        return {"stoch": stoch, "deter": deter, "logit": logit}
+
     def img_step(self, prev_state, prev_action, sample=True, noise=None):
         """networks.py:208-233."""
+        if AG.wants_grad(prev_state["stoch"], prev_state["deter"], prev_action, *self._all_params()):
+            return self._img_step_grad(prev_state, prev_action, sample, noise)
         st = prev_state["stoch"].contiguous()
         M = st.shape[0]
         b = self._step_bufs(M, st.device)
@@ -183,6 +242,24 @@ class RSSM(nn.Module):
         dev = embed.device
         S, D, SD, De, Hd, A = self._stoch, self._discrete, self._stoch * self._discrete, self._deter, \
             self._hidden, self._num_actions
+        ps = prev_state or {}
+        if AG.wants_grad(embed, prev_action, ps.get("stoch"), ps.get("deter"), *self._all_params()):
+            # networks.py:174-206 with the reset as a branch-free blend (m = 0: identity; m = 1: initial state)
+            nz = noise or {}
+            m = is_first.to(torch.float32).reshape(B, 1)
+            init = self.initial(B)
+            if prev_state is None:
+                prev_state, prev_action = init, torch.zeros(B, A, device=dev)
+            else:
+                prev_action = prev_action.to(torch.float32) * (1.0 - m)
+                mm = lambda v: m.reshape((B,) + (1,) * (v.dim() - 1))
+                prev_state = {k: v * (1.0 - mm(v)) + init[k] * mm(v) for k, v in prev_state.items()}
+            pri = self._img_step_grad(prev_state, prev_action, sample, nz.get("prior"))
+            x = self._obs_out_layers(torch.cat([pri["deter"], embed.to(torch.float32)], -1))
+            logit = self._suff_stats_layer("obs", x)["logit"]
+            dist = tools.OneHotDist(logit, unimix_ratio=self._unimix_ratio, rng=self._rng())
+            stoch = dist.sample(noise=nz.get("post")) if sample else dist.mode()
+            return {"stoch": stoch, "deter": pri["deter"], "logit": logit}, (pri if prior else None)
         s0, d0 = self.engine.init_state_fwd()
         first = is_first.to(torch.float32).reshape(B).contiguous()
         sin, din, ain = torch.empty(B, SD, device=dev), torch.empty(B, De, device=dev), torch.empty(B, A, device=dev)
@@ -214,9 +291,26 @@ class RSSM(nn.Module):
         """networks.py:127-143: embed [B,T,E], action [B,T,A], is_first [B,T] -> (post, prior) of [B,T,...]."""
         B, T = embed.shape[0], embed.shape[1]
         dev = embed.device
+        nz = noise or {}
+        if state is None and AG.wants_grad(embed, *self._all_params()):
+            # the whole scan as ONE autograd node over engine.RSSMEngine.observe_fwd / observe_bwd
+            tmg = lambda x: x.to(torch.float32).transpose(0, 1).contiguous()
+            dims = dict(stoch=self._stoch, discrete=self._discrete, deter=self._deter, hidden=self._hidden,
+                        num_actions=self._num_actions, embed=self._embed, unimix=self._unimix_ratio)
+            ps, pl, dt, qs, ql = AG.ObserveFn.apply(tmg(embed), tmg(action), tmg(is_first), nz.get("q_prior"),
+                                                   nz.get("q_post"), self._rng(), dims, *self._all_params())
+            self._rng().commit()
+            bt = lambda x: x.transpose(0, 1)
+            return ({"stoch": bt(ps), "deter": bt(dt), "logit": bt(pl)},
+                    {"stoch": bt(qs), "deter": bt(dt), "logit": bt(ql)})
+        if state is not None and AG.wants_grad(embed, *self._all_params()):
+            # carried state (rare with gradients): step by step through obs_step's autograd chain
+            swap = lambda x: x.transpose(0, 1)
+            outs = tools.static_scan(lambda prev, a, e, f: self.obs_step(prev[0], a, e, f),
+                                     (swap(action), swap(embed), swap(is_first)), (state, state))
+            return tuple({k: swap(v) for k, v in o.items()} for o in outs)
         tm = lambda x: ops.transpose01(x.to(torch.float32).contiguous(),
                                        torch.empty((T, B) + tuple(x.shape[2:]), device=dev))
-        nz = noise or {}
         state0 = None
         if state is not None:  # carried state {stoch [B,S,D], deter [B,De], logit}: step 0 does not reset
             state0 = (state["stoch"].to(torch.float32).reshape(B, -1).contiguous(),
@@ -242,6 +336,8 @@ class RSSM(nn.Module):
 
     def kl_loss(self, post, prior, free, dyn_scale, rep_scale):
         """networks.py:272-290 forward values: (loss, value, dyn_loss, rep_loss), each [B,T]."""
+        if AG.wants_grad(post["logit"], prior["logit"]):
+            return AG.KLLossFn.apply(post["logit"], prior["logit"], free, dyn_scale, rep_scale, self._unimix_ratio)
         pl, ql = post["logit"].contiguous(), prior["logit"].contiguous()
         shape = pl.shape[:-2]
         kl = torch.empty(shape, device=pl.device)
@@ -312,6 +408,8 @@ class MLP(nn.Module):
     def make_dist(self, mean, std=None):
         d = self._dist
         if d == "normal":
+            if std is None:  # fixed std (networks.py:614, 683-684): the constant goes through the same squashing
+                std = torch.full_like(mean, float(self._std))
             return tools.ContDist(mean, std, self._min_std, self._max_std, absmax=self._absmax)
         if d == "onehot":
             return tools.OneHotDist(mean, unimix_ratio=self._unimix_ratio)
@@ -323,7 +421,29 @@ class MLP(nn.Module):
             return tools.SymlogDist(mean)
         raise NotImplementedError(d)
 
+    def _forward_grad(self, features):
+        """networks.py:657-681 as autograd nodes: the trunk is one node (engine.MLPEngine forward / backward), every
+        head Linear another; the returned distributions differentiate through dv3hip.autograd's head Functions."""
+        x = features.to(torch.float32)
+        if self._symlog_inputs:
+            x = tools.symlog(x)  # inputs are data for every caller: no gradient through the symlog
+        flat = []
+        for P in self.trunk_params():
+            flat += [P.W, P.g, P.b]
+        h = AG.TrunkFn.apply(x, *flat) if flat else x
+        if self._shape is None:
+            return h
+        if isinstance(self._shape, dict):
+            return {k: self.make_dist(AG.LinearFn.apply(h, self.mean_layer[k].weight, self.mean_layer[k].bias)
+                                      .reshape(tuple(h.shape[:-1]) + tuple(shp)))
+                    for k, shp in self._shape.items()}
+        mean = AG.LinearFn.apply(h, self.mean_layer.weight, self.mean_layer.bias)
+        std = AG.LinearFn.apply(h, self.std_layer.weight, self.std_layer.bias) if hasattr(self, "std_layer") else None
+        return self.make_dist(mean, std)
+
     def forward(self, features, dtype=None):
+        if AG.wants_grad(features, *self.parameters()):
+            return self._forward_grad(features)
         lead = features.shape[:-1]
         x = features.reshape(-1, features.shape[-1]).to(torch.float32).contiguous()
         if self._symlog_inputs:
@@ -400,6 +520,12 @@ class ConvEncoder(nn.Module):
         """obs f32 in [0,1], [..., H, W, C] (networks.py:486-496) -> [..., outdim]."""
         lead = obs.shape[:-3]
         x = (obs.to(torch.float32) - 0.5).reshape((-1,) + tuple(obs.shape[-3:])).contiguous()
+        if AG.wants_grad(*self.parameters()):
+            flat = []
+            for L in self.conv_params():
+                flat += [L.W, L.g, L.b]
+            emb = AG.ConvEncoderFn.apply(x, self._size, *flat)
+            return emb.reshape(tuple(lead) + (emb.shape[-1],))
         emb = self.engine.forward(x_f32=x, keep=False)
         return emb.reshape(tuple(lead) + (emb.shape[-1],)).clone()
 
@@ -449,6 +575,14 @@ class ConvDecoder(nn.Module):
     def forward(self, features, dtype=None):
         """networks.py:568-585: features [..., F] -> mean image [..., H, W, C] (+0.5)."""
         lead = features.shape[:-1]
+        if AG.wants_grad(features, *self.parameters()):
+            L = self.conv_params()
+            flat = [self._linear_layer.weight, self._linear_layer.bias]
+            for l in L[:-1]:
+                flat += [l.W, l.g, l.b]
+            flat += [L[-1].W, L[-1].bias]
+            rec = AG.ConvDecoderFn.apply(features.reshape(-1, features.shape[-1]), self._minres, *flat)
+            return rec.reshape(tuple(lead) + tuple(rec.shape[1:]))
         x = features.reshape(-1, features.shape[-1]).to(torch.float32).contiguous()
         rec = self.engine.forward(x, None)
         return rec.reshape(tuple(lead) + tuple(rec.shape[1:])).clone()

@@ -9,9 +9,11 @@ lazily, to the integrator's OWN reference `tools.py` (module-level __getattr__ b
 environment variable DV3_REFERENCE_TOOLS or from a `tools.py` found further down sys.path), so the reference's
 `dreamer.py` runs against this module with no import edits.
 
-Distribution objects are forward-only views over kernel outputs: training never differentiates
-through them (models.WorldModel._train / ImagBehavior._train run the hand-derived backward in
-dv3hip.engine); acting and logging only need values.
+Distribution objects are views over kernel outputs.  The fused training path never differentiates through them
+(models.WorldModel._train / ImagBehavior._train run the hand-derived backward in dv3hip.engine) and acting / logging
+only need values; when a caller builds a loss with autograd on top of them (exploration.Plan2Explore, the causal
+world models: SURVEY.md 8(f) N4) and their parameters carry a graph, every method goes through the matching
+dv3hip.autograd Function -- the same kernels forward and backward.
 """
 from __future__ import annotations
 
@@ -25,6 +27,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from dv3hip import autograd as AG
 from dv3hip import ops
 from dv3hip.params import ParamBucket
 
@@ -77,6 +80,8 @@ class OneHotDist:
         return self._logits
 
     def mode(self):
+        if AG.wants_grad(self._logits):
+            return AG.OneHotSampleFn.apply(self._logits, None, None, self._unimix, True)
         out = torch.empty_like(self._logits)
         return ops.onehot_sample(self._logits, out, unimix=self._unimix, mode=True)
 
@@ -89,6 +94,11 @@ class OneHotDist:
         rng = None
         if noise is None:
             rng = self._rng if self._rng is not None else default_rng(self._logits.device)
+        if AG.wants_grad(self._logits):  # exact one-hot forward, straight-through gradient (tools.py:452-460)
+            out = AG.OneHotSampleFn.apply(self._logits, noise, rng, self._unimix, False)
+            if rng is not None:
+                rng.commit()
+            return out
         ops.onehot_sample(self._logits, out, noise=noise, rng=rng, unimix=self._unimix)
         if rng is not None:
             rng.commit()
@@ -96,11 +106,15 @@ class OneHotDist:
 
     def entropy(self):
         """Entropy per categorical group (callers wrap in Independent to sum over groups)."""
+        if AG.wants_grad(self._logits):
+            return AG.OneHotEntLogpFn.apply(self._logits, None, self._unimix, True)
         ent = torch.empty(self._logits.shape[:-1], device=self._logits.device)
         ops.onehot_ent_logp_fwd(self._logits, None, ent, None, unimix=self._unimix)
         return ent
 
     def log_prob(self, x):
+        if AG.wants_grad(self._logits):
+            return AG.OneHotEntLogpFn.apply(self._logits, x, self._unimix, False)
         lp = torch.empty(self._logits.shape[:-1], device=self._logits.device)
         ops.onehot_ent_logp_fwd(self._logits, x.contiguous(), None, lp, unimix=self._unimix)
         return lp
@@ -134,6 +148,8 @@ class DiscDist:
         self.logits = logits.contiguous()
 
     def mean(self):
+        if AG.wants_grad(self.logits):
+            return AG.DiscModeFn.apply(self.logits)
         out = torch.empty(self.logits.shape[:-1] + (1,), device=self.logits.device)
         return ops.disc_mode_fwd(self.logits, out)
 
@@ -143,6 +159,8 @@ class DiscDist:
         x = x.to(torch.float32)
         if x.dim() == self.logits.dim() and x.shape[-1] == 1:
             x = x[..., 0]
+        if AG.wants_grad(self.logits):
+            return AG.DiscLogProbFn.apply(self.logits, x)
         out = torch.empty(self.logits.shape[:-1], device=self.logits.device)
         return ops.disc_logprob_fwd(self.logits, x.contiguous(), out)
 
@@ -183,6 +201,8 @@ class SymlogDist:
 
     def log_prob(self, value):
         assert self._mode.shape == value.shape
+        if AG.wants_grad(self._mode):
+            return AG.SymlogMSEFn.apply(self._mode, value)
         loss = torch.empty(self._mode.shape[:-1], device=self._mode.device)
         ops.symlog_mse(self._mode, value.to(torch.float32).contiguous(), loss)
         return -loss
@@ -200,14 +220,17 @@ class ContDist:
         self.absmax = absmax
         self._rng = rng
 
+    def _grad(self):
+        return AG.wants_grad(self._mr, self._sr)
+
     @property
     def mean(self):
-        return torch.tanh(self._mr)
+        return AG.TanhFn.apply(self._mr) if self._grad() else torch.tanh(self._mr)
 
     def mode(self):
-        out = torch.tanh(self._mr)
-        if self.absmax is not None:
-            out = out * (self.absmax / torch.clip(torch.abs(out), min=self.absmax))
+        out = self.mean
+        if self.absmax is not None:  # tools.py:584-587: the rescale factor is detached
+            out = out * (self.absmax / torch.clip(torch.abs(out.detach()), min=self.absmax))
         return out
 
     def sample(self, sample_shape=(), noise=None):
@@ -218,17 +241,25 @@ class ContDist:
             noise = torch.empty_like(self._mr)
             ops.fill_normal(noise, rng)
             rng.commit()
+        if self.absmax is None:
+            raise NotImplementedError("ContDist.sample without absmax (the sampling kernel applies the absmax-1 rescale)")
+        if self._grad():
+            return AG.NormalFn.apply(self._mr, self._sr, noise, "sample", self._min, self._max)
         action = torch.empty_like(self._mr)
         ops.actor_normal_fwd(self._mr, self._sr, noise.contiguous(), action, None, min_std=self._min,
                              max_std=self._max)
         return action
 
     def entropy(self):
+        if self._grad():
+            return AG.NormalFn.apply(self._mr, self._sr, None, "entropy", self._min, self._max)
         ent = torch.empty(self._mr.shape[:-1], device=self._mr.device)
         ops.actor_normal_fwd(self._mr, self._sr, None, None, ent, min_std=self._min, max_std=self._max)
         return ent
 
     def log_prob(self, x):
+        if self._grad():
+            return AG.NormalFn.apply(self._mr, self._sr, x, "logp", self._min, self._max)
         lp = torch.empty(self._mr.shape[:-1], device=self._mr.device)
         ops.actor_normal_logp(self._mr, self._sr, x.to(torch.float32).contiguous(), lp, min_std=self._min,
                               max_std=self._max)
@@ -249,6 +280,8 @@ class Bernoulli:
         return torch.round(torch.sigmoid(self._logits))
 
     def log_prob(self, x):
+        if AG.wants_grad(self._logits):
+            return AG.BernoulliLogProbFn.apply(self._logits, x).sum(-1)
         out = torch.empty_like(self._logits)
         ops.bernoulli_logprob_fwd(self._logits, x.to(torch.float32).contiguous(), out)
         return out.sum(-1)
@@ -702,10 +735,15 @@ def _find_reference_tools():
             raise ImportError(f"DV3_REFERENCE_TOOLS={cand}: no such file")
         return cand
     here = os.path.abspath(__file__)
-    for d in sys.path:
+    for d in sys.path:  # DV3_REFERENCE_TOOLS unset: the reference checkout further down sys.path (its own dreamer.py's dir)
         f = os.path.abspath(os.path.join(d or ".", "tools.py"))
         if f != here and os.path.isfile(f):
-            return f
+            try:
+                text = open(f, errors="ignore").read()
+            except OSError:
+                continue
+            if "def simulate(" in text and "class Logger" in text:  # looks like the reference's: only then execute it
+                return f
     return None
 
 
@@ -719,15 +757,23 @@ def _reference_tools():
         spec = importlib.util.spec_from_file_location("_dv3_reference_tools", path)
         mod = importlib.util.module_from_spec(spec)
         sys.modules["_dv3_reference_tools"] = mod
-        spec.loader.exec_module(mod)
+        try:
+            spec.loader.exec_module(mod)
+        except BaseException:
+            sys.modules.pop("_dv3_reference_tools", None)  # never leave a half-initialised module behind
+            raise
+        if not (hasattr(mod, "simulate") and hasattr(mod, "Logger")):
+            sys.modules.pop("_dv3_reference_tools", None)
+            raise ImportError(f"{path} is not the reference's tools.py (no simulate / Logger)")
         _REFERENCE_TOOLS = mod
     return _REFERENCE_TOOLS
 
 
 def __getattr__(name):
     """PEP 562: attributes this module does not define come from the integrator's reference tools.py."""
-    if name.startswith("__"):
-        raise AttributeError(name)
+    if name.startswith("__") or name not in PASSTHROUGH:
+        # only the listed host-side helpers are delegated: a typo or a hasattr() probe never executes a foreign file
+        raise AttributeError(f"module 'tools' (MI355X drop-in) has no attribute {name!r}")
     try:
         ref = _reference_tools()
     except ImportError as e:

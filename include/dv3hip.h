@@ -26,6 +26,10 @@ extern "C" {
 #define DV3_ERR_ARG 10001
 
 int dv3_version(void);
+/* 1 when the library was built with -DDV3_DEV_SWITCHES (`build.py --dev`): only then do the DV3_* A/B environment
+ * switches of the launchers (and of the Python host code, dv3hip/_dev.py) have any effect.  The shipped build
+ * returns 0 and reads no environment variable. */
+int dv3_dev_switches(void);
 
 /* ---- dense layers -------------------------------------------------------------------------------
  * C[M,N] (+)= [A | A2][M,K] * op(B)[K,N] + bias[N] on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).

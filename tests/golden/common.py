@@ -115,6 +115,46 @@ def param_shapes(name: str) -> Dict[str, Tuple[int, ...]]:
     return sh
 
 
+def p2e_param_shapes(name: str) -> Dict[str, Tuple[int, ...]]:
+    """Plan2Explore's own parameters by state_dict name (exploration.py:66-73: `_networks.<i>` = networks.MLP with the
+    default name "NoName"; its `_behavior.actor` / `_behavior.value` / `_behavior._slow_value` have the shapes of the
+    task behaviour's)."""
+    s = SHAPES[name]
+    c = s["p2e"]
+    SD, F = s["stoch"] * s["discrete"], s["stoch"] * s["discrete"] + s["deter"]
+    inp = F + (s["A"] if c["disag_action_cond"] else 0)
+    out = {"stoch": SD, "deter": s["deter"], "embed": s["cnn_depth"] * 8 * 16}[c["disag_target"]]
+    U = c["disag_units"]
+    sh: Dict[str, Tuple[int, ...]] = {}
+    for i in range(c["disag_models"]):
+        for j in range(c["disag_layers"]):
+            sh[f"_networks.{i}.layers.NoName_linear{j}.weight"] = (U, inp if j == 0 else U)
+            sh[f"_networks.{i}.layers.NoName_norm{j}.weight"] = (U,)
+            sh[f"_networks.{i}.layers.NoName_norm{j}.bias"] = (U,)
+        sh[f"_networks.{i}.mean_layer.weight"] = (out, U)
+        sh[f"_networks.{i}.mean_layer.bias"] = (out,)
+    for k, v in param_shapes(name).items():
+        if k.split(".")[0] in ("actor", "value", "_slow_value"):
+            sh["_behavior." + k] = v
+    return sh
+
+
+def make_p2e_weights(name: str, seed: int = 3) -> Dict[str, np.ndarray]:
+    """Deterministic weights of the Plan2Explore module (same scheme as make_weights, its own seed so that the
+    exploration actor / critic differ from the task behaviour's)."""
+    out = {}
+    for k, shp in p2e_param_shapes(name).items():
+        rs = np.random.RandomState((zlib.crc32(k.encode()) + 7919 * seed) & 0x7FFFFFFF)
+        if len(shp) == 1:
+            w = (1.0 + 0.1 * rs.randn(*shp)) if k.endswith(".weight") and "norm" in k else 0.1 * rs.randn(*shp)
+        else:
+            w = rs.randn(*shp) * np.sqrt(2.0 / (shp[0] + shp[1]))
+            if "value" in k and "mean_layer" in k:
+                w *= 0.3
+        out[k] = w.astype(np.float32)
+    return out
+
+
 def make_weights(name: str, seed: int = 0) -> Dict[str, np.ndarray]:
     """Deterministic fp32 weights, one numpy stream per parameter name.
 

@@ -162,9 +162,13 @@ def build_reference(name, tools, networks, models):
         batch_length=s["T"], imag_horizon=s["H"], imag_gradient=s["imag_gradient"],
         encoder=dict(cnn_depth=s["cnn_depth"]), decoder=dict(cnn_depth=s["cnn_depth"]),
         causal_world_model=False, imag_gradient_mix=s.get("imag_gradient_mix", 0.0),
+        actor=dict(layers=s.get("actor_layers", 2)), critic=dict(layers=s.get("critic_layers", 2)),
+        reward_head=dict(layers=s.get("reward_layers", 2)), cont_head=dict(layers=s.get("cont_layers", 2)),
     )
+    if "p2e" in s:
+        ov.update(expl_behavior="plan2explore", **s["p2e"])
     if s["actor_dist"] == "onehot":
-        ov["actor"] = dict(dist="onehot", std="none")
+        ov["actor"].update(dist="onehot", std="none")
     if s["encoder"] == "mlp":
         ov["encoder"].update(mlp_units=s["enc_mlp_units"], mlp_layers=s["enc_mlp_layers"])
         ov["decoder"].update(mlp_units=s["enc_mlp_units"], mlp_layers=s["enc_mlp_layers"])
@@ -369,6 +373,90 @@ def run_config(name, tools, networks, models, full: bool):
           f"value_loss={float(out['value_loss']):.6f}")
 
 
+def run_p2e(name, tools, networks, models):
+    """One exploration update of the reference's exploration.Plan2Explore (exploration.py:86-135) after the world
+    model's own update, exactly as dreamer.py:194-203 orders them: wm._train(data) -> p2e.train(start, context, data).
+    Stored: the ensemble loss / gradients / post-Adam parameters, the intrinsic reward on the imagined states, and
+    the exploration actor's and critic's losses, gradients and post-Adam parameters."""
+    global TAPE
+    sys.path.insert(0, REF)
+    import exploration
+
+    s = common.SHAPES[name]
+    cfg, wm, beh, w = build_reference(name, tools, networks, models)
+    extr = lambda f, st, a: wm.heads["reward"](f).mean()  # dreamer.py:80
+    with contextlib.redirect_stdout(io.StringIO()):
+        p2e = exploration.Plan2Explore(cfg, wm, extr)
+    p2e.requires_grad_(False)
+    pw = common.make_p2e_weights(name)
+    sd = p2e.state_dict()
+    # (`actor.*` are aliases of `_behavior.actor.*`: exploration.py:47 registers the same module twice)
+    own = {k for k in sd if not k.startswith(("_behavior._world_model.", "actor.")) and k != "_behavior.ema_vals"}
+    assert own == set(pw), own ^ set(pw)
+    for k in own:
+        assert tuple(sd[k].shape) == pw[k].shape, (k, sd[k].shape, pw[k].shape)
+        sd[k] = torch.from_numpy(pw[k])
+        if k.startswith("_behavior.actor."):
+            sd[k[len("_behavior."):]] = sd[k]
+    p2e.load_state_dict(sd)
+    data = common.make_batch(name)
+    noise = common.make_noise(name)
+    noise_x = common.make_noise(name, seed=5)  # the exploration behaviour's own imagination draws
+    out = {}
+    quiet = contextlib.redirect_stdout(io.StringIO())
+
+    # gradients as the optimizers see them (after clipping, which is inactive at these norms), captured at Adam.step
+    grabbed = {}
+
+    def grab(tag, named):
+        def hook(opt, args, kwargs):
+            for k, prm in named:
+                grabbed[f"{tag}{k}"] = prm.grad.detach().clone()
+        return hook
+
+    p2e._expl_opt._opt.register_step_pre_hook(grab("_networks.", list(p2e._networks.named_parameters())))
+    p2e._behavior._actor_opt._opt.register_step_pre_hook(grab("_behavior.actor.", list(p2e._behavior.actor.named_parameters())))
+    p2e._behavior._value_opt._opt.register_step_pre_hook(grab("_behavior.value.", list(p2e._behavior.value.named_parameters())))
+    seen = {}
+    stock_reward = p2e._intrinsic_reward
+
+    def spy(feat, state, action):
+        r = stock_reward(feat, state, action)
+        seen["reward"], seen["feat"], seen["action"] = r.detach().clone(), feat.detach().clone(), action.detach().clone()
+        return r
+
+    p2e._intrinsic_reward = spy
+
+    TAPE = Tape(common.observe_tape(noise))
+    with quiet:
+        post, context, _ = wm._train({k: v.copy() for k, v in data.items()})
+    assert TAPE.pos == len(TAPE.arrays)
+    TAPE = Tape(common.imagine_tape(noise_x))
+    with quiet:
+        _, mets = p2e.train(post, context, {k: v.copy() for k, v in data.items()})
+    assert TAPE.pos == len(TAPE.arrays)
+    TAPE = None
+    for k in ("explorer_loss", "explorer_grad_norm", "actor_loss", "actor_grad_norm", "value_loss", "value_grad_norm",
+              "actor_entropy", "EMA_005", "EMA_095", "imag_reward_mean", "imag_reward_std", "target_mean",
+              "value_mean"):
+        out["train/" + k] = np.asarray(mets[k], np.float64)
+    out["imag/reward"] = to_np(seen["reward"])
+    out["imag/feat"] = to_np(seen["feat"])
+    out["imag/action"] = to_np(seen["action"])
+    for k, g in grabbed.items():
+        out["grad/" + k] = to_np(g)
+    for k, v in p2e.state_dict().items():
+        if not k.startswith(("_behavior._world_model.", "actor.")):
+            out["after/" + k] = to_np(v)
+    out["post/stoch"], out["post/deter"] = to_np(post["stoch"]), to_np(post["deter"])
+    out["meta/name"] = np.array(name)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"[golden] wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB, {len(out)} arrays; explorer_loss="
+          f"{float(out['train/explorer_loss']):.6f} actor_loss={float(out['train/actor_loss']):.6f} "
+          f"reward mean {float(out['imag/reward'].mean()):.6f}")
+
+
 def run_video(name, tools, networks, models):
     """WorldModel.video_pred of the reference (models.py:192-213) with injected noise -> {name}_video.npz
     (full output for the tiny config; checksum + the first sequence's rows 0/4/5/T-1 otherwise)."""
@@ -402,7 +490,7 @@ def main():
     tools, networks, models = import_reference()
     install_noise_hooks(tools)
     plan = [("tiny", True), ("tiny_onehot", True), ("tiny_proprio", True), ("tiny_both", True), ("cfg2", False),
-            ("cfg1", False), ("cfg3", False)]
+            ("cfg1", False), ("cfg3", False), ("cfg4_b4", False), ("cfg5_b4", False)]
     for name, full in plan:
         if args.only and name != args.only:
             continue
@@ -410,6 +498,9 @@ def main():
     for name in ("tiny", "cfg2"):
         if args.only in (None, name + "_video"):
             run_video(name, tools, networks, models)
+    for name in ("tiny_p2e", "tiny_p2e_ac"):
+        if args.only in (None, name):
+            run_p2e(name, tools, networks, models)
 
 
 if __name__ == "__main__":
