@@ -141,7 +141,10 @@ class Dreamer(nn.Module):
             staged = self._runner.last_data
             xm = self._expl_behavior.train(self._runner.last_post, self._runner.last_context, staged)[-1]
             mets.update({"expl_" + k: v for k, v in xm.items()})
-        dev = [(k, v._t) for k, v in mets.items() if isinstance(v, models.DeviceScalar)]
+        # device-resident metrics: the snapshots of the fused path (DeviceScalar) and the 0-d tensors an autograd-style
+        # caller's Optimizer.__call__ returns (the explorer)
+        dev = [(k, v._t if isinstance(v, models.DeviceScalar) else v.detach()) for k, v in mets.items()
+               if isinstance(v, (models.DeviceScalar, torch.Tensor))]
         if self._metric_keys != [k for k, _ in dev]:
             self._flush_metrics()
             self._metric_keys = [k for k, _ in dev]
@@ -150,7 +153,7 @@ class Dreamer(nn.Module):
         self._metric_sum.add_(torch.stack([t.reshape(()).to(torch.float32) for _, t in dev]))
         self._metric_n += 1
         for k, v in mets.items():
-            if not isinstance(v, models.DeviceScalar):
+            if not isinstance(v, (models.DeviceScalar, torch.Tensor)):
                 self._metrics.setdefault(k, []).append(v)
 
     def _flush_metrics(self):

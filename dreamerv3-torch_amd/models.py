@@ -592,7 +592,9 @@ class ImagBehavior(nn.Module):
                       action=im["action"].detach().requires_grad_(need_grad))
         state = {"stoch": leaves["stoch"], "deter": leaves["deter"], "logit": st["logit"].detach()}
         with torch.enable_grad() if need_grad else torch.no_grad():
-            feat = self._world_model.dynamics.get_feat(state)
+            # as in the reference, `feat` is detached (models.py:513-517 returns get_feat(state).detach()): gradients
+            # reach the dynamics through `state` and `action` only
+            feat = self._world_model.dynamics.get_feat(state).detach()
             r = objective(feat, state, leaves["action"])
         if not isinstance(r, torch.Tensor) or r.numel() != H * N:
             raise ValueError(f"objective must return one reward per imagined state [H={H}, N={N}, 1]; got "
@@ -732,9 +734,11 @@ class ImagBehavior(nn.Module):
             if custom:
                 # d loss / d reward -> the objective's own graph -> gradients on the imagined stoch / deter / action
                 # (reward[0] never enters a return, so dreward[0] = 0 and row block 0 receives nothing)
-                g_st, g_dt, g_act = torch.autograd.grad(
-                    obj_out, [obj_leaves["stoch"], obj_leaves["deter"], obj_leaves["action"]],
-                    grad_outputs=dreward.view_as(obj_out), allow_unused=True)
+                g_st = g_dt = None
+                if obj_out.requires_grad:  # (an objective of the detached feat alone has no gradient at all)
+                    g_st, g_dt, g_act = torch.autograd.grad(
+                        obj_out, [obj_leaves["stoch"], obj_leaves["deter"], obj_leaves["action"]],
+                        grad_outputs=dreward.view_as(obj_out), allow_unused=True)
                 for buf, gr, w in ((gs, g_st, SD), (gd, g_dt, De)):
                     if gr is None:
                         buf.view(HN, w)[rows].zero_()

@@ -438,7 +438,8 @@ class Optimizer:
             raise ValueError("params are not the parameters this Optimizer was built over")
         self.begin()
         loss.backward(retain_graph=retain_graph)
-        return self.finish(loss.detach())
+        # snapshots: the norm lives in the bucket's state vector, which the next step overwrites
+        return {k: v.detach().clone() for k, v in self.finish(loss.detach()).items()}
 
     def finish(self, loss, allreduce=True):
         """loss: 0-d device tensor (metric only).  Returns the reference's metric dict with device scalars.

@@ -611,15 +611,21 @@ def quantile_05_95(x: Tensor) -> Tensor:
 
 
 def behavior_forward(cfg: PathConfig, p, start: Dict[str, Tensor], act_noise: Tensor, q_prior: Tensor,
-                     ema_vals: Tensor) -> Dict[str, Tensor]:
+                     ema_vals: Tensor, reward_fn=None) -> Dict[str, Tensor]:
     """ImagBehavior._train up to the two scalar losses (models.py:337-429, 620-681).
 
     `ema_vals` [2] is updated in place (models.py:23).  Slow-critic params live under
     `_slow_value.`; the caller applies the EMA update (models.py:683-689) beforehand.
+    reward_fn(feat, states, actions) -> [H,N,1]: the `objective` argument of models.py:327-331 (default: the world
+    model's reward head on the imagined states, dreamer.py:196-199).  As in the reference, `feat` is DETACHED
+    (models.py:513-517 returns get_feat(state).detach()); gradients reach the dynamics through `states` / `actions` only.
     """
     feats, states, actions = imagine(cfg, p, start, act_noise, q_prior)
     sfeat = get_feat(cfg, states)
-    reward = disc_mode(head_logits(p, "heads.reward.", "Reward", cfg.reward_layers, sfeat))
+    if reward_fn is not None:
+        reward = reward_fn(feats, states, actions)
+    else:
+        reward = disc_mode(head_logits(p, "heads.reward.", "Reward", cfg.reward_layers, sfeat))
     ent = actor_entropy(cfg, p, feats)
     disc = cfg.discount * torch.sigmoid(head_logits(p, "heads.cont.", "Cont", cfg.cont_layers, sfeat))
     v_logits = head_logits(p, "value.", "Value", cfg.critic_layers, feats)
@@ -658,6 +664,62 @@ def behavior_forward(cfg: PathConfig, p, start: Dict[str, Tensor], act_noise: Te
         value=value, target=target, weights=weights, normed_target=normed_target,
         actor_loss=actor_loss, value_loss=value_loss, value_logits=v_logits,
     )
+
+
+# --------------------------------------------------------------------------------------
+# Plan2Explore                                                      exploration.py:40-135
+# --------------------------------------------------------------------------------------
+@dataclass
+class P2EConfig:
+    disag_models: int = 10  # configs.yaml:122
+    disag_layers: int = 4  # configs.yaml:124
+    disag_units: int = 400  # configs.yaml:125
+    disag_target: str = "stoch"  # configs.yaml:120
+    disag_offset: int = 1  # configs.yaml:123
+    disag_log: bool = True  # configs.yaml:121
+    disag_action_cond: bool = False  # configs.yaml:126
+    expl_intr_scale: float = 1.0  # configs.yaml:119
+    expl_extr_scale: float = 0.0  # configs.yaml:118
+
+
+# networks.MLP with its defaults dist="normal", std=1.0, min_std=0.1, max_std=1.0 (networks.py:597-600, 614):
+# Normal(tanh(mean), (max_std - min_std) * sigmoid(1.0 + 2.0) + min_std)   (networks.py:693-696)
+P2E_STD = 0.9 / (1.0 + math.exp(-3.0)) + 0.1
+
+
+def p2e_member_mean(c: P2EConfig, pp, i: int, x: Tensor) -> Tensor:
+    """`head(inputs)` of ensemble member i: trunk named "NoName" (networks.py:607) + mean_layer; the distribution's
+    mean == mode (tools.py:581-587, absmax None) is tanh(mean_layer(h))."""
+    pre = f"_networks.{i}."
+    h = mlp_trunk(pp, pre, "NoName", c.disag_layers, x)
+    return torch.tanh(h @ pp[pre + "mean_layer.weight"].t() + pp[pre + "mean_layer.bias"])
+
+
+def p2e_ensemble_loss(c: P2EConfig, pp, inputs: Tensor, targets: Tensor) -> Tensor:
+    """Plan2Explore._train_ensemble (exploration.py:123-133): inputs [B,T,F(+A)], targets [B,T,W] ->
+    -mean_i mean_{b,t} log N(target_{t+offset}; mode_i(input_t), P2E_STD) summed over W."""
+    if c.disag_offset:
+        targets, inputs = targets[:, c.disag_offset:], inputs[:, :-c.disag_offset]
+    targets, inputs = targets.detach(), inputs.detach()
+    likes = []
+    for i in range(c.disag_models):
+        mu = p2e_member_mean(c, pp, i, inputs)
+        lp = -((targets - mu) ** 2) / (2 * P2E_STD**2) - math.log(P2E_STD) - math.log(math.sqrt(2 * math.pi))
+        likes.append(lp.sum(-1).mean()[None])
+    return -torch.mean(torch.cat(likes, 0))
+
+
+def p2e_intrinsic_reward(c: P2EConfig, pp, feat: Tensor, action: Tensor, extr: Optional[Tensor] = None) -> Tensor:
+    """Plan2Explore._intrinsic_reward (exploration.py:108-121): [..,F] -> [..,1]."""
+    x = torch.cat([feat, action], -1) if c.disag_action_cond else feat
+    preds = torch.stack([p2e_member_mean(c, pp, i, x) for i in range(c.disag_models)], 0)
+    disag = torch.mean(torch.std(preds, 0), -1)[..., None]
+    if c.disag_log:
+        disag = torch.log(disag)
+    reward = c.expl_intr_scale * disag
+    if c.expl_extr_scale:
+        reward = reward + c.expl_extr_scale * extr
+    return reward
 
 
 # --------------------------------------------------------------------------------------

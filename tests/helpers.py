@@ -87,6 +87,9 @@ def oracle_update(name, threads=None, piecewise=False):
             if k.startswith("value."):
                 sk = "_slow_value." + k[len("value."):]
                 p[sk].copy_(cfg.slow_target_fraction * p[k] + (1 - cfg.slow_target_fraction) * p[sk])
+    # the state the behaviour update runs on: world model after its Adam step, slow critic after its EMA step
+    res["params_mid"] = {k: v.detach().clone() for k, v in p.items()
+                         if k.split(".")[0] in WM_PREFIXES or k.startswith("_slow_value.")}
     ema = torch.zeros(2)
     bout = O.behavior_forward(cfg, p, start, n["act"], n["q_img"], ema)
     ga = torch.autograd.grad(bout["actor_loss"], [p[k] for k in akeys], retain_graph=True)
@@ -159,3 +162,71 @@ def forced_draws(name, exp, beh_key="beh", device="cuda"):
     if s["actor_dist"] == "onehot":
         im_force["force_act"] = to_time_major_rows(onehot_index(b["actions"]), B, T).contiguous().to(device)
     return wm_force, im_force
+
+
+def oracle_p2e_update(name):
+    """dreamer.py:194-203 in the oracle for expl_behavior 'plan2explore': the world model's update, then one
+    exploration update (ensemble regression + Adam, then the exploration behaviour on the intrinsic reward).
+    -> dict with the quantities tests/golden/<name>.npz holds from the reference's exploration.Plan2Explore.train."""
+    s = common.SHAPES[name]
+    cfg = common.path_config(name)
+    c = O.P2EConfig(**s["p2e"])
+    p = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in common.make_weights(name).items()}
+    pp = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in common.make_p2e_weights(name).items()}
+    n = {k: torch.from_numpy(v) for k, v in common.make_noise(name).items()}
+    nx = {k: torch.from_numpy(v) for k, v in common.make_noise(name, seed=5).items()}
+    data = common.make_batch(name)
+    out = O.wm_forward(cfg, p, data, n["q_prior"], n["q_post"])
+    wkeys = [k for k in p if k.split(".")[0] in WM_PREFIXES]
+    grads = torch.autograd.grad(out["model_loss"], [p[k] for k in wkeys])
+    start = {k: v.detach() for k, v in out["post"].items()}
+    feat = O.get_feat(cfg, start)
+    embed = out["embed"].detach()
+    with torch.no_grad():
+        st = dict(step=0, m=[torch.zeros_like(p[k]) for k in wkeys], v=[torch.zeros_like(p[k]) for k in wkeys])
+        O.clip_and_adam([p[k] for k in wkeys], list(grads), st, lr=1e-4, eps=1e-8, clip=1000.0)
+    # ---- ensemble regression (exploration.py:88-103)
+    B, T = s["B"], s["T"]
+    target = {"stoch": start["stoch"].reshape(B, T, -1), "deter": start["deter"], "embed": embed}[c.disag_target]
+    inputs = feat
+    if c.disag_action_cond:
+        inputs = torch.cat([inputs, torch.from_numpy(data["action"])], -1)
+    ekeys = [k for k in pp if k.startswith("_networks.")]
+    eloss = O.p2e_ensemble_loss(c, pp, inputs, target)
+    eg = torch.autograd.grad(eloss, [pp[k] for k in ekeys])
+    res = dict(explorer_loss=eloss.detach(), explorer_grads=dict(zip(ekeys, eg)), post=start)
+    with torch.no_grad():
+        st = dict(step=0, m=[torch.zeros_like(pp[k]) for k in ekeys], v=[torch.zeros_like(pp[k]) for k in ekeys])
+        res["explorer_grad_norm"] = O.clip_and_adam([pp[k] for k in ekeys], list(eg), st, lr=1e-4, eps=1e-8, clip=1000.0)
+    # ---- the exploration behaviour (its own actor / critic) on the intrinsic reward
+    q = dict(p)
+    for k, v in pp.items():
+        if k.startswith("_behavior."):
+            q[k[len("_behavior."):]] = v
+    with torch.no_grad():
+        for k in list(q):
+            if k.startswith("value."):
+                sk = "_slow_value." + k[len("value."):]
+                q[sk].copy_(cfg.slow_target_fraction * q[k] + (1 - cfg.slow_target_fraction) * q[sk])
+
+    def reward_fn(sfeat, states, actions):
+        extr = None
+        if c.expl_extr_scale:
+            extr = O.disc_mode(O.head_logits(q, "heads.reward.", "Reward", cfg.reward_layers, sfeat))
+        return O.p2e_intrinsic_reward(c, pp, sfeat, actions, extr)
+
+    ema = torch.zeros(2)
+    b = O.behavior_forward(cfg, q, start, nx["act"], nx["q_img"], ema, reward_fn=reward_fn)
+    akeys = [k for k in q if k.startswith("actor.")]
+    vkeys = [k for k in q if k.startswith("value.")]
+    ga = torch.autograd.grad(b["actor_loss"], [q[k] for k in akeys], retain_graph=True)
+    gv = torch.autograd.grad(b["value_loss"], [q[k] for k in vkeys])
+    res.update(beh=b, ema=ema, actor_grads=dict(zip(akeys, ga)), value_grads=dict(zip(vkeys, gv)))
+    with torch.no_grad():
+        for keys, gr, nm in ((akeys, ga, "actor"), (vkeys, gv, "value")):
+            st = dict(step=0, m=[torch.zeros_like(q[k]) for k in keys], v=[torch.zeros_like(q[k]) for k in keys])
+            res[nm + "_grad_norm"] = O.clip_and_adam([q[k] for k in keys], list(gr), st, lr=3e-5, eps=1e-5, clip=100.0)
+    res["p2e_after"] = {k: v.detach() for k, v in pp.items()}
+    res["wm_after"] = {k: p[k].detach() for k in wkeys}
+    res["data"], res["noise"], res["noise_x"], res["cfg"], res["p2e_cfg"] = data, n, nx, cfg, c
+    return res

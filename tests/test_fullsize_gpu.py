@@ -1,5 +1,7 @@
 """Full-size parity on the MI355X for the BASELINE configs that have a reference fixture
-(cfg 1 dmc_proprio, cfg 2 dmc_vision, cfg 3 atari100k shapes: tests/golden/cfg{1,2,3}.npz):
+(cfg 1 dmc_proprio, cfg 2 dmc_vision, cfg 3 atari100k shapes: tests/golden/cfg{1,2,3}.npz; and the crafter-width
+layers of cfg 4 / cfg 5 -- cnn_depth 96, deter 4096 / 2048, hidden = units = 1024, five-layer heads -- at the batch
+the reference finishes in a minute on the build container's CPU: tests/golden/cfg{4,5}_b4.npz):
 
 * against the golden vectors the REFERENCE produced for the config (world-model outputs, imagination rows,
   lambda-returns, per-frame losses, scalar losses, gradient and post-Adam parameter checksums),
@@ -26,6 +28,10 @@ from tests.golden import common
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CONFIGS = ["cfg2", "cfg1", "cfg3"]
+REF_CONFIGS = CONFIGS + ["cfg4_b4", "cfg5_b4"]
+# Teacher-forced sample flips measured on the MI355X (run A: the forward kernels are deterministic, so these are
+# exact): asserted, not just printed.  cfg 3's one flip in 1 079 296 draws is an argmax tie within one ulp.
+EXPECTED_FLIPS = {"cfg1": (0, 0), "cfg2": (0, 0), "cfg3": (1, 1), "cfg4_b4": (0, 0), "cfg5_b4": (0, 0)}  # (wm, im) upper bounds
 # fp32 tolerances (north_star: outputs within 1e-4), relative to max(1, max|ref|) of the tensor compared
 TOL_OUT = 1e-4  # logits, deter, pixels, returns, values, rewards, actions
 TOL_LOSS = 2e-5  # scalar losses (means over >= 1024 rows) against the live oracle
@@ -77,7 +83,7 @@ def n_draws(s, onehot_actor):
     return wm, im
 
 
-@pytest.fixture(scope="module", params=CONFIGS)
+@pytest.fixture(scope="module", params=REF_CONFIGS)
 def full(request):
     """Oracle expectation + two teacher-forced GPU runs: (A) the pieces, world-model forward/backward and the
     behaviour losses on the NOT yet updated world model (what the golden file's imag/*, grad/* hold); (B) the
@@ -140,6 +146,9 @@ def test_sample_flip_rate(full):
     assert full["wm_flips"] <= max(1, MAX_FLIP_RATE * d_wm), (full["wm_flips"], d_wm)
     assert full["im_flips"] <= max(1, MAX_FLIP_RATE * d_im), (full["im_flips"], d_im)
     assert full["B"]["flips"] <= max(2, MAX_FLIP_RATE * (d_wm + d_im)), (full["B"]["flips"], d_wm + d_im)
+    # the measured counts themselves (README / DESIGN quote them): world model + imagination of run A together
+    lim_wm, lim_im = EXPECTED_FLIPS[full["name"]]
+    assert full["wm_flips"] + full["im_flips"] <= max(lim_wm, lim_im), (full["name"], full["wm_flips"], full["im_flips"])
 
 
 def test_world_model_outputs_vs_oracle_and_reference(full):
@@ -249,26 +258,33 @@ def test_full_update_vs_oracle_and_reference(full):
     un = lambda x: Hh.from_time_major_rows(x, B, T)
     mw, mb, eb = Bv["mets_wm"], Bv["mets_beh"], exp["beh"]
     f = lambda d, k: torch.tensor(float(d[k]))
+    # This run's rollout uses the world model AFTER the GPU's own Adam step.  At crafter widths (100-180 M parameters)
+    # a few hundred entries whose gradient is ~0 land up to 2 lr away from the oracle's (sign-like first Adam step on
+    # a rounding-level gradient): test_rollout_on_the_oracles_updated_weights counts them and shows that on IDENTICAL
+    # updated weights the rollout is within 1e-4; here the bound is the measured effect of those entries.
+    wide = s["deter"] >= 2048
+    TOL_UPD, TOL_UPD_LOSS = (1e-3, 2e-4) if wide else (TOL_OUT, TOL_LOSS)
     close(f(mw, "model_loss"), exp["wm"]["model_loss"], TOL_LOSS, "model_loss")
     close(f(mw, "model_grad_norm"), exp["model_grad_norm"], 2e-4, "model_grad_norm")
-    close(f(mb, "actor_loss"), eb["actor_loss"], TOL_LOSS, "actor_loss")
-    close(f(mb, "value_loss"), eb["value_loss"], TOL_LOSS, "value_loss")
-    close(f(mb, "actor_grad_norm"), exp["actor_grad_norm"], 3e-4, "actor_grad_norm")
-    close(f(mb, "value_grad_norm"), exp["value_grad_norm"], 3e-4, "value_grad_norm")
+    close(f(mb, "actor_loss"), eb["actor_loss"], TOL_UPD_LOSS, "actor_loss")
+    close(f(mb, "value_loss"), eb["value_loss"], TOL_UPD_LOSS, "value_loss")
+    close(f(mb, "actor_grad_norm"), exp["actor_grad_norm"], 10 * TOL_UPD if wide else 3e-4, "actor_grad_norm")
+    close(f(mb, "value_grad_norm"), exp["value_grad_norm"], 10 * TOL_UPD if wide else 3e-4, "value_grad_norm")
     assert torch.equal(un(Bv["imag"]["stoch"]).cpu(), eb["states"]["stoch"].detach())
-    close(un(Bv["last"]["target"]), eb["target"].detach().squeeze(-1), TOL_OUT, "lambda-return (updated model)")
-    close(un(Bv["last"]["reward"]), eb["reward"].detach().squeeze(-1), TOL_OUT, "reward (updated model)")
-    close(un(Bv["last"]["value"]), eb["value"].detach().squeeze(-1), TOL_OUT, "value (updated model)")
-    close(Bv["beh"].ema_vals, exp["ema"], TOL_OUT, "ema_vals")
-    close(Bv["beh"].ema_vals, g["ema_vals_after"], TOL_OUT, "ema_vals vs reference")  # (aliases the buffer after _train)
+    close(un(Bv["last"]["target"]), eb["target"].detach().squeeze(-1), TOL_UPD, "lambda-return (updated model)")
+    close(un(Bv["last"]["reward"]), eb["reward"].detach().squeeze(-1), TOL_UPD, "reward (updated model)")
+    close(un(Bv["last"]["value"]), eb["value"].detach().squeeze(-1), TOL_UPD, "value (updated model)")
+    close(Bv["beh"].ema_vals, exp["ema"], TOL_UPD, "ema_vals")
+    close(Bv["beh"].ema_vals, g["ema_vals_after"], TOL_UPD, "ema_vals vs reference")  # (aliases the buffer after _train)
     # the reference's own _train metrics for this minibatch
     for k in ("model_loss", "kl", "prior_ent", "post_ent"):
         close(f(mw, k), g["train/" + k], TOL_LOSS if k == "model_loss" else TOL_OUT, k + " vs reference")
     close(f(mw, "model_grad_norm"), g["train/model_grad_norm"], 2e-4, "model_grad_norm vs reference")
-    for k, tol in (("actor_loss", TOL_LOSS_REF), ("value_loss", TOL_LOSS_REF), ("actor_grad_norm", 3e-4),
-                   ("value_grad_norm", 3e-4), ("actor_entropy", TOL_OUT), ("EMA_005", TOL_OUT), ("EMA_095", TOL_OUT),
-                   ("target_mean", TOL_OUT), ("target_std", TOL_OUT), ("imag_reward_mean", TOL_OUT),
-                   ("value_mean", TOL_OUT)):
+    for k, tol in (("actor_loss", max(TOL_LOSS_REF, TOL_UPD_LOSS)), ("value_loss", max(TOL_LOSS_REF, TOL_UPD_LOSS)),
+                   ("actor_grad_norm", 10 * TOL_UPD if wide else 3e-4), ("value_grad_norm", 10 * TOL_UPD if wide else 3e-4),
+                   ("actor_entropy", TOL_UPD), ("EMA_005", TOL_UPD), ("EMA_095", TOL_UPD),
+                   ("target_mean", TOL_UPD), ("target_std", TOL_UPD), ("imag_reward_mean", TOL_UPD),
+                   ("value_mean", TOL_UPD)):
         close(f(mb, k), g["train/" + k], tol, k + " vs reference")
     # Adam-updated parameters: oracle tensors and the reference's checksums
     sd = dict(Bv["wm"].state_dict())
@@ -288,6 +304,62 @@ def test_full_update_vs_oracle_and_reference(full):
         # abs-sum moves by at most (outliers <= 5e-3 n) * 2 lr + n * 2e-6 rounding
         assert abs(cs[1] - ref_cs[1]) <= n * (2e-6 + 5e-3 * 2.1 * this_lr) + 1e-9, f"after checksum {k}"
         assert abs(cs[2] - ref_cs[2]) <= 2.1 * this_lr + 2e-6, f"after max {k}"
+
+
+def test_rollout_on_the_oracles_updated_weights(full):
+    """What separates the GPU's updated world model from the oracle's, measured: (1) the number of world-model
+    parameters that differ by more than 2e-6 after the first Adam step and the largest difference (bounded by 2 lr:
+    a sign-like step on a rounding-level gradient); (2) with the ORACLE's updated world model and slow critic loaded
+    into the GPU modules, the imagination rollout, rewards, values, lambda-returns, both losses and every actor /
+    critic gradient are within the 1e-4 bar at every width -- the rollout kernels carry no error of their own."""
+    name, s, exp, Bv = full["name"], full["s"], full["exp"], full["B"]
+    B, T = s["B"], s["T"]
+    mid = exp["params_mid"]
+    sd = Bv["wm"].state_dict()
+    n_diff = n_all = 0
+    worst = 0.0
+    for k, v in sd.items():
+        d = (v.detach().cpu().double() - mid[k].double()).abs()
+        n_diff += int((d > 2e-6).sum())
+        n_all += d.numel()
+        worst = max(worst, float(d.max()))
+    print(f"\n[{name}] world-model parameters differing by > 2e-6 after the first Adam step: {n_diff} of {n_all} "
+          f"({n_diff / n_all:.2e}); largest difference {worst:.2e} (lr 1e-4)")
+    assert worst <= 2.1e-4 and n_diff <= 5e-3 * n_all
+    cfg, wm, beh = Hh.build_models(name)
+    wsd = wm.state_dict()
+    for k in wsd:
+        wsd[k] = mid[k]
+    wm.load_state_dict(wsd)
+    bsd = beh.state_dict()
+    for k in bsd:
+        if k.startswith("_slow_value."):
+            bsd[k] = mid[k]
+        elif k.startswith("_world_model."):
+            bsd[k] = mid[k[len("_world_model."):]]
+    beh.load_state_dict(bsd)
+    flips = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _, im_noise = gpu_noise(name, exp, "beh", flips)
+    beh._update_slow_target = lambda: None  # already applied in params_mid
+    # the oracle's posterior as a [B,T,...] view of time-major storage, which is how WorldModel._train hands it over
+    # (rows of the rollout are then t*B+b, the order gpu_noise lays the draws out in)
+    start = {k: v.detach().cuda().transpose(0, 1).contiguous().transpose(0, 1) for k, v in exp["wm"]["post"].items()}
+    beh.train_fwd_bwd(start, noise=im_noise)
+    (_, imag_state, action, weights), _, (aloss, vloss) = beh._pending
+    un = lambda x: Hh.from_time_major_rows(x, B, T)
+    eb = exp["beh"]
+    assert int(flips.item()) <= 1, f"{int(flips.item())} teacher-forced flips"
+    assert torch.equal(un(imag_state["stoch"]).cpu(), eb["states"]["stoch"].detach()), "imagined states differ"
+    close(un(imag_state["deter"]), eb["states"]["deter"], TOL_OUT, "imag deter (oracle-updated weights)")
+    close(un(action), eb["actions"], TOL_OUT, "imag action (oracle-updated weights)")
+    close(un(beh._last["reward"]), eb["reward"].squeeze(-1), TOL_OUT, "reward (oracle-updated weights)")
+    close(un(beh._last["value"]), eb["value"].squeeze(-1), TOL_OUT, "value (oracle-updated weights)")
+    close(un(beh._last["target"]), eb["target"].squeeze(-1), TOL_OUT, "lambda-return (oracle-updated weights)")
+    close(aloss, eb["actor_loss"], TOL_LOSS, "actor_loss (oracle-updated weights)")
+    close(vloss, eb["value_loss"], TOL_LOSS, "value_loss (oracle-updated weights)")
+    params = dict(beh.named_parameters())
+    for k, ref in list(exp["actor_grads"].items()) + list(exp["value_grads"].items()):
+        close(params[k].grad, ref, TOL_GRAD, "grad (oracle-updated weights) " + k, floor=1e-12)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -200,7 +200,7 @@ def test_full_update_matches_reference_train(name):
         close(p[k], g["after/" + k], tol=1e-6, what="after/" + k)
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg1", "cfg3"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg1", "cfg3", "cfg4_b4", "cfg5_b4"])
 def test_full_size_slices_and_checksums(name):
     """Full-size configs: stored row slices + whole-tensor checksums of the reference's outputs, world model and
     behaviour (imagination rows, lambda-returns, losses) -- this is what pins the oracle the GPU tests use at
@@ -245,6 +245,33 @@ def test_full_size_slices_and_checksums(name):
     # array aliases the module buffer; it is compared in the full-update tests)
 
 
+@pytest.mark.parametrize("name", ["cfg4_b4", "cfg5_b4"])
+def test_crafter_width_gradients_and_update(name):
+    """Crafter-size layers (configs.yaml:158-174: cnn_depth 96, deter 4096 / 2048, hidden = units = 1024; cfg5_b4
+    also the 5-layer actor / reward / cont heads, one-hot actor, reinforce) at batch 4 x 8, horizon 5: every gradient
+    of the three losses (whole-tensor checksums of the reference's), the three grad norms, and the reference's own
+    `_train` metrics after its optimizer steps -- the pin of the oracle at BASELINE cfg 4 / cfg 5 widths."""
+    from tests import helpers as Hh
+
+    g = load(name)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    r = Hh.oracle_update(name, piecewise=True)
+    for k, v in r["wm_grads"].items():
+        check_sum(g, "grad/" + k, v.numpy(), tol=2e-4)
+    for k, v in r["actor_grads0"].items():
+        check_sum(g, "grad/actor." + k[len("actor."):], v.numpy(), tol=2e-4)
+    for k, v in r["value_grads0"].items():
+        check_sum(g, "grad/value." + k[len("value."):], v.numpy(), tol=2e-4)
+    close(r["model_grad_norm"], g["model_grad_norm"], tol=2e-3, what="model_grad_norm")
+    close(r["wm"]["model_loss"], g["train/model_loss"], tol=1e-5, what="train/model_loss")
+    close(r["beh"]["actor_loss"], g["train/actor_loss"], tol=2e-4, what="train/actor_loss")
+    close(r["beh"]["value_loss"], g["train/value_loss"], tol=2e-4, what="train/value_loss")
+    close(r["actor_grad_norm"], g["train/actor_grad_norm"], tol=2e-3, what="train/actor_grad_norm")
+    close(r["value_grad_norm"], g["train/value_grad_norm"], tol=2e-3, what="train/value_grad_norm")
+    close(r["ema"][0], g["train/EMA_005"], tol=2e-4, what="EMA_005")
+    close(r["ema"][1], g["train/EMA_095"], tol=2e-4, what="EMA_095")
+
+
 @pytest.mark.parametrize("name", ["tiny", "cfg2"])
 def test_video_pred_matches_reference(name):
     """Open-loop prediction video (models.py:192-213) against the reference's own output."""
@@ -261,3 +288,34 @@ def test_video_pred_matches_reference(name):
     else:
         T = v.shape[1]
         close(v[0, [0, 4, 5, T - 1]], g["video_rows"], what="video rows")
+
+
+@pytest.mark.parametrize("name", ["tiny_p2e", "tiny_p2e_ac"])
+def test_plan2explore_update_matches_reference(name):
+    """The oracle's restatement of exploration.Plan2Explore.train (ensemble regression + Adam, intrinsic reward, the
+    exploration behaviour's actor / critic update) against the reference's own run (tests/golden/make_golden.py run_p2e)."""
+    from tests import helpers as Hh
+
+    g = load(name)
+    r = Hh.oracle_p2e_update(name)
+    s = common.SHAPES[name]
+    B, T = s["B"], s["T"]
+    close(r["post"]["stoch"], g["post/stoch"], what="post/stoch")
+    close(r["explorer_loss"], g["train/explorer_loss"], tol=1e-6, what="explorer_loss")
+    close(r["explorer_grad_norm"], g["train/explorer_grad_norm"], tol=1e-4, what="explorer_grad_norm")
+    for k, v in r["explorer_grads"].items():
+        close(v, g["grad/" + k], tol=2e-4, what="grad/" + k)
+    b = r["beh"]
+    close(b["reward"], g["imag/reward"], tol=2e-5, what="imag/reward")
+    close(b["actions"], g["imag/action"], tol=2e-5, what="imag/action")
+    close(b["actor_loss"], g["train/actor_loss"], tol=1e-5, what="actor_loss")
+    close(b["value_loss"], g["train/value_loss"], tol=1e-5, what="value_loss")
+    close(r["ema"][0], g["train/EMA_005"], what="EMA_005")
+    close(r["ema"][1], g["train/EMA_095"], what="EMA_095")
+    close(r["actor_grad_norm"], g["train/actor_grad_norm"], tol=2e-4, what="actor_grad_norm")
+    close(r["value_grad_norm"], g["train/value_grad_norm"], tol=2e-4, what="value_grad_norm")
+    for nm in ("actor", "value"):
+        for k, v in r[nm + "_grads"].items():
+            close(v, g["grad/_behavior." + k], tol=2e-4, what="grad/_behavior." + k)
+    for k, v in r["p2e_after"].items():
+        close(v, g["after/" + k], tol=1e-6, what="after/" + k)

@@ -94,7 +94,9 @@ def test_behaviour_update(tiny_run):
     # This rollout runs on the world model AFTER its Adam step (dreamer.py:194-200).  With 100-180 M parameters (the
     # crafter-size cells) a few hundred entries whose gradient is ~0 differ by up to 2 lr between two fp32 summation
     # orders (test_world_model_gradients_and_adam_step), which moves the imagined states by a few 1e-4; the rollout on
-    # IDENTICAL weights is held to 1e-4 in test_imagination_on_identical_weights below (measured 1e-6).
+    # IDENTICAL weights is held to 1e-4 in test_imagination_on_identical_weights below (measured 1e-6), and on the
+    # oracle's UPDATED weights in test_fullsize_gpu.py::test_rollout_on_the_oracles_updated_weights, which also counts
+    # the differing parameters.
     tol = 1e-3 if s["deter"] >= 2048 else TOL
     assert torch.equal(unperm(imag_state["stoch"]).cpu(), eb["states"]["stoch"].detach()), "imagined samples differ"
     close(unperm(imag_state["deter"]), eb["states"]["deter"], tol=tol, what="imag deter")
