@@ -131,7 +131,8 @@ def phase_timers(wm, beh, data, H, t_upd_ms, reps=10):
     ops.PROFILE.start()
     beh._imagine_fwd(post, H)
     prof = ops.PROFILE.stop()
-    gflop = sum(v["flops"] for v in prof.values()) / 1e9
+    gflop = sum(v["flops"] for v in prof.values()) / 1e9  # dense-equivalent: the gather layers priced as the Linear they replace
+    gflop_mfma = sum(v["flops"] for k, v in prof.items() if k.startswith(("gemm_kernel", "conv"))) / 1e9
     t_img = replay_ms(lambda: beh._imagine_fwd(post, H))
 
     def behaviour():
@@ -141,7 +142,7 @@ def phase_timers(wm, beh, data, H, t_upd_ms, reps=10):
     t_beh = replay_ms(behaviour)
     return {"T_upd_ms": t_upd_ms, "T_beh_ms": t_beh, "T_img_ms": t_img,
             "method": "hipGraph replay of the phase, HIP events, median of 10",
-            "imagine_fwd_gflop": gflop, "imagine_fwd_tflops": gflop / t_img}
+            "imagine_fwd_gflop": gflop, "imagine_fwd_gflop_mfma": gflop_mfma, "imagine_fwd_tflops": gflop / t_img}
 
 
 def launch_ranks(n: int) -> int:
@@ -175,6 +176,52 @@ def launch_ranks(n: int) -> int:
     return rc
 
 
+def secondary_config(name, device, steps, warmup):
+    """A second BASELINE config measured in the SAME run on rank 0 (cfg 3 = the largest `1xMI355X` config of
+    BASELINE.json): time per update over `steps` hipGraph replays, T_img, and the dominant MFMA kernel's fraction."""
+    import models
+    import tools
+    from dv3hip import ops, shapes
+    from dv3hip.graph import UpdateRunner
+
+    shape = shapes.SHAPES[name]
+    B, T, H = shape["B"], shape["T"], shape["H"]
+    torch.manual_seed(0)
+    cfg = shapes.make_config(name, str(device))
+    wm = models.WorldModel(shapes.obs_space(name), None, 0, cfg).to(device)
+    beh = models.ImagBehavior(cfg, wm).to(device)
+    wm.requires_grad_(False), beh.requires_grad_(False)
+    data = synthetic_batch(name, seed=0, device=device)
+    runner = UpdateRunner(wm, beh)
+    for _ in range(warmup):
+        runner.step(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step(data)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    loss = float(runner.last_metrics["model_loss"])
+    ops.PROFILE.by_shape = False
+    ops.PROFILE.start()
+    runner.step(data, eager=True)
+    prof = ops.PROFILE.stop()
+    eng = {k: v for k, v in prof.items() if v["flops"] > 0 and k.startswith(("gemm_kernel", "conv"))
+           and "skinny16" not in k and "narrowN" not in k}
+    dom = max(eng, key=lambda k: eng[k]["ms"])
+    ach = eng[dom]["flops"] / (eng[dom]["ms"] * 1e-3) / 1e12
+    tm = phase_timers(wm, beh, data, H, ms, reps=5)
+    return {"workload": f"{name}: {WORKLOADS.get(name, name)}, batch {B} x seq {T}, horizon {H}", "ms_per_step": ms,
+            "value": B * T * H / (ms * 1e-3), "unit": "imagination-steps/s", "steps": steps, "warmup": warmup,
+            "model_loss": loss,
+            "roofline": {"kernel": dom, "kernel_symbol": ops.kernel_symbol(dom), "achieved": ach,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                         "avg_launch_us": eng[dom]["ms"] * 1e3 / eng[dom]["launches"]},
+            "T_img_ms": tm["T_img_ms"], "T_beh_ms": tm["T_beh_ms"],
+            "T_img_frac": tm["imagine_fwd_tflops"] / PEAK_F32_MFMA_TFLOPS,
+            "T_img_frac_mfma_executed": tm["imagine_fwd_gflop_mfma"] / tm["T_img_ms"] / PEAK_F32_MFMA_TFLOPS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +231,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--by-shape", action="store_true", help="roofline leg: key GEMM launches by (M,N,K) too")
+    ap.add_argument("--also", default="cfg3", help="second config measured in the same run on one GPU ('' = none)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -322,12 +370,17 @@ def main():
     if world == 1:
         timers = phase_timers(wm, beh, data, H, elapsed / args.steps * 1e3)
         if roofline is not None:
+            g_mfma = timers.pop("imagine_fwd_gflop_mfma")
             roofline["imagine_fwd"] = {
-                "gflop_executed": timers.pop("imagine_fwd_gflop"), "ms": timers["T_img_ms"],
+                "gflop_dense_equivalent": timers.pop("imagine_fwd_gflop"), "ms": timers["T_img_ms"],
                 "achieved": timers["imagine_fwd_tflops"], "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
                 "frac": timers.pop("imagine_fwd_tflops") / PEAK_F32_MFMA_TFLOPS,
-                "note": "MFMA utilisation of the imagination rollout (15 actor evaluations + 14 img_steps at 1024 "
-                        "rows; the discarded 15th successor of models.py:546 is not computed)"}
+                "gflop_mfma_executed": g_mfma,
+                "frac_mfma_executed": g_mfma / timers["T_img_ms"] / PEAK_F32_MFMA_TFLOPS,
+                "note": "imagination rollout (H actor evaluations + H-1 img_steps on B*T rows; the discarded H-th "
+                        "successor of models.py:546 is not computed).  frac = SURVEY 8(d) algorithmic FLOPs (the "
+                        "one-hot gather layers priced as the Linear they replace) / T_img / peak; frac_mfma_executed "
+                        "= what the MFMA kernels actually multiply / T_img / peak"}
 
     # ---- PCIe-inclusive rate (never `value`): every step stages a fresh HOST batch through the pinned,
     # double-buffered stager (dv3hip/staging.py), overlapped with the previous update
@@ -344,6 +397,10 @@ def main():
             runner.step(stager.stage(host))
         torch.cuda.synchronize()
         timers["T_upd_host_staged_ms"] = (time.perf_counter() - t0) / args.steps * 1e3
+
+    others = None
+    if rank == 0 and world == 1 and args.also and args.also != name:
+        others = {args.also: secondary_config(args.also, device, steps=max(5, args.steps // 2), warmup=3)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -366,7 +423,7 @@ def main():
                        "global_batch": B * world, "seq_len": T, "horizon": H, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if (runner.use_graph and not args.no_graph) else "eager"},
             "model_loss": loss, "timers": timers,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "configs": others,
         }
         print(json.dumps(out))
     if world > 1:

@@ -196,8 +196,12 @@ def test_world_model_gradients_vs_oracle_and_reference(full):
         worst = max(worst, close(A["wm_grads"][k], ref, TOL_GRAD, "grad " + k, floor=1e-12))
         checksum_close(A["wm_grads"][k], g["sum/grad/" + k], TOL_GRAD, "grad checksum vs reference " + k)
     gn = torch.sqrt(sum((v.double() ** 2).sum() for v in A["wm_grads"].values()))
-    close(gn, exp["model_grad_norm"], 2e-4, "model grad norm")
+    # tight against the float64 norms (of the oracle's gradient tensors; the fixture's is accumulated in float64 too);
+    # torch's own float32 clip_grad_norm_ scalar drifts by ~1e-3 over 100-180 M parameters on the CPU
+    true_norm = torch.sqrt(sum((v.double() ** 2).sum() for v in exp["wm_grads"].values()))
+    close(gn, true_norm, 2e-5, "model grad norm (float64)")
     close(gn, g["model_grad_norm"], 2e-4, "model grad norm vs reference")
+    close(gn, exp["model_grad_norm"], 2e-3 if full["s"]["deter"] >= 2048 else 2e-4, "model grad norm (oracle's float32 scalar)")
     print(f"\n[{full['name']}] worst world-model gradient error (relative to the tensor's max): {worst:.2e}")
 
 
@@ -265,7 +269,7 @@ def test_full_update_vs_oracle_and_reference(full):
     wide = s["deter"] >= 2048
     TOL_UPD, TOL_UPD_LOSS = (1e-3, 2e-4) if wide else (TOL_OUT, TOL_LOSS)
     close(f(mw, "model_loss"), exp["wm"]["model_loss"], TOL_LOSS, "model_loss")
-    close(f(mw, "model_grad_norm"), exp["model_grad_norm"], 2e-4, "model_grad_norm")
+    close(f(mw, "model_grad_norm"), exp["model_grad_norm"], 2e-3 if wide else 2e-4, "model_grad_norm")
     close(f(mb, "actor_loss"), eb["actor_loss"], TOL_UPD_LOSS, "actor_loss")
     close(f(mb, "value_loss"), eb["value_loss"], TOL_UPD_LOSS, "value_loss")
     close(f(mb, "actor_grad_norm"), exp["actor_grad_norm"], 10 * TOL_UPD if wide else 3e-4, "actor_grad_norm")
@@ -279,7 +283,7 @@ def test_full_update_vs_oracle_and_reference(full):
     # the reference's own _train metrics for this minibatch
     for k in ("model_loss", "kl", "prior_ent", "post_ent"):
         close(f(mw, k), g["train/" + k], TOL_LOSS if k == "model_loss" else TOL_OUT, k + " vs reference")
-    close(f(mw, "model_grad_norm"), g["train/model_grad_norm"], 2e-4, "model_grad_norm vs reference")
+    close(f(mw, "model_grad_norm"), g["train/model_grad_norm"], 2e-3 if wide else 2e-4, "model_grad_norm vs reference")
     for k, tol in (("actor_loss", max(TOL_LOSS_REF, TOL_UPD_LOSS)), ("value_loss", max(TOL_LOSS_REF, TOL_UPD_LOSS)),
                    ("actor_grad_norm", 10 * TOL_UPD if wide else 3e-4), ("value_grad_norm", 10 * TOL_UPD if wide else 3e-4),
                    ("actor_entropy", TOL_UPD), ("EMA_005", TOL_UPD), ("EMA_095", TOL_UPD),
