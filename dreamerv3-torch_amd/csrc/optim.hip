@@ -97,6 +97,24 @@ __device__ __forceinline__ uint32_t fkey(float x) {
 __device__ __forceinline__ float fkey_inv(uint32_t k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
+// One LDS atomic per DISTINCT bucket among a wave's lanes instead of one per lane: the lanes that share the leader's
+// bucket are counted with a ballot and the leader adds the count.  Returns concentrate in a narrow range, so in the first
+// passes nearly every lane hits the same bucket (64 serialised LDS atomics per wave and batch: 106 us at 14 k values).
+__device__ __forceinline__ void wave_hist_add(unsigned int* h, uint32_t b, bool valid) {
+  unsigned long long active = __ballot(valid);
+  const int lane = threadIdx.x & 63;
+  while (active) {  // wave-uniform
+    const int leader = __ffsll((long long)active) - 1;
+    const uint32_t lb = (uint32_t)__shfl((int)b, leader, 64);
+    const unsigned long long m = __ballot(valid && b == lb);
+    if (lane == leader) atomicAdd(&h[lb], (unsigned int)__popcll(m));
+    active &= ~m;
+  }
+}
+// torch.lerp (ATen/native/Lerp.h), the interpolation torch.quantile applies between the two neighbouring order statistics
+__device__ __forceinline__ float torch_lerp(float a, float b, float w) {
+  return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.f - w);
+}
 __global__ __launch_bounds__(1024) void quantile2_ema_kernel(const float* __restrict__ x, long n, double q0, double q1,
                                                              float* __restrict__ ema, float alpha,
                                                              float* __restrict__ out_q) {
@@ -107,13 +125,15 @@ __global__ __launch_bounds__(1024) void quantile2_ema_kernel(const float* __rest
   __shared__ float frac[2];
   const int tid = threadIdx.x, wave = tid >> 6;
   if (tid == 0) {
-    const double p0 = q0 * (double)(n - 1), p1 = q1 * (double)(n - 1);
-    rank[0] = (long)floor(p0); rank[1] = (long)ceil(p0);
-    rank[2] = (long)floor(p1); rank[3] = (long)ceil(p1);
-    frac[0] = (float)(p0 - floor(p0)); frac[1] = (float)(p1 - floor(p1));
+    // ranks in float32 as torch.quantile computes them (q is a float32 tensor, models.py:16: ranks = q * (n - 1))
+    const float p0 = (float)q0 * (float)(n - 1), p1 = (float)q1 * (float)(n - 1);
+    rank[0] = (long)floorf(p0); rank[1] = (long)ceilf(p0);
+    rank[2] = (long)floorf(p1); rank[3] = (long)ceilf(p1);
+    frac[0] = p0 - floorf(p0); frac[1] = p1 - floorf(p1);
     for (int t = 0; t < 4; ++t) prefix[t] = 0u;
   }
   uint32_t mask = 0u;
+  int has_nan = 0;
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
     for (int i = tid; i < 4 * 256; i += 1024) (&hist[0][0])[i] = 0u;
@@ -125,9 +145,13 @@ __global__ __launch_bounds__(1024) void quantile2_ema_kernel(const float* __rest
     // order statistics still share their prefix one count serves all of them, taken in wave-private histograms.
     const bool same = (p0 == p1) && (p1 == p2) && (p2 == p3);  // uniform
     if (same) {
-      for (long i = tid; i < n; i += 1024) {
-        const uint32_t k = fkey(x[i]);
-        if ((k & mask) == p0) atomicAdd(&whist[wave][(k >> shift) & 255u], 1u);
+      for (long i0 = 0; i0 < n; i0 += 1024) {  // uniform trip count: the ballots inside need every lane
+        const long i = i0 + tid;
+        const bool in = i < n;
+        const float v = in ? x[i] : 0.f;
+        if (pass == 0) has_nan |= (v != v);
+        const uint32_t k = fkey(v);
+        wave_hist_add(whist[wave], (k >> shift) & 255u, in && (k & mask) == p0);
       }
       __syncthreads();
       if (tid < 256) {
@@ -137,13 +161,15 @@ __global__ __launch_bounds__(1024) void quantile2_ema_kernel(const float* __rest
         hist[0][tid] = hist[1][tid] = hist[2][tid] = hist[3][tid] = c;
       }
     } else {
-      for (long i = tid; i < n; i += 1024) {
-        const uint32_t k = fkey(x[i]);
+      for (long i0 = 0; i0 < n; i0 += 1024) {
+        const long i = i0 + tid;
+        const bool in = i < n;
+        const uint32_t k = fkey(in ? x[i] : 0.f);
         const uint32_t km = k & mask, b = (k >> shift) & 255u;
-        if (km == p0) atomicAdd(&hist[0][b], 1u);
-        if (km == p1) atomicAdd(&hist[1][b], 1u);
-        if (km == p2) atomicAdd(&hist[2][b], 1u);
-        if (km == p3) atomicAdd(&hist[3][b], 1u);
+        wave_hist_add(hist[0], b, in && km == p0);
+        wave_hist_add(hist[1], b, in && km == p1);
+        wave_hist_add(hist[2], b, in && km == p2);
+        wave_hist_add(hist[3], b, in && km == p3);
       }
     }
     __syncthreads();
@@ -175,9 +201,13 @@ __global__ __launch_bounds__(1024) void quantile2_ema_kernel(const float* __rest
     mask |= 0xFFu << shift;
     __syncthreads();
   }
+  // a NaN anywhere makes both quantiles NaN, as torch.quantile does (the EMA then turns NaN too instead of training
+  // on silently wrong statistics)
+  const int any_nan = __syncthreads_or(has_nan);
   if (tid == 0) {
     const float a0 = fkey_inv(prefix[0]), a1 = fkey_inv(prefix[1]), b0 = fkey_inv(prefix[2]), b1 = fkey_inv(prefix[3]);
-    const float v0 = a0 + (a1 - a0) * frac[0], v1 = b0 + (b1 - b0) * frac[1];
+    float v0 = torch_lerp(a0, a1, frac[0]), v1 = torch_lerp(b0, b1, frac[1]);
+    if (any_nan) v0 = v1 = NAN;
     if (out_q) { out_q[0] = v0; out_q[1] = v1; }
     if (ema) {
       ema[0] = alpha * v0 + (1.f - alpha) * ema[0];
@@ -251,9 +281,26 @@ extern "C" int dv3_quantile2_ema(const float* x, long n, double q0, double q1, f
 // tools.tensorstats (tools.py:949-958): out[0..3] = mean, std (unbiased, torch.std), min, max of (x[i] - shift) * scale
 // in one launch (the reference's four reductions per logged tensor).  shift / scale (optional device scalars) fold
 // the normed_target expression (models.py:412-414) into the read.
+struct StatsJobs {
+  const float* x[6];
+  long n[6];
+  const float* shift[6];
+  const float* scale[6];
+};
+__device__ void tensorstats_body(const float* __restrict__ x, long n, const float* __restrict__ shift,
+                                 const float* __restrict__ inv_scale, float* __restrict__ out);
 __global__ __launch_bounds__(1024) void tensorstats_kernel(const float* __restrict__ x, long n,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ inv_scale, float* __restrict__ out) {
+  tensorstats_body(x, n, shift, inv_scale, out);
+}
+// one workgroup per logged tensor: the five statistics groups of a behaviour update (models.py:431-445) in ONE launch
+__global__ __launch_bounds__(1024) void tensorstats_multi_kernel(StatsJobs j, float* __restrict__ out) {
+  const int b = blockIdx.x;
+  tensorstats_body(j.x[b], j.n[b], j.shift[b], j.scale[b], out + 4 * b);
+}
+__device__ void tensorstats_body(const float* __restrict__ x, long n, const float* __restrict__ shift,
+                                 const float* __restrict__ inv_scale, float* __restrict__ out) {
   // one pass: sum and sum of squares in double (n <= ~1e6 logged values of O(1..100): the cancellation in
   // sum(x^2) - n mean^2 stays far below float resolution), min / max in float
   __shared__ double red[2][16];
@@ -312,6 +359,27 @@ extern "C" int dv3_tensorstats(const float* x, long n, const float* shift, const
                                void* stream) {
   if (n <= 0 || !x || !out4) return DV3_ERR_ARG;
   hipLaunchKernelGGL(tensorstats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, shift, scale, out4);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_tensorstats_multi(int count, const float* x0, long n0, const float* shift0, const float* scale0,
+                                     const float* x1, long n1, const float* shift1, const float* scale1,
+                                     const float* x2, long n2, const float* shift2, const float* scale2,
+                                     const float* x3, long n3, const float* shift3, const float* scale3,
+                                     const float* x4, long n4, const float* shift4, const float* scale4,
+                                     const float* x5, long n5, const float* shift5, const float* scale5, float* out,
+                                     void* stream) {
+  if (count < 1 || count > 6 || !out) return DV3_ERR_ARG;
+  StatsJobs j;
+  const float* xs[6] = {x0, x1, x2, x3, x4, x5};
+  const long ns[6] = {n0, n1, n2, n3, n4, n5};
+  const float* sh[6] = {shift0, shift1, shift2, shift3, shift4, shift5};
+  const float* sc[6] = {scale0, scale1, scale2, scale3, scale4, scale5};
+  for (int i = 0; i < 6; ++i) {
+    if (i < count && (!xs[i] || ns[i] <= 0)) return DV3_ERR_ARG;
+    j.x[i] = xs[i]; j.n[i] = ns[i]; j.shift[i] = sh[i]; j.scale[i] = sc[i];
+  }
+  hipLaunchKernelGGL(tensorstats_multi_kernel, dim3(count), dim3(1024), 0, (hipStream_t)stream, j, out);
   return (int)hipGetLastError();
 }
 

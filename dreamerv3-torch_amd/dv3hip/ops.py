@@ -285,6 +285,27 @@ def tensorstats(x, out4, *, shift=None, scale=None):
     return out4
 
 
+def tensorstats_multi(jobs, out):
+    """jobs: up to 6 tuples (x, shift, scale); out [len(jobs), 4] = mean / std / min / max of each, one launch."""
+    if not 1 <= len(jobs) <= 6:
+        raise ValueError("tensorstats_multi takes 1..6 tensors")
+    _contig(out, "out")
+    if out.numel() != 4 * len(jobs):
+        raise ValueError("tensorstats_multi output must have 4 elements per tensor")
+    args = []
+    for x, shift, scale in jobs:
+        _contig(x, "x")
+        if x.numel() == 0:
+            raise ValueError("tensorstats_multi: empty tensor")
+        for t, nm in ((shift, "shift"), (scale, "scale")):
+            if t is not None:
+                _contig(t, nm)
+        args += [_ptr(x), x.numel(), _ptr(shift), _ptr(scale)]
+    args += [None, 0, None, None] * (6 - len(jobs))
+    _call("dv3_tensorstats_multi", len(jobs), *args, _ptr(out), _stream())
+    return out
+
+
 def concat_flat(parts, dst):
     """dst[flat] = concatenation of up to 6 contiguous float tensors, one launch (the acting step packs its outputs
     for a single device-to-host hop; dv3hip.graph.PolicyRunner)."""

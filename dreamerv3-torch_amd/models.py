@@ -790,19 +790,16 @@ class ImagBehavior(nn.Module):
         # ---- metrics + optimizers
         ops.dot_accumulate(ent.view(HN), acc[2:3], scale=1.0 / HN)
         metrics = {}
-        metrics.update(tools.tensorstats(value[:-1], "value"))  # the critic on feat[:-1] (models.py:419, 431)
-        metrics.update(tools.tensorstats(target, "target"))
-        metrics.update(tools.tensorstats(reward, "imag_reward"))
-        if normal:
-            metrics.update(tools.tensorstats(action, "imag_action"))
-        else:
-            metrics.update(tools.tensorstats(torch.argmax(action, dim=-1).float(), "imag_action"))
+        # the five statistics groups of models.py:431-445 in one launch (value: the critic on feat[:-1], models.py:419)
+        groups = [(value[:-1], "value", None, None), (target, "target", None, None), (reward, "imag_reward", None, None),
+                  (action if normal else torch.argmax(action, dim=-1).float(), "imag_action", None, None)]
         if cfg.imag_gradient == "both":
             metrics["imag_gradient_mix"] = cfg.imag_gradient_mix
         if cfg.reward_EMA:
             scale = torch.clip(ema[1:2] - ema[0:1], min=1.0)
-            metrics.update(tools.tensorstats(target, "normed_target", shift=ema[0:1], scale=scale))
+            groups.append((target, "normed_target", ema[0:1], scale))
             metrics["EMA_005"], metrics["EMA_095"] = ema[0], ema[1]
+        metrics.update(tools.tensorstats_many(groups))
         metrics["actor_entropy"] = acc[2]
         self._last = dict(reward=reward, value=value, target=target, weights=weights, disc=disc, slow=slow)
         imag_state = {"stoch": stoch.view(H, N, S, D), "deter": deter, "logit": im["logit"].view(H, N, S, D)}

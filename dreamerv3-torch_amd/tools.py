@@ -670,6 +670,18 @@ def tensorstats(tensor, prefix=None, *, shift=None, scale=None):
     return {f"{prefix}_{k}": v for k, v in metrics.items()} if prefix else metrics
 
 
+def tensorstats_many(groups):
+    """tools.tensorstats for several tensors in ONE launch: groups = [(tensor, prefix, shift, scale), ...] (at most 6,
+    device float32) -> the merged metric dict."""
+    out = torch.empty(len(groups), 4, device=groups[0][0].device)
+    ops.tensorstats_multi([(t.detach().contiguous(), sh, sc) for t, _, sh, sc in groups], out)
+    metrics = {}
+    for i, (_, prefix, _, _) in enumerate(groups):
+        for j, k in enumerate(("mean", "std", "min", "max")):
+            metrics[f"{prefix}_{k}"] = out[i, j]
+    return metrics
+
+
 def args_type(default):  # tools.py:786-803
     def parse_string(x):
         if default is None:

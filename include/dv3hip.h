@@ -324,6 +324,15 @@ int dv3_quantile2_ema(const float* x, long n, double q0, double q1, float* ema, 
  * scale[0] over x[n]; shift / scale are optional DEVICE scalars (NULL: 0 / 1) -- the normed_target statistics of
  * models.py:412-414 read (target - ema[0]) / (ema[1] - ema[0] clipped) without materialising it. */
 int dv3_tensorstats(const float* x, long n, const float* shift, const float* scale, float* out4, void* stream);
+/* The same for up to six tensors in ONE launch (one workgroup each): out[4 * i ..] = statistics of tensor i.  The five
+ * tensorstats groups ImagBehavior._train logs per update (value, target, imag_reward, imag_action, normed_target:
+ * models.py:431-445, 659-661) were five launches of 20 us. */
+int dv3_tensorstats_multi(int count, const float* x0, long n0, const float* shift0, const float* scale0,
+                          const float* x1, long n1, const float* shift1, const float* scale1,
+                          const float* x2, long n2, const float* shift2, const float* scale2,
+                          const float* x3, long n3, const float* shift3, const float* scale3,
+                          const float* x4, long n4, const float* shift4, const float* scale4,
+                          const float* x5, long n5, const float* shift5, const float* scale5, float* out, void* stream);
 
 /* dv3_onehot_sample_fwd_ex (D = 32, with the next observe step's reset blend: next_first [M], init [S][32], init_idx [S]
  * -> next_out [M][S][32], next_idx [M][S]) followed by dv3_onehot_linear_ln_fwd on the blended indices, in ONE launch:

@@ -13,8 +13,8 @@ import os
 
 REF = "/root/reference"
 FILES = ["dreamer.py", "exploration.py", "scm_world_model.py", "causal_VAE.py", "main_with_causal.py"]
-MODULES = ("tools", "models", "networks")
-OBJECTS = {"dynamics": "RSSM", "_wm": "WorldModel", "_world_model": "WorldModel", "world_model": "WorldModel",
+MODULES = ("tools", "models", "networks", "expl")  # dreamer.py:16 `import exploration as expl`
+OBJECTS = {"dynamics": "RSSM", "rssm": "RSSM", "_rssm": "RSSM", "_wm": "WorldModel", "_world_model": "WorldModel", "world_model": "WorldModel",
            "_task_behavior": "ImagBehavior", "_behavior": "ImagBehavior"}
 
 

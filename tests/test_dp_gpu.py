@@ -121,3 +121,28 @@ def test_rccl_backend_runs_the_update_on_one_rank():
     single = torch.cat([p.detach().reshape(-1) for p in wm.parameters()]).cpu()
     diff = (single - r["wm"]).abs()
     assert float((diff > 1e-6).float().mean()) < 2e-3 and float(diff.max()) <= 2.1 * wm._config.model_lr
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (gloo here: two ranks share the
+    one device of the test box; RCCL needs a device per rank) and reports the rank count it ran with; asking for more
+    ranks than devices under the RCCL backend is refused instead of printing a one-GPU line."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3",
+                        "--config", "tiny", "--no-cpu-baseline"], env=dict(env, DV3_DIST_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == "gloo" and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 2 * common.SHAPES["tiny"]["B"] and out["value"] > 0
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1"],
+                           env=dict(env, DV3_DIST_BACKEND="nccl"), capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and not any(ln.startswith("{") for ln in r.stdout.splitlines())

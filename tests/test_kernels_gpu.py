@@ -1111,9 +1111,28 @@ def test_tensorstats_kernel_matches_torch_reductions(ops, n):
     assert_close(out, torch.stack([y.mean(), y.std(), y.min(), y.max()]), tol=2e-6, what="shifted stats")
 
 
-@pytest.mark.parametrize("n", [14336, 7, 1, 2, 1000, 458752])
+def test_tensorstats_multi_matches_single(ops):
+    """Six logged tensors of different sizes (one with shift / scale) in one launch == six single launches."""
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(n, generator=g) * (i + 1) + i for i, n in enumerate((14336, 15360, 7, 1024, 90000, 33))]
+    sh, sc = dev(torch.tensor([0.7])), dev(torch.tensor([2.5]))
+    jobs = [(dev(x), sh if i == 4 else None, sc if i == 4 else None) for i, x in enumerate(xs)]
+    out = torch.empty(6, 4, device="cuda")
+    ops.tensorstats_multi(jobs, out)
+    for i, (x, s_, c_) in enumerate(jobs):
+        one = torch.empty(4, device="cuda")
+        ops.tensorstats(x, one, shift=s_, scale=c_)
+        assert torch.equal(out[i], one), i
+    with pytest.raises(ValueError):
+        ops.tensorstats_multi(jobs + jobs[:1], torch.empty(7, 4, device="cuda"))
+
+
+@pytest.mark.parametrize("n", [14336, 7, 1, 2, 21, 1000, 20001, 28672, 458752])
 def test_quantile_ema_matches_torch_quantile(ops, n):
-    """models.RewardEMA (models.py:11-26): exact radix-selected 5 % / 95 % quantiles + EMA == torch.quantile + axpby."""
+    """models.RewardEMA (models.py:11-26): exact radix-selected 5 % / 95 % quantiles + EMA == torch.quantile + axpby.
+    Ranks and the interpolation are computed in float32 exactly as torch.quantile does (n = 21, 20001: q (n - 1) is an
+    integer in exact arithmetic, the case where a float64 rank would pick another neighbour), so the float32 result
+    is BIT-equal to torch.quantile on the same values."""
     g = torch.Generator().manual_seed(n)
     x = torch.randn(n, generator=g) * 3 + 0.5
     if n > 10:
@@ -1121,9 +1140,23 @@ def test_quantile_ema_matches_torch_quantile(ops, n):
         x[1] = -0.0
         x[2] = 0.0
     ref = torch.quantile(x.double(), torch.tensor([0.05, 0.95], dtype=torch.float64)).float()
+    ref32 = torch.quantile(x, torch.tensor([0.05, 0.95]))
     out = torch.empty(2, device="cuda")
     ops.quantile2_ema(dev(x), 0.05, 0.95, out_q=out)
+    assert torch.equal(out.cpu(), ref32), (out.cpu(), ref32)
     assert_close(out, ref, tol=1e-6, what="quantiles")
+    # concentrated values (what imagined returns look like): every element in one bucket for the first two passes
+    y = 1.0 + 1e-3 * torch.randn(n, generator=g)
+    ops.quantile2_ema(dev(y), 0.05, 0.95, out_q=out)
+    assert torch.equal(out.cpu(), torch.quantile(y, torch.tensor([0.05, 0.95])))
+    # a NaN among the values makes both quantiles (and the EMA) NaN, as torch.quantile does
+    if n > 1:
+        z = x.clone()
+        z[n // 2] = float("nan")
+        ema_nan = torch.tensor([0.3, 2.0], device="cuda")
+        ops.quantile2_ema(dev(z), 0.05, 0.95, out_q=out, ema=ema_nan, alpha=0.01)
+        assert torch.isnan(out).all() and torch.isnan(ema_nan).all()
+        assert torch.isnan(torch.quantile(z, torch.tensor([0.05, 0.95]))).all()
     ema = torch.tensor([0.3, 2.0], device="cuda")
     ops.quantile2_ema(dev(x), 0.05, 0.95, ema=ema, alpha=0.01)
     assert_close(ema, 0.01 * ref + 0.99 * torch.tensor([0.3, 2.0]), tol=1e-6, what="ema")

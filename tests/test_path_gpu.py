@@ -186,3 +186,34 @@ def test_three_consecutive_updates_match_the_oracle(name):
         assert float((d > 3e-6).double().mean()) <= 5e-3, f"{k}: {float((d > 3e-6).double().mean()):.3e} outliers"
         checked += 1
     assert checked >= 20
+
+
+def test_dev_switch_variants():
+    """The A/B switches of the launchers and of the host code (DV3_*; live only in a `build.py --dev` library, see
+    dv3hip/_dev.py) select older / unfused launch sequences that must compute the same update: one child process with
+    every fusion switched off runs the tiny end-to-end parity tests and the cfg 2 full-size output / imagination checks
+    against the oracle and the reference fixture.  The shipped library ignores the same variables (second child)."""
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev_lib = os.path.join(repo, "dreamerv3-torch_amd", "dv3hip", "libdv3hip_dev.so")
+    assert os.path.exists(dev_lib), "run __graft_entry__.build() (builds libdv3hip_dev.so as well)"
+    off = dict(DV3_FUSED_IMAG="0", DV3_GATHER_OBS="0", DV3_FUSE_BLEND="0", DV3_FUSE_SAMPLE="0", DV3_FUSE_SAMPLE_IN="0",
+               DV3_FUSE_CARRY="0", DV3_STACK_DETER="0", DV3_C3_MFMA="0", DV3_CONV_L16="0", DV3_CONVT_L16="0",
+               DV3_SIDE_STREAM="1")
+    probe = ("import sys; sys.path[:0] = [%r, %r]; from dv3hip import _dev, engine; import models; "
+             "print(int(_dev.enabled()), int(engine._GATHER_OBS), int(models._FUSED_IMAG))"
+             % (repo, os.path.join(repo, "dreamerv3-torch_amd")))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DV3")}
+    r = subprocess.run([sys.executable, "-c", probe], env=dict(env, **off), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split()[-3:] == ["0", "1", "1"], (r.stdout, r.stderr[-500:])  # shipped: ignored
+    r = subprocess.run([sys.executable, "-c", probe], env=dict(env, DV3HIP_LIB=dev_lib, **off), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split()[-3:] == ["1", "0", "0"], (r.stdout, r.stderr[-500:])
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                        os.path.join(repo, "tests", "test_path_gpu.py"), os.path.join(repo, "tests", "test_fullsize_gpu.py"),
+                        "-k", "(tiny and not dev_switch) or (cfg2 and (outputs or imagination_and_returns or gradients))"],
+                       env=dict(env, DV3HIP_LIB=dev_lib, **off), capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
