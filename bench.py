@@ -231,7 +231,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--by-shape", action="store_true", help="roofline leg: key GEMM launches by (M,N,K) too")
-    ap.add_argument("--also", default="cfg3", help="second config measured in the same run on one GPU ('' = none)")
+    ap.add_argument("--also", default="cfg3", help="second config measured in the same run on one GPU ('none' = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -401,7 +401,7 @@ def main():
         timers["T_upd_host_staged_ms"] = (time.perf_counter() - t0) / args.steps * 1e3
 
     others = None
-    if rank == 0 and world == 1 and args.also and args.also != name:
+    if rank == 0 and world == 1 and args.also not in ("", "none", name):
         others = {args.also: secondary_config(args.also, device, steps=max(5, args.steps // 2), warmup=3)}
 
     cpu = None

@@ -95,18 +95,27 @@ def test_optimizer_call_with_an_autograd_loss_is_clip_plus_adam():
         opt(torch.zeros((), device="cuda"), net.parameters())
 
 
-def test_objective_argument_is_checked_against_the_reward_head():
+def test_objective_and_policy_arguments():
+    """ImagBehavior._train(start, objective) / _imagine(start, policy, horizon) take what the reference's take
+    (models.py:327-331, 448): the reward-head lambda of dreamer.py:196-199 is recognised and stays on the fused path; any
+    other objective trains through the autograd hook (tests/test_autograd_gpu.py pins the numbers against the reference's
+    Plan2Explore); a foreign policy rolls out through the public methods."""
     name = "tiny"
+    s = common.SHAPES[name]
     cfg, wm, beh = Hh.build_models(name)
     n = {k: torch.from_numpy(v).cuda() for k, v in common.make_noise(name).items()}
     post, _, _ = wm._train(common.make_batch(name), noise=dict(q_prior=n["q_prior"], q_post=n["q_post"]))
     post = {k: v.clone() for k, v in post.items()}
-    reward = lambda f, s, a: wm.heads["reward"](wm.dynamics.get_feat(s)).mode()  # dreamer.py:196-198
+    reward = lambda f, s_, a: wm.heads["reward"](wm.dynamics.get_feat(s_)).mode()  # dreamer.py:196-198
     out = beh._train(post, reward)
-    assert np.isfinite(float(out[-1]["actor_loss"])) and beh._objective_checked
-    cfg, wm2, beh2 = Hh.build_models(name)
-    post2, _, _ = wm2._train(common.make_batch(name), noise=dict(q_prior=n["q_prior"], q_post=n["q_post"]))
-    with pytest.raises(NotImplementedError, match="objective"):
-        beh2._train({k: v.clone() for k, v in post2.items()}, lambda f, s, a: torch.ones_like(f[..., :1]))
-    with pytest.raises(NotImplementedError, match="policy"):
-        beh2._imagine(post2, lambda feat: None, 3)
+    assert np.isfinite(float(out[-1]["actor_loss"])) and list(beh._objective_kinds.values()) == [True]
+    # an objective of the imagined deter and action: trained through its own autograd graph
+    out = beh._train(post, lambda f, s_, a: s_["deter"].pow(2).mean(-1, keepdim=True) + a.sum(-1, keepdim=True))
+    assert np.isfinite(float(out[-1]["actor_loss"])) and np.isfinite(float(out[-1]["actor_grad_norm"]))
+    assert sorted(beh._objective_kinds.values()) == [False, True]
+    with pytest.raises(ValueError, match="one reward per imagined state"):
+        beh._train(post, lambda f, s_, a: torch.ones(3, device=f.device))
+    feats, states, actions = beh._imagine(post, lambda feat: beh.actor(feat), 3)
+    N = s["B"] * s["T"]
+    assert feats.shape[:2] == (3, N) and actions.shape == (3, N, s["A"]) and states["stoch"].shape[:2] == (3, N)
+

@@ -1,10 +1,10 @@
 # rocprofv3 evidence for profiles/: kernel-trace stats, SQ (MFMA busy) counters, FETCH_SIZE and WRITE_SIZE passes
 # (separate passes; counters only with --kernel-trace, never with sys/runtime traces)
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline"
+CMD="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --also none"
 # counter passes run for minutes without output: keep gpurun's silence watchdog fed
 ( while true; do date >> $OUT/heartbeat.log; sleep 45; done ) &
 HB=$!
