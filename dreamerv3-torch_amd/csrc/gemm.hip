@@ -888,7 +888,9 @@ static void launch_l16(const GemmParams& p0, int force, hipStream_t s) {
   int sel = wgs(128, 128) >= 448 ? 4 : wgs(64, 64) >= 512 ? 2 : 3;
   if (force >= 1 && force <= 3) sel = force;
   if (force == 4) sel = 4;  // 128 x 128 (tile 15)
-  const int bm = sel == 3 ? 32 : sel == 4 ? 128 : 64, bn = sel == 1 ? 96 : sel == 4 ? 128 : 64;
+  if (force == 5 || force == 6) sel = force;  // 128 x 64 (tile 16), 64 x 128 (tile 17)
+  const int bm = sel == 3 ? 32 : (sel == 4 || sel == 5) ? 128 : 64;
+  const int bn = sel == 1 ? 96 : (sel == 4 || sel == 6) ? 128 : 64;
   p.tiles_m = (p.M + bm - 1) / bm;
   p.tiles_n = (p.N + bn - 1) / bn;
   pick_xcd_grid(p);
@@ -899,6 +901,8 @@ static void launch_l16(const GemmParams& p0, int force, hipStream_t s) {
     if (sel == 1) hipLaunchKernelGGL((gemm_l16_kernel<64, 96, PFV>), grid, block, 0, s, p);      \
     else if (sel == 2) hipLaunchKernelGGL((gemm_l16_kernel<64, 64, PFV>), grid, block, 0, s, p); \
     else if (sel == 4) hipLaunchKernelGGL((gemm_l16_kernel<128, 128, PFV>), grid, block, 0, s, p); \
+    else if (sel == 5) hipLaunchKernelGGL((gemm_l16_kernel<128, 64, PFV>), grid, block, 0, s, p); \
+    else if (sel == 6) hipLaunchKernelGGL((gemm_l16_kernel<64, 128, PFV>), grid, block, 0, s, p); \
     else hipLaunchKernelGGL((gemm_l16_kernel<32, 64, PFV>), grid, block, 0, s, p);               \
   } while (0)
   if (pf == 2) DV3_L16_LAUNCH(2);
@@ -1251,7 +1255,7 @@ extern "C" int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const f
   }
   // float4 path needs dword alignment only (gfx950 global loads); pointers from torch are >= 4B aligned.
   p.vecA = 1; p.vecB = 1;
-  int t = ((tile >= 0 && tile <= 6) || (tile >= 8 && tile <= 15)) ? tile : pick_tile(M, N, K, accumulate);
+  int t = ((tile >= 0 && tile <= 6) || (tile >= 8 && tile <= 17)) ? tile : pick_tile(M, N, K, accumulate);
   if (t >= 11 && tile < 0 && !l16_ok(p, transA, transB)) t = legacy_tile(M, N);
   if (t == 9 && tile < 0 && (transA || (A2 && (K1 % 16) != 0))) t = ((long)M * N <= 512L * 1024) ? 8 : 6;
   if (A2 && (K1 % 64) != 0 && (t == 5 || t == 6 || t == 8)) t = 1;

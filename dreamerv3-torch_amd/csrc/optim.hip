@@ -118,6 +118,7 @@ __device__ __forceinline__ float torch_lerp(float a, float b, float w) {
 __global__ __launch_bounds__(1024) void quantile2_ema_kernel(const float* __restrict__ x, long n, double q0, double q1,
                                                              float* __restrict__ ema, float alpha,
                                                              float* __restrict__ out_q) {
+  constexpr int kU = 8, kR = 16;
   __shared__ unsigned int hist[4][256];
   __shared__ unsigned int whist[16][256];  // per-wave histogram for the passes in which the four prefixes coincide
   __shared__ uint32_t prefix[4];
@@ -134,6 +135,17 @@ __global__ __launch_bounds__(1024) void quantile2_ema_kernel(const float* __rest
   }
   uint32_t mask = 0u;
   int has_nan = 0;
+  // up to 16 k values (cfg 1 / cfg 2: 14 x 1024 returns) stay in registers for all four passes: ONE batch of loads
+  const bool cached = n <= 1024L * kR;
+  float vc[kR];
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < kR; ++u) {
+      const long i = (long)u * 1024 + tid;
+      vc[u] = i < n ? x[i] : 0.f;
+      has_nan |= (vc[u] != vc[u]);
+    }
+  }
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
     for (int i = tid; i < 4 * 256; i += 1024) (&hist[0][0])[i] = 0u;
@@ -144,32 +156,45 @@ __global__ __launch_bounds__(1024) void quantile2_ema_kernel(const float* __rest
     // shared-histogram atomics per element serialised the whole workgroup on it (79 us at 14k values).  While the four
     // order statistics still share their prefix one count serves all of them, taken in wave-private histograms.
     const bool same = (p0 == p1) && (p1 == p2) && (p2 == p3);  // uniform
-    if (same) {
-      for (long i0 = 0; i0 < n; i0 += 1024) {  // uniform trip count: the ballots inside need every lane
-        const long i = i0 + tid;
-        const bool in = i < n;
-        const float v = in ? x[i] : 0.f;
-        if (pass == 0) has_nan |= (v != v);
-        const uint32_t k = fkey(v);
-        wave_hist_add(whist[wave], (k >> shift) & 255u, in && (k & mask) == p0);
+    auto count = [&](float v, bool in) {
+      const uint32_t k = fkey(v);
+      const uint32_t km = k & mask, bkt = (k >> shift) & 255u;
+      if (same) {
+        wave_hist_add(whist[wave], bkt, in && km == p0);
+      } else {
+        wave_hist_add(hist[0], bkt, in && km == p0);
+        wave_hist_add(hist[1], bkt, in && km == p1);
+        wave_hist_add(hist[2], bkt, in && km == p2);
+        wave_hist_add(hist[3], bkt, in && km == p3);
       }
+    };
+    if (cached) {  // the values sit in registers since before the first pass
+#pragma unroll
+      for (int u = 0; u < kR; ++u) count(vc[u], (long)u * 1024 + tid < n);
+    } else {
+      // kU independent loads in flight per lane and chunk: one load per loop trip exposed a full memory round trip
+      // per 1024 values (14 trips x 4 passes ~ 100 us at 14 k values: that WAS the cost of this kernel)
+      for (long i0 = 0; i0 < n; i0 += 1024 * kU) {  // uniform trip count: the ballots inside need every lane
+        float v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const long i = i0 + (long)u * 1024 + tid;
+          v[u] = i < n ? x[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          if (pass == 0) has_nan |= (v[u] != v[u]);
+          count(v[u], i0 + (long)u * 1024 + tid < n);
+        }
+      }
+    }
+    if (same) {
       __syncthreads();
       if (tid < 256) {
         unsigned int c = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) c += whist[w][tid];
         hist[0][tid] = hist[1][tid] = hist[2][tid] = hist[3][tid] = c;
-      }
-    } else {
-      for (long i0 = 0; i0 < n; i0 += 1024) {
-        const long i = i0 + tid;
-        const bool in = i < n;
-        const uint32_t k = fkey(in ? x[i] : 0.f);
-        const uint32_t km = k & mask, b = (k >> shift) & 255u;
-        wave_hist_add(hist[0], b, in && km == p0);
-        wave_hist_add(hist[1], b, in && km == p1);
-        wave_hist_add(hist[2], b, in && km == p2);
-        wave_hist_add(hist[3], b, in && km == p3);
       }
     }
     __syncthreads();

@@ -88,7 +88,7 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
 
 _TILE_NAMES = {0: "128x128x16", 1: "64x64x32", 2: "32x128x32", 3: "skinny16", 4: "128x128x32", 5: "64x64x64", 6: "32x64x64s2", 7: "narrowN",
                8: "32x32x64s4", 9: "direct32x64", 10: "directTN32x64", 11: "l16", 12: "l16_64x96", 13: "l16_64x64",
-               14: "l16_32x64", 15: "l16_128x128"}
+               14: "l16_32x64", 15: "l16_128x128", 16: "l16_128x64", 17: "l16_64x128"}
 
 
 _TILE_TEMPLATES = {0: "2, 2, 2, 2, 16, 1", 1: "2, 2, 1, 1, 32, 1", 2: "1, 4, 1, 1, 32, 1", 4: "2, 2, 2, 2, 32, 1",
@@ -117,7 +117,9 @@ def kernel_symbol(key: str) -> str:
         if tile >= 11:
             return {12: "void dv3::gemm_l16_kernel<64, 96, 1, 0>(dv3::GemmParams)",
                     13: "void dv3::gemm_l16_kernel<64, 64, 1, 0>(dv3::GemmParams)",
-                    15: "void dv3::gemm_l16_kernel<128, 128, 1, 0>(dv3::GemmParams)"}.get(
+                    15: "void dv3::gemm_l16_kernel<128, 128, 1, 0>(dv3::GemmParams)",
+                    16: "void dv3::gemm_l16_kernel<128, 64, 1, 0>(dv3::GemmParams)",
+                    17: "void dv3::gemm_l16_kernel<64, 128, 1, 0>(dv3::GemmParams)"}.get(
                         tile, "void dv3::gemm_l16_kernel<32, 64, 1, 0>(dv3::GemmParams)")
         return f"void dv3::gemm_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, {ta}, {tb}>(dv3::GemmParams)"
     m = re.match(r"conv_wgrad_kernel<([^,>]+)(,c3)?>", key)

@@ -3,6 +3,8 @@
 hipGraph replays, plus a per-kernel (by shape) HIP-event breakdown of one eager rollout (MI355X only).
 
     python tools/imag_bench.py [cfg2] [--json out.json]
+    python tools/imag_bench.py cfg2 --replays N      # ONLY N hipGraph replays of the rollout after one warm update:
+                                                     # the command tools/pmc_timg.sh puts under rocprofv3 --pmc
 
 Algorithmic FLOPs are the dense-equivalent 2*M*N*K of SURVEY.md 8(d) (the one-hot gather layers are priced as the
 Linear they replace); "mfma_gflop" counts only what the MFMA kernels execute.
@@ -46,7 +48,7 @@ def main():
     from dv3hip import ops
 
     out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
-    args = [a for a in sys.argv[1:] if not a.startswith("--") and a != out_json]
+    args = [a for a in sys.argv[1:] if not a.startswith("--") and a != out_json and not a.isdigit()]
     name = args[0] if args else "cfg2"
     cfg, wm, beh = Hh.build_models(name)
     s = common.SHAPES[name]
@@ -56,6 +58,11 @@ def main():
     post = {k: v.clone() for k, v in post.items()}
     beh._imagine_fwd(post, H)  # warm: code objects loaded, workspaces allocated
     torch.cuda.synchronize()
+    if "--replays" in sys.argv:
+        n = int(sys.argv[sys.argv.index("--replays") + 1])
+        t = replay_ms(lambda: beh._imagine_fwd(post, H), reps=n)
+        print(json.dumps({"config": name, "replays": n, "T_img_ms": t}))
+        return
     ops.PROFILE.by_shape = True
     ops.PROFILE.start()
     beh._imagine_fwd(post, H)
