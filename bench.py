@@ -231,6 +231,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--by-shape", action="store_true", help="roofline leg: key GEMM launches by (M,N,K) too")
+    ap.add_argument("--plain", action="store_true",
+                    help="only the warm-up and timed updates (no roofline / phase-timer / staging / cpu legs): the "
+                         "command tools/run_trace.sh puts under rocprofv3 so that every traced launch belongs to an update")
     ap.add_argument("--also", default="cfg3", help="second config measured in the same run on one GPU ('none' = skip)")
     args = ap.parse_args()
 
@@ -299,6 +302,14 @@ def main():
 
     # ---- roofline leg: per-launch HIP-event timing of one more (eager) update on the launch stream
     roofline = None
+    if args.plain:
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": world * B * T * H * args.steps / elapsed, "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                              "config": {"workload": name}, "plain": True}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if rank != 0:
         runner.step(data, eager=True)  # every rank takes part in the profiled update's all-reduces
         torch.cuda.synchronize()

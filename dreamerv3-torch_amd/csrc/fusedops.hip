@@ -298,41 +298,26 @@ struct AHParams {
 // one per output), and wave w starts its batch at output w % OB so that the 1024 waves do not hit the same cache
 // lines at the same moment (from global memory in output order this took 26-36 us for 1024 rows).
 template <int NV>
-struct AHRowCtx {
+__global__ __launch_bounds__(256) void actor_head_kernel(AHParams p) {
+  __shared__ float hsh[4 * 16 * 65];
+  __shared__ float hres[4 * 128];
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const float inv_n = 1.f / (float)p.U;
   float g[NV], b[NV];
-  unsigned long long seed, offset;
-  int nout, rot;
-};
-template <int NV>
-__device__ __forceinline__ constexpr int ah_ob() { return (NV <= 8) ? 12 : 6; }  // OB * NV weight registers per batch
-
-template <int NV>
-__device__ __forceinline__ void actor_head_setup(const AHParams& p, AHRowCtx<NV>& c, int rot_id) {
-  const int l = threadIdx.x & 63;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const int col = l + 64 * v;
-    c.g[v] = col < p.U ? p.gamma[col] : 0.f;
-    c.b[v] = col < p.U ? p.beta[col] : 0.f;
+    const int c = l + 64 * v;
+    g[v] = c < p.U ? p.gamma[c] : 0.f;
+    b[v] = c < p.U ? p.beta[c] : 0.f;
   }
-  c.seed = c.offset = 0;
+  unsigned long long seed = 0, offset = 0;
   if (!p.noise) {
-    c.seed = p.rng[0];
-    c.offset = p.rng[1] + p.rng_off;
+    seed = p.rng[0];
+    offset = p.rng[1] + p.rng_off;
   }
-  c.nout = p.Ws ? 2 * p.A : p.A;
-  c.rot = rot_id % ah_ob<NV>();
-}
-
-// One row of the actor head by ONE wave (sh: 16 * 65 floats, res: 128 floats of wave-private LDS).  act_lds (optional,
-// >= A floats of LDS): also receives the sampled action (the fused kernel's gather reads it from there).
-template <int NV>
-__device__ __forceinline__ void actor_head_row(const AHParams& p, const AHRowCtx<NV>& c, long r, float* sh, float* res,
-                                               float* act_lds) {
-  constexpr int OB = ah_ob<NV>();
-  const int l = threadIdx.x & 63;
-  const float inv_n = 1.f / (float)p.U;
-  const int nout = c.nout, rot = c.rot;
+  const int nout = p.Ws ? 2 * p.A : p.A;
+  constexpr int OB = (NV <= 8) ? 12 : 6;  // OB * NV weight registers per batch of outputs
+  const int rot = (int)((blockIdx.x * 4 + wave) % OB);
   auto load_w = [&](float (&wv)[OB][NV], int o0) {
     const int no = min(OB, nout - o0);
 #pragma unroll
@@ -343,8 +328,8 @@ __device__ __forceinline__ void actor_head_row(const AHParams& p, const AHRowCtx
         const float* w = (o < p.A) ? p.Wm + (long)o * p.U : p.Ws + (long)(o - p.A) * p.U;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-          const int col = l + 64 * v;
-          wv[jj][v] = col < p.U ? w[col] : 0.f;
+          const int c = l + 64 * v;
+          wv[jj][v] = c < p.U ? w[c] : 0.f;
         }
       } else {
 #pragma unroll
@@ -352,13 +337,13 @@ __device__ __forceinline__ void actor_head_row(const AHParams& p, const AHRowCtx
       }
     }
   };
-  {
+  for (long r = (long)blockIdx.x * 4 + wave; r < p.M; r += (long)gridDim.x * 4) {
     float x[NV];
     float s = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const int col = l + 64 * v;
-      x[v] = col < p.U ? p.pre[r * p.ldpre + col] : 0.f;
+      const int c = l + 64 * v;
+      x[v] = c < p.U ? p.pre[r * p.ldpre + c] : 0.f;
       s += x[v];
     }
     const float mean = group_sum<64>(s) * inv_n;
@@ -371,9 +356,9 @@ __device__ __forceinline__ void actor_head_row(const AHParams& p, const AHRowCtx
     const float rstd = rsqrtf(group_sum<64>(q) * inv_n + kLnEps);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const int col = l + 64 * v;
-      x[v] = col < p.U ? siluf_((x[v] - mean) * rstd * c.g[v] + c.b[v]) : 0.f;
-      if (col < p.U) p.y[r * p.ldy + col] = x[v];
+      const int c = l + 64 * v;
+      x[v] = c < p.U ? siluf_((x[v] - mean) * rstd * g[v] + b[v]) : 0.f;
+      if (c < p.U) p.y[r * p.ldy + c] = x[v];
     }
     if (l == 0) {
       if (p.mean) p.mean[r] = mean;
@@ -384,6 +369,8 @@ __device__ __forceinline__ void actor_head_row(const AHParams& p, const AHRowCtx
     // through in chunks of 16; `res` collects them so that lane a ends up with mean[a] and std[a].
     float mr = 0.f, sr = 0.f;
     {
+      float* sh = hsh + wave * (16 * 65);
+      float* res = hres + wave * 128;
       for (int o0 = 0; o0 < nout; o0 += OB) {
         const int no = min(OB, nout - o0);
         // (hoisting the first batch above the row's own loads and LayerNorm was measured: 96 live registers across
@@ -428,8 +415,8 @@ __device__ __forceinline__ void actor_head_row(const AHParams& p, const AHRowCtx
           eps = p.noise[e];
         } else {  // the element fill_normal_kernel would have produced: Box-Muller over Philox counter e >> 2
           uint32_t o[4];
-          Philox ph(c.seed);
-          ph(c.offset + ((unsigned long long)e >> 2), 0x6e6f726dULL, o);
+          Philox ph(seed);
+          ph(offset + ((unsigned long long)e >> 2), 0x6e6f726dULL, o);
           const int j = (int)(e & 3);
           const float rad = sqrtf(-2.f * logf(u01(o[j & 2])));
           const float ang = 6.283185307179586f * u01(o[(j & 2) + 1]);
@@ -439,9 +426,7 @@ __device__ __forceinline__ void actor_head_row(const AHParams& p, const AHRowCtx
         const float mu = tanhf(mr);
         const float sd = (p.max_std - p.min_std) * sigmoidf_(sr + 2.f) + p.min_std;
         const float pre = mu + sd * eps;
-        const float a = pre * (1.f / fmaxf(fabsf(pre), 1.f));
-        p.action[e] = a;
-        if (act_lds) act_lds[l] = a;
+        p.action[e] = pre * (1.f / fmaxf(fabsf(pre), 1.f));
         en = 0.5f + 0.9189385332046727f + logf(sd);
       }
       en = group_sum<64>(en);
@@ -458,8 +443,8 @@ __device__ __forceinline__ void actor_head_row(const AHParams& p, const AHRowCtx
           qv = p.noise[e];
         } else {
           uint32_t o[4];
-          Philox ph4(c.seed);
-          ph4(c.offset + ((unsigned long long)e >> 2), 0x5eedULL, o);
+          Philox ph4(seed);
+          ph4(offset + ((unsigned long long)e >> 2), 0x5eedULL, o);
           qv = fmaxf(-logf(u01(o[e & 3])), 1e-30f);
         }
       }
@@ -479,118 +464,10 @@ __device__ __forceinline__ void actor_head_row(const AHParams& p, const AHRowCtx
         if (l == 0 && p.flips && f != bi) atomicAdd(p.flips, 1u);
         bi = f;
       }
-      if (valid) {
-        const float a = (l == bi) ? 1.f : 0.f;
-        p.action[e] = a;
-        if (act_lds) act_lds[l] = a;
-      }
+      if (valid) p.action[e] = (l == bi) ? 1.f : 0.f;
       if (l == 0 && p.act_idx) p.act_idx[r] = bi;
       const float en = group_sum<64>(valid ? -ph * logf(ph) : 0.f);
       if (l == 0 && p.ent) p.ent[r] = en;
-    }
-  }
-}
-
-template <int NV>
-__global__ __launch_bounds__(256) void actor_head_kernel(AHParams p) {
-  __shared__ float hsh[4 * 16 * 65];
-  __shared__ float hres[4 * 128];
-  const int wave = threadIdx.x >> 6;
-  AHRowCtx<NV> c;
-  actor_head_setup<NV>(p, c, (int)(blockIdx.x * 4 + wave));
-  for (long r = (long)blockIdx.x * 4 + wave; r < p.M; r += (long)gridDim.x * 4)
-    actor_head_row<NV>(p, c, r, hsh + wave * (16 * 65), hres + wave * 128, nullptr);
-}
-
-// The actor head of a row AND the img_in layer of the imagination step that consumes its action (networks.py:216-218:
-// Linear(cat[stoch, action]) -> LayerNorm -> SiLU, the stoch part gathered by class index as in
-// onehot_linear_ln_vec_kernel) in ONE launch, a workgroup per row: wave 0 runs the head (the same code as
-// actor_head_kernel: identical actions), the action goes through LDS, then the four waves gather.  One launch per
-// imagination step less (14 of 134 per rollout at H = 15).
-template <int NV, int NV4>
-__global__ __launch_bounds__(256) void actor_head_imgin_kernel(AHParams p, OLParams o) {
-  __shared__ float hsh[16 * 65];
-  __shared__ float hres[128];
-  __shared__ float sact[64];
-  __shared__ __attribute__((aligned(16))) float part[4][256 * NV4];
-  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
-  AHRowCtx<NV> c;
-  if (wave == 0) actor_head_setup<NV>(p, c, (int)blockIdx.x);
-  const float inv_n = 1.f / (float)o.N;
-  constexpr int MAXB = 8;
-  for (long r = blockIdx.x; r < p.M; r += gridDim.x) {
-    __syncthreads();  // the previous row's gather is done with sact
-    if (wave == 0) actor_head_row<NV>(p, c, r, hsh, hres, sact);
-    // the gathered weight rows do not depend on the action: issue them before waiting for wave 0
-    const int my = (l < o.S) ? o.idx[r * o.S + l] : 0;
-    f32x4 acc[NV4];
-#pragma unroll
-    for (int v = 0; v < NV4; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int s0 = wave; s0 < o.S; s0 += 4 * MAXB) {
-      f32x4 t[MAXB][NV4];
-#pragma unroll
-      for (int u = 0; u < MAXB; ++u) {
-        const int sg = s0 + 4 * u;
-        if (sg < o.S) {  // wave-uniform
-          const int id = __builtin_amdgcn_readlane(my, sg);
-          const float* w = o.WT + (long)(sg * o.D + id) * o.ldw + 4 * l;
-#pragma unroll
-          for (int v = 0; v < NV4; ++v) t[u][v] = *reinterpret_cast<const f32x4u*>(w + 256 * v);
-        } else {
-#pragma unroll
-          for (int v = 0; v < NV4; ++v) t[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < MAXB; ++u)
-#pragma unroll
-        for (int v = 0; v < NV4; ++v) acc[v] += t[u][v];
-    }
-    __syncthreads();  // sact holds the action; the previous row's readers are done with `part`
-    for (int a = wave; a < o.A2; a += 4) {
-      const float xa = sact[a];
-      const float* w = o.WT + (long)(o.S * o.D + a) * o.ldw + 4 * l;
-#pragma unroll
-      for (int v = 0; v < NV4; ++v) acc[v] += xa * *reinterpret_cast<const f32x4u*>(w + 256 * v);
-    }
-#pragma unroll
-    for (int v = 0; v < NV4; ++v) *reinterpret_cast<f32x4*>(&part[wave][4 * (l + 64 * v)]) = acc[v];
-    __syncthreads();
-#pragma unroll
-    for (int v = 0; v < NV4; ++v) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&part[0][4 * (l + 64 * v)]);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&part[1][4 * (l + 64 * v)]);
-      const f32x4 a2 = *reinterpret_cast<const f32x4*>(&part[2][4 * (l + 64 * v)]);
-      const f32x4 a3 = *reinterpret_cast<const f32x4*>(&part[3][4 * (l + 64 * v)]);
-      acc[v] = (a0 + a1) + (a2 + a3);
-      if ((v & 3) == wave) *reinterpret_cast<f32x4u*>(o.pre + r * o.ldpre + 4 * (l + 64 * v)) = acc[v];
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int v = 0; v < NV4; ++v) s += (acc[v][0] + acc[v][1]) + (acc[v][2] + acc[v][3]);
-    const float mean = group_sum<64>(s) * inv_n;
-    float q = 0.f;
-#pragma unroll
-    for (int v = 0; v < NV4; ++v)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float d = acc[v][e] - mean;
-        q += d * d;
-      }
-    const float rstd = rsqrtf(group_sum<64>(q) * inv_n + kLnEps);
-#pragma unroll
-    for (int v = 0; v < NV4; ++v) {
-      if ((v & 3) != wave) continue;  // wave-uniform
-      const f32x4 g = *reinterpret_cast<const f32x4u*>(o.gamma + 4 * (l + 64 * v));
-      const f32x4 b = *reinterpret_cast<const f32x4u*>(o.beta + 4 * (l + 64 * v));
-      f32x4 z;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) z[e] = siluf_((acc[v][e] - mean) * rstd * g[e] + b[e]);
-      *reinterpret_cast<f32x4u*>(o.y + r * o.ldy + 4 * (l + 64 * v)) = z;
-    }
-    if (threadIdx.x == 0) {
-      if (o.mean) o.mean[r] = mean;
-      if (o.rstd) o.rstd[r] = rstd;
     }
   }
 }
@@ -731,46 +608,6 @@ extern "C" int dv3_actor_head_fwd(const float* pre, long ldpre, const float* gam
   else if (U <= 256) hipLaunchKernelGGL((actor_head_kernel<4>), grid, block, 0, s, p);
   else if (U <= 512) hipLaunchKernelGGL((actor_head_kernel<8>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((actor_head_kernel<16>), grid, block, 0, s, p);
-  return (int)hipGetLastError();
-}
-
-extern "C" int dv3_actor_head_imgin_fwd(const float* pre, long ldpre, const float* gamma, const float* beta, float* y,
-                                        long ldy, float* mean, float* rstd, const float* Wm, const float* bm,
-                                        const float* Ws, const float* bs, float* out_m, float* out_s,
-                                        const float* noise, const unsigned long long* rng_state,
-                                        unsigned long long rng_offset, float* eps_out, float* action, float* entropy,
-                                        int* act_idx, const int* forced, unsigned int* flips, long M, int U, int A,
-                                        float min_std, float max_std, float unimix, int onehot, const int* idx, int S,
-                                        int D, const float* WT, long ldw, float* x1pre, long ldx1pre,
-                                        const float* gamma1, const float* beta1, float* x1, long ldx1, float* mean1,
-                                        float* rstd1, int N, void* stream) {
-  if (M <= 0) return 0;
-  if (!pre || !gamma || !beta || !y || !Wm || !bm || !out_m || !action || U <= 0 || U > 1024 || A <= 0 || A > 64 ||
-      ldpre < U || ldy < U)
-    return DV3_ERR_ARG;
-  if (!onehot && (!Ws || !bs || !out_s)) return DV3_ERR_ARG;
-  if (onehot && Ws) return DV3_ERR_ARG;
-  if (!noise && !rng_state) return DV3_ERR_ARG;
-  if (!idx || !WT || !x1pre || !gamma1 || !beta1 || !x1 || S <= 0 || S > 32 || D <= 0 || N <= 0 || (N % 256) != 0 ||
-      N > 1024 || ldw < N || ldx1pre < N || ldx1 < N || (ldw % 4) || (ldx1pre % 4) || (ldx1 % 4))
-    return DV3_ERR_ARG;
-  AHParams p{pre, ldpre, gamma, beta, y, ldy, mean, rstd, Wm, bm, Ws, bs, out_m, out_s, noise, rng_state, rng_offset,
-             eps_out, action, entropy, act_idx, forced, flips, M, U, A, min_std, max_std, unimix, onehot};
-  OLParams o{idx, S, D, nullptr, 0, A, WT, ldw, nullptr, 0, x1pre, ldx1pre, gamma1, beta1, x1, ldx1, mean1, rstd1, M, N, 1};
-  hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(cap_grid(M, 1, 32768)), block(256);
-#define DV3_AHI(NVV)                                                                                  \
-  switch (N / 256) {                                                                                  \
-    case 1: hipLaunchKernelGGL((actor_head_imgin_kernel<NVV, 1>), grid, block, 0, s, p, o); break;     \
-    case 2: hipLaunchKernelGGL((actor_head_imgin_kernel<NVV, 2>), grid, block, 0, s, p, o); break;     \
-    case 3: hipLaunchKernelGGL((actor_head_imgin_kernel<NVV, 3>), grid, block, 0, s, p, o); break;     \
-    default: hipLaunchKernelGGL((actor_head_imgin_kernel<NVV, 4>), grid, block, 0, s, p, o); break;    \
-  }
-  if (U <= 64) { DV3_AHI(1) }
-  else if (U <= 256) { DV3_AHI(4) }
-  else if (U <= 512) { DV3_AHI(8) }
-  else { DV3_AHI(16) }
-#undef DV3_AHI
   return (int)hipGetLastError();
 }
 

@@ -38,7 +38,6 @@ _FUSE_SAMPLE = _dev.flag("DV3_FUSE_SAMPLE", True)  # sampling in the epilogue of
 _GATHER_OBS = _dev.flag("DV3_GATHER_OBS", True)  # one-hot gather for img_in / head first layers in observe
 _FUSE_SAMPLE_IN = _dev.flag("DV3_FUSE_SAMPLE_IN", True)  # observe scan: sample(t) + img_in(t+1) in one launch
 _FUSE_CARRY = _dev.flag("DV3_FUSE_CARRY", True)  # reverse scan: carry + next straight-through in one launch
-_FUSE_HEAD_IN = _dev.flag("DV3_FUSE_HEAD_IN", True)  # imagination: actor head + the step's img_in layer in one launch
 
 
 class SideStream:
@@ -251,8 +250,7 @@ class MLPEngine:
                            None if onehot else out2[rs], head["action"], head["ent"], noise=head.get("noise"),
                            rng=head.get("rng"), eps_out=head.get("eps_out"), act_idx=head.get("act_idx"),
                            forced=head.get("forced"), flips=head.get("flips"), min_std=head.get("min_std", 0.1),
-                           max_std=head.get("max_std", 1.0), unimix=head.get("unimix", 0.01), onehot=onehot,
-                           imgin=head.get("imgin"))
+                           max_std=head.get("max_std", 1.0), unimix=head.get("unimix", 0.01), onehot=onehot)
             return h1, out[rs], None if onehot else out2[rs]
         o = o2 = None
         if out is not None:
@@ -552,19 +550,8 @@ class RSSMEngine:
         ops.transpose2d(W, wt)
         return wt
 
-    def imgin_fused_ok(self) -> bool:
-        """The img_in layer can ride in the actor-head launch (ops.actor_head(imgin=...))."""
-        return _FUSE_HEAD_IN and ops.actor_head_imgin_ok(self.S, self.Hd)
-
-    def imgin_args(self, idx, bufs):
-        """The `imgin` argument of ops.actor_head for this step's buffers (pack_img_in must have run)."""
-        P = self.P
-        wt = self.ws.get("rssm.img_in_wt", (P.img_in.W.shape[1], P.img_in.W.shape[0]))
-        return dict(idx=idx, D=self.D, WT=wt, pre=bufs["x1pre"], gamma=P.img_in.g, beta=P.img_in.b, y=bufs["x1"],
-                    mean=bufs["m1"], rstd=bufs["r1"])
-
     def img_step_fwd(self, stoch, deter, action, bufs, *, noise=None, rng=None, sample=True, forced=None,
-                     flips=None, idx=None, idx_out=None, wcat=None, head=True, x1_done=False):
+                     flips=None, idx=None, idx_out=None, wcat=None, head=True):
         """stoch [M,SD], deter [M,De], action [M,A]; bufs: dict of per-step buffers (see imagine_fwd).
         idx (int32 [M,S]): the class indices of stoch (an exact one-hot): img_in then runs as gather + LayerNorm +
         SiLU in one launch (pack_img_in must have run) instead of GEMM + LN.  idx_out (int32 [M,S]) receives the
@@ -574,9 +561,7 @@ class RSSMEngine:
         head=False stops after the GRU (deter' only): the acting step never reads the prior (dreamer.py:131-134)."""
         P = self.P
         M = stoch.shape[0]
-        if x1_done:
-            pass  # bufs["x1"] came out of the actor-head launch (imgin_args)
-        elif idx is not None:
+        if idx is not None:
             wt = self.ws.get("rssm.img_in_wt", (P.img_in.W.shape[1], P.img_in.W.shape[0]))
             ops.onehot_linear_ln(idx, self.D, wt, bufs["x1pre"], x2=action, gamma=P.img_in.g, beta=P.img_in.b,
                                  y=bufs["x1"], mean=bufs["m1"], rstd=bufs["r1"])

@@ -1214,10 +1214,8 @@ def onehot_sample_linear_ln(logit, out, *, next_first, init, init_idx, next_out,
 
 def actor_head(pre, gamma, beta, y, mean, rstd, Wm, bm, Ws, bs, out_m, out_s, action, entropy, *, noise=None,
                rng=None, eps_out=None, act_idx=None, forced=None, flips=None, min_std=0.1, max_std=1.0, unimix=0.01,
-               onehot=False, imgin=None):
-    """Last trunk LayerNorm+SiLU, the heads, the action sample and the entropy of the actor in one launch.
-    imgin = dict(idx [M,S] int32, D, WT [S*D+A, N], pre, gamma, beta, y, mean, rstd): the img_in layer of the
-    imagination step that consumes the action (gather + LayerNorm + SiLU, as onehot_linear_ln) in the SAME launch."""
+               onehot=False):
+    """Last trunk LayerNorm+SiLU, the heads, the action sample and the entropy of the actor in one launch."""
     M, U, ldpre = _rows2d(pre, "pre")
     My, Uy, ldy = _rows2d(y, "y")
     A = Wm.shape[0]
@@ -1251,36 +1249,11 @@ def actor_head(pre, gamma, beta, y, mean, rstd, Wm, bm, Ws, bs, out_m, out_s, ac
         if rng is None:
             raise ValueError("actor_head needs noise or an RngStream")
         rng_state, rng_off = rng.state, rng.take(M * A)
-    head_args = (_ptr(pre), ldpre, _ptr(gamma), _ptr(beta), _ptr(y), ldy, _ptr(mean), _ptr(rstd), _ptr(Wm),
-                 _ptr(bm), _ptr(Ws), _ptr(bs), _ptr(out_m), _ptr(out_s), _ptr(noise), _ptr(rng_state), int(rng_off),
-                 _ptr(eps_out), _ptr(action), _ptr(entropy), _ptr(act_idx), _ptr(forced), _ptr(flips), M, U, A,
-                 float(min_std), float(max_std), float(unimix), int(onehot))
-    if imgin is not None:
-        # ... and the img_in layer of the imagination step that consumes the action, same launch (actor_head_imgin_ok)
-        idx, D, WT = imgin["idx"], int(imgin["D"]), imgin["WT"]
-        x1pre, x1 = imgin["pre"], imgin["y"]
-        _contig(idx, "idx", torch.int32)
-        S = idx.shape[1]
-        Kw, N, ldw = _rows2d(WT, "WT")
-        M1, N1, ldx1pre = _rows2d(x1pre, "x1pre")
-        M2, N2, ldx1 = _rows2d(x1, "x1")
-        g1, b1, m1, r1 = imgin["gamma"], imgin["beta"], imgin["mean"], imgin["rstd"]
-        for t, nm in ((g1, "gamma1"), (b1, "beta1"), (m1, "mean1"), (r1, "rstd1")):
-            _contig(t, nm)
-        if (idx.shape[0] != M or Kw != S * D + A or (M1, N1) != (M, N) or (M2, N2) != (M, N) or g1.numel() != N
-                or b1.numel() != N or m1.numel() != M or r1.numel() != M or not actor_head_imgin_ok(S, N)
-                or ldw % 4 or ldx1pre % 4 or ldx1 % 4):
-            raise ValueError("actor_head imgin shapes mismatch")
-        _call("dv3_actor_head_imgin_fwd", *head_args, _ptr(idx), S, D, _ptr(WT), ldw, _ptr(x1pre), ldx1pre, _ptr(g1),
-              _ptr(b1), _ptr(x1), ldx1, _ptr(m1), _ptr(r1), N, _stream(),
-              flops=2.0 * M * U * A * (1 if onehot else 2) + 2.0 * M * N * (S * D + A))
-        return
-    _call("dv3_actor_head_fwd", *head_args, _stream(), flops=2.0 * M * U * A * (1 if onehot else 2))
-
-
-def actor_head_imgin_ok(S, N) -> bool:
-    """Preconditions of the fused actor head + img_in launch (csrc/fusedops.hip actor_head_imgin_kernel)."""
-    return S <= 32 and N % 256 == 0 and N <= 1024
+    _call("dv3_actor_head_fwd", _ptr(pre), ldpre, _ptr(gamma), _ptr(beta), _ptr(y), ldy, _ptr(mean), _ptr(rstd), _ptr(Wm),
+          _ptr(bm), _ptr(Ws), _ptr(bs), _ptr(out_m), _ptr(out_s), _ptr(noise), _ptr(rng_state), int(rng_off),
+          _ptr(eps_out), _ptr(action), _ptr(entropy), _ptr(act_idx), _ptr(forced), _ptr(flips), M, U, A,
+          float(min_std), float(max_std), float(unimix), int(onehot), _stream(),
+          flops=2.0 * M * U * A * (1 if onehot else 2))
 
 
 def gemm_sample_ok(M, N, D, A=None) -> bool:

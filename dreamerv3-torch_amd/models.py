@@ -508,12 +508,9 @@ class ImagBehavior(nn.Module):
             n, r0 = rc.stop - rc.start, rc.start
             for t in range(H):
                 nz_act = None if act_noise is None else act_noise[t][rc]
-                fuse_in = _FUSED_IMAG and t < H - 1 and rssm.imgin_fused_ok()
                 if _FUSED_IMAG:
                     head = dict(action=action[t][rc], ent=ent[t][rc], rng=rng, onehot=not normal, flips=flips,
                                 noise=nz_act)
-                    if fuse_in:  # the step's img_in layer rides in the actor-head launch
-                        head["imgin"] = rssm.imgin_args(idx[t][rc], {k: v[t][rc] for k, v in step.items()})
                     if normal:
                         head.update(eps_out=eps[t][rc], min_std=cfg.actor["min_std"], max_std=cfg.actor["max_std"])
                     else:
@@ -541,8 +538,7 @@ class ImagBehavior(nn.Module):
                     rssm.img_step_fwd(stoch[t][rc], deter[t][rc], action[t][rc], b,
                                       noise=None if q_img is None else q_img[t][rc], rng=rng,
                                       forced=None if f_img is None else f_img[t][rc], flips=flips,
-                                      idx=idx[t][rc] if _FUSED_IMAG else None, idx_out=idx[t + 1][rc], wcat=wcat,
-                                      x1_done=fuse_in)
+                                      idx=idx[t][rc] if _FUSED_IMAG else None, idx_out=idx[t + 1][rc], wcat=wcat)
 
         run_chain(slice(0, N))
         rng.commit()

@@ -372,20 +372,6 @@ int dv3_actor_head_fwd(const float* pre, long ldpre, const float* gamma, const f
                        unsigned long long rng_offset, float* eps_out, float* action, float* entropy, int* act_idx,
                        const int* forced, unsigned int* flips, long M, int U, int A, float min_std, float max_std,
                        float unimix, int onehot, void* stream);
-/* dv3_actor_head_fwd for a row FOLLOWED BY the img_in layer of the imagination step that consumes the sampled action
- * (ImagBehavior._imagine's step, models.py:513-517: action = policy(feat).sample(); img_step(state, action) whose first
- * layer is Linear(cat[stoch, action]) -> LayerNorm -> SiLU, networks.py:216-218) in ONE launch, a workgroup per row:
- * x1pre[M,N] = sum_s WT[s*D + idx[m][s]] + sum_a action[m][a] * WT[S*D + a]; x1 = SiLU(LN(x1pre; gamma1, beta1)); mean1 /
- * rstd1 [M] saved.  WT [S*D + A][N] as in dv3_onehot_linear_ln_fwd; N % 256 == 0, N <= 1024, S <= 32.  The actor outputs
- * are bit-identical to dv3_actor_head_fwd (same code path). */
-int dv3_actor_head_imgin_fwd(const float* pre, long ldpre, const float* gamma, const float* beta, float* y, long ldy,
-                             float* mean, float* rstd, const float* Wm, const float* bm, const float* Ws,
-                             const float* bs, float* out_m, float* out_s, const float* noise,
-                             const unsigned long long* rng_state, unsigned long long rng_offset, float* eps_out,
-                             float* action, float* entropy, int* act_idx, const int* forced, unsigned int* flips, long M,
-                             int U, int A, float min_std, float max_std, float unimix, int onehot, const int* idx,
-                             int S, int D, const float* WT, long ldw, float* x1pre, long ldx1pre, const float* gamma1,
-                             const float* beta1, float* x1, long ldx1, float* mean1, float* rstd1, int N, void* stream);
 int dv3_transpose2d(const float* src, long lds, int R, int C, float* dst, long ldd, void* stream);
 int dv3_onehot_to_idx(const float* onehot, int* idx, long R, int D, void* stream);
 

@@ -962,47 +962,6 @@ def test_actor_head_onehot(ops, M, U, A):
     assert abs(int(flips.item()) - int((samp_ref.argmax(-1).int() != forced).sum())) <= int((~same).sum())
 
 
-@pytest.mark.parametrize("M,U,A,S,D,N,onehot", [(1024, 512, 6, 32, 32, 512, False), (2048, 512, 18, 32, 32, 512, True),
-                                                  (37, 512, 6, 32, 32, 1024, False), (5, 1024, 17, 32, 32, 1024, True),
-                                                  (64, 256, 6, 8, 16, 256, False)])
-def test_actor_head_with_img_in_equals_two_launches(ops, M, U, A, S, D, N, onehot):
-    """dv3_actor_head_imgin_fwd == dv3_actor_head_fwd followed by dv3_onehot_linear_ln_fwd on the sampled action
-    (the first layer of RSSM.img_step, networks.py:216-218): bit-equal, with injected noise and with the Philox stream."""
-    g = torch.Generator().manual_seed(M + U + A + N)
-    pre = dev(torch.randn(M, U, generator=g))
-    gamma, beta = dev(1 + 0.1 * torch.randn(U, generator=g)), dev(0.1 * torch.randn(U, generator=g))
-    Wm, bm = dev(torch.randn(A, U, generator=g) / math.sqrt(U) * 3), dev(0.1 * torch.randn(A, generator=g))
-    Ws, bs = (None, None) if onehot else (dev(torch.randn(A, U, generator=g) / math.sqrt(U)), dev(0.1 * torch.randn(A, generator=g)))
-    noise = torch.empty(M, A).exponential_(1.0, generator=g).clamp_min(1e-20) if onehot else torch.randn(M, A, generator=g)
-    idx = dev(torch.randint(0, D, (M, S), generator=g, dtype=torch.int32))
-    WT = dev(torch.randn(S * D + A, N, generator=g) / math.sqrt(S + A))
-    g1, b1 = dev(1 + 0.1 * torch.randn(N, generator=g)), dev(0.1 * torch.randn(N, generator=g))
-    mk = lambda *s: torch.empty(*s, device="cuda")
-
-    def run(fused, rng=None):
-        o = dict(y=mk(M, U), mean=mk(M), rstd=mk(M), om=mk(M, A), os=None if onehot else mk(M, A), act=mk(M, A),
-                 ent=mk(M), x1pre=mk(M, N), x1=mk(M, N), m1=mk(M), r1=mk(M), eps=None if onehot else mk(M, A))
-        imgin = dict(idx=idx, D=D, WT=WT, pre=o["x1pre"], gamma=g1, beta=b1, y=o["x1"], mean=o["m1"], rstd=o["r1"])
-        ops.actor_head(pre, gamma, beta, o["y"], o["mean"], o["rstd"], Wm, bm, Ws, bs, o["om"], o["os"], o["act"], o["ent"],
-                       noise=None if rng is not None else dev(noise), rng=rng, eps_out=o["eps"], onehot=onehot,
-                       imgin=imgin if fused else None)
-        if not fused:
-            ops.onehot_linear_ln(idx, D, WT, o["x1pre"], x2=o["act"], gamma=g1, beta=b1, y=o["x1"], mean=o["m1"],
-                                 rstd=o["r1"])
-        return o
-
-    for rng_seed in (None, 7):
-        a = run(False, None if rng_seed is None else ops.RngStream("cuda", seed=rng_seed))
-        b = run(True, None if rng_seed is None else ops.RngStream("cuda", seed=rng_seed))
-        for k in a:
-            if a[k] is not None:
-                assert torch.equal(a[k], b[k]), (k, rng_seed)
-    # and against the plain math: x1 = SiLU(LN(onehot(idx) @ WT[:S*D] + action @ WT[S*D:]))
-    oh = F.one_hot(idx.cpu().long(), D).float().reshape(M, S * D)
-    ref = F.silu(O.layer_norm(oh @ WT.cpu()[:S * D] + b["act"].cpu() @ WT.cpu()[S * D:], g1.cpu(), b1.cpu()))
-    assert_close(b["x1"], ref, tol=2e-5, what="x1")
-
-
 def test_onehot_sample_teacher_forcing_counts_flips(ops):
     R, D = 4096, 32
     g = torch.Generator().manual_seed(3)
