@@ -38,6 +38,11 @@ _FUSE_SAMPLE = _dev.flag("DV3_FUSE_SAMPLE", True)  # sampling in the epilogue of
 _GATHER_OBS = _dev.flag("DV3_GATHER_OBS", True)  # one-hot gather for img_in / head first layers in observe
 _FUSE_SAMPLE_IN = _dev.flag("DV3_FUSE_SAMPLE_IN", True)  # observe scan: sample(t) + img_in(t+1) in one launch
 _FUSE_CARRY = _dev.flag("DV3_FUSE_CARRY", True)  # reverse scan: carry + next straight-through in one launch
+# observe scan: GRU gates / obs_out LayerNorm in the prologue of the few-row GEMM that consumes them (csrc/scanops.hip)
+_FUSE_SCAN_ROW = _dev.flag("DV3_FUSE_SCAN_ROW", True)
+_FUSE_SCAN_LN = _dev.flag("DV3_FUSE_SCAN_LN", True)  # ... forward: obs_out LayerNorm + posterior-logit GEMM
+_FUSE_SCAN_LNBWD = _dev.flag("DV3_FUSE_SCAN_LNBWD", True)  # ... reverse: the two LayerNorm backward + data-gradient GEMMs
+_FUSE_SCAN_CS = _dev.flag("DV3_FUSE_SCAN_CS", True)  # ... reverse: carry + straight-through + logit data-gradient GEMM
 
 
 class SideStream:
@@ -405,6 +410,7 @@ class RSSMEngine:
         ops.reset_blend(v2(action_tm, A), None, first.view(TB), v2(ain, A))
         fuse = ((De % 256 == 0 and De <= 1024) or (De % 1024 == 0 and De <= 4096)) and _FUSE_BLEND
         fuse_in = fuse and gather and _FUSE_SAMPLE_IN and ops.sample_linear_ln_ok(S, D, Hd) and Hd % 4 == 0
+        fuse_row = _FUSE_SCAN_ROW and _FUSE_SCAN_LN and B <= 64 and ops.scan_ln_gemm_ok(Hd, SD)
         for t in range(T):
             if t == 0 or not fuse:
                 prev_s = post_stoch[t - 1].view(B, SD) if t > 0 else (None if state0 is None else state0[0])
@@ -424,8 +430,12 @@ class RSSMEngine:
             ops.gru_fwd(gpre[t], P.gru.g, P.gru.b, din[t], deter[t], mg[t], rg[t],
                         next_blend=(first[t + 1], d0.view(De), din[t + 1]) if nxt else None)
             ops.gemm(deter[t], P.obs_out.W[:, :De], x3pre[t], accumulate=True)
-            ops.ln_act_fwd(x3pre[t], P.obs_out.g, P.obs_out.b, x3[t], m3[t], r3[t], act=True)
-            ops.gemm(x3[t], P.obs.W, post_logit[t].view(B, SD), bias=P.obs.b)
+            if fuse_row:  # the obs_out LayerNorm rides in the logit GEMM (5 launches per step instead of 6)
+                ops.scan_ln_gemm(x3pre[t], P.obs_out.g, P.obs_out.b, x3[t], m3[t], r3[t], P.obs.W,
+                                 post_logit[t].view(B, SD), bias=P.obs.b)
+            else:
+                ops.ln_act_fwd(x3pre[t], P.obs_out.g, P.obs_out.b, x3[t], m3[t], r3[t], act=True)
+                ops.gemm(x3[t], P.obs.W, post_logit[t].view(B, SD), bias=P.obs.b)
             if fuse_in and nxt:
                 # the posterior sample of this step and the img_in layer of the next one in one launch
                 ops.onehot_sample_linear_ln(post_logit[t], post_stoch[t], noise=None if q_post is None else q_post[t],
@@ -505,21 +515,51 @@ class RSSMEngine:
         dsin = ws.zeros("obs.dsin", (T, B, SD))
         dstoch0, ddeter0 = ws.zeros("obs.dstoch0", (SD,)), ws.zeros("obs.ddeter0", (De,))
         fuse_carry = _FUSE_CARRY
+        # row operations in the prologue of the few-row GEMM that consumes them (csrc/scanops.hip): 5 launches per step
+        fuse_row = (_FUSE_SCAN_ROW and _FUSE_SCAN_LNBWD and B <= 64 and ops.scan_lnbwd_gemm_ok(Hd, De)
+                    and ops.scan_lnbwd_gemm_ok(Hd, SD))
+        fuse_cs = (_FUSE_SCAN_ROW and _FUSE_SCAN_CS and B <= 64 and fuse_carry and ops.scan_carry_st_gemm_ok(S, D, Hd))
+        # (the fused first launch re-reads its inputs from every column tile: the finished logit gradient goes to its
+        # own buffer instead of in place)
+        dpl_out = g("obs.dpl_out", (T, B, S, D)) if fuse_cs else dpost_logit
+        if fuse_row:
+            # what the two LayerNorm + SiLU backward prologues need from the forward pass, for all steps at once
+            xh3, jc3 = g("obs.xh3", (T, B, Hd)), g("obs.jc3", (T, B, Hd))
+            xh1, jc1 = g("obs.xh1", (T, B, Hd)), g("obs.jc1", (T, B, Hd))
+            ops.scan_ln_factors(v2(x3pre, Hd), P.obs_out.g, P.obs_out.b, m3.view(TB), r3.view(TB), xh3, jc3)
+            ops.scan_ln_factors(v2(x1pre, Hd), P.img_in.g, P.img_in.b, m1.view(TB), r1.view(TB), xh1, jc1)
         for t in reversed(range(T)):
             gs_t, gd_t = gs[t], gd[t]  # already hold the carry from step t+1 (folded in by obs_blend_bwd)
             dx1, ddin = dxd[t][:, :Hd], dxd[t][:, Hd:]
-            if t == T - 1 or not fuse_carry:  # (otherwise done by step t+1's fused carry + straight-through launch)
-                ops.onehot_st_bwd(post_logit[t], gs_t.view(B, S, D), dpost_logit[t], unimix=self.unimix,
-                                  accumulate=True)
-            ops.gemm(dpost_logit[t].view(B, SD), P.obs.W, dx3[t], transB=False, accumulate="atomic")
-            dense_ln_bwd_pre(P.obs_out, dx3[t], x3pre[t], m3[t], r3[t], dx3pre[t], wgrad=True)
-            ops.gemm(dx3pre[t], P.obs_out.W[:, :De], gd_t, transB=False, accumulate="atomic")
+            if fuse_cs:
+                # the carry out of step t+1, this step's straight-through gradient and dx3 += dlogit W_obs
+                carry = None if t == T - 1 else (dsin[t + 1], dxd[t + 1][:, Hd:], first[t + 1], gd_t, dstoch0, ddeter0)
+                ops.scan_carry_st_gemm(gs_t.view(B, SD), post_logit[t], dpost_logit[t], dpl_out[t], P.obs.W, dx3[t],
+                                       unimix=self.unimix, carry=carry)
+            else:
+                if t == T - 1 or not fuse_carry:  # (otherwise done by step t+1's fused carry + straight-through launch)
+                    ops.onehot_st_bwd(post_logit[t], gs_t.view(B, S, D), dpost_logit[t], unimix=self.unimix,
+                                      accumulate=True)
+                ops.gemm(dpost_logit[t].view(B, SD), P.obs.W, dx3[t], transB=False, accumulate="atomic")
+            if fuse_row:
+                ops.scan_lnbwd_gemm(dx3[t], xh3[t], jc3[t], P.obs_out.g, r3[t], dx3pre[t], P.obs_out.W[:, :De], gd_t,
+                                    _g(P.obs_out.g), _g(P.obs_out.b))
+            else:
+                dense_ln_bwd_pre(P.obs_out, dx3[t], x3pre[t], m3[t], r3[t], dx3pre[t], wgrad=True)
+                ops.gemm(dx3pre[t], P.obs_out.W[:, :De], gd_t, transB=False, accumulate="atomic")
             ops.gru_bwd(gd_t, gpre[t], P.gru.g, P.gru.b, din[t], mg[t], rg[t], dgpre[t], ddin, _g(P.gru.g),
                         _g(P.gru.b))
             ops.gemm(dgpre[t], P.gru.W, dxd[t], transB=False, accumulate="atomic")
-            dense_ln_bwd_pre(P.img_in, dx1, x1pre[t], m1[t], r1[t], dx1pre[t], wgrad=True)
-            ops.gemm(dx1pre[t], P.img_in.W[:, :SD], dsin[t], transB=False, accumulate="atomic")
-            if fuse_carry and t > 0:
+            if fuse_row:
+                ops.scan_lnbwd_gemm(dx1, xh1[t], jc1[t], P.img_in.g, r1[t], dx1pre[t], P.img_in.W[:, :SD], dsin[t],
+                                    _g(P.img_in.g), _g(P.img_in.b))
+            else:
+                dense_ln_bwd_pre(P.img_in, dx1, x1pre[t], m1[t], r1[t], dx1pre[t], wgrad=True)
+                ops.gemm(dx1pre[t], P.img_in.W[:, :SD], dsin[t], transB=False, accumulate="atomic")
+            if fuse_cs:
+                if t == 0:
+                    ops.obs_blend_bwd(dsin[0], ddin, first[0], None, None, dstoch0, ddeter0)
+            elif fuse_carry and t > 0:
                 ops.obs_carry_st_bwd(dsin[t], ddin, first[t], gs[t - 1], gd[t - 1], dstoch0, ddeter0, post_logit[t - 1],
                                      dpost_logit[t - 1], unimix=self.unimix)
             else:
@@ -528,7 +568,7 @@ class RSSMEngine:
         # ---- the encoder-output gradient (critical path) and, beside it, the batched weight gradients
         side.join()  # the init-state backward below adds into the same prior-head gradients
         ops.gemm(v2(dx3pre, Hd), P.obs_out.W[:, De:], v2(dembed, E), transB=False)
-        dpl = v2(dpost_logit, SD)
+        dpl = v2(dpl_out, SD)
 
         def _scan_wgrads():
             lin_wgrad(P.obs.W, dpl, v2(x3, Hd))

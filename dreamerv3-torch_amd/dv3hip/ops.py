@@ -430,6 +430,123 @@ def gru_fwd(p, gamma, beta, h, h_new, mean, rstd, *, next_blend=None):
     return h_new
 
 
+def scan_ln_gemm_ok(K, N) -> bool:
+    """Shapes dv3_scan_ln_gemm_fwd takes (K = the LayerNorm width)."""
+    return K in (256, 512, 1024) and N % 16 == 0
+
+
+def scan_ln_gemm(x, gamma, beta, y, mean, rstd, W, C, *, bias=None, accumulate=False):
+    """ln_act_fwd(act=True) and C (+)= y @ W^T + bias in ONE launch (the observe scan's obs_out LayerNorm + the
+    posterior-logit Linear, networks.py:197-200).  y / mean / rstd may be None."""
+    M, K, ldx = _rows2d(x, "x")
+    N, Kw, ldw = _rows2d(W, "W")
+    Mc, Nc, ldc = _rows2d(C, "C")
+    if Kw != K or (Mc, Nc) != (M, N):
+        raise ValueError("scan_ln_gemm shapes mismatch")
+    if not scan_ln_gemm_ok(K, N):
+        raise ValueError(f"scan_ln_gemm: unsupported K={K} N={N}")
+    _contig(gamma, "gamma"), _contig(beta, "beta")
+    if gamma.numel() != K or beta.numel() != K:
+        raise ValueError("scan_ln_gemm param sizes mismatch")
+    ldy = 0
+    if y is not None:
+        My, Ky, ldy = _rows2d(y, "y")
+        if (My, Ky) != (M, K):
+            raise ValueError("scan_ln_gemm y shape mismatch")
+    for t, nm in ((mean, "mean"), (rstd, "rstd")):
+        if t is not None:
+            _contig(t, nm)
+            if t.numel() != M:
+                raise ValueError(f"scan_ln_gemm {nm} size mismatch")
+    if bias is not None:
+        _contig(bias, "bias")
+        if bias.numel() != N:
+            raise ValueError("scan_ln_gemm bias size mismatch")
+    _call("dv3_scan_ln_gemm_fwd", _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(y), ldy, _ptr(mean), _ptr(rstd), _ptr(W),
+          ldw, _ptr(bias), _ptr(C), ldc, M, K, N, int(bool(accumulate)), _stream(),
+          key="gemm_kernel<skinny16+ln,tA=0,tB=1>", flops=2.0 * M * N * K, nbytes=4.0 * (N * K + M * (2 * K + N)))
+    return C
+
+
+def scan_lnbwd_gemm_ok(K, N) -> bool:
+    return K in (256, 512, 1024) and N % 64 == 0
+
+
+def scan_ln_factors(x, gamma, beta, mean, rstd, xhat, jac):
+    """xhat = (x - mean) * rstd, jac = SiLU'(xhat * gamma + beta) for all rows of a LayerNorm + SiLU layer: what its
+    backward needs from the forward pass (scan_lnbwd_gemm reads them; once per update, in front of the reverse scan)."""
+    R, K, ldx = _rows2d(x, "x")
+    _contig(gamma, "gamma"), _contig(beta, "beta"), _contig(mean, "mean"), _contig(rstd, "rstd")
+    _contig(xhat, "xhat"), _contig(jac, "jac")
+    if gamma.numel() != K or beta.numel() != K or mean.numel() != R or rstd.numel() != R or xhat.numel() != R * K \
+            or jac.numel() != R * K or K % 4:
+        raise ValueError("scan_ln_factors sizes mismatch")
+    _call("dv3_scan_ln_factors", _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(xhat), _ptr(jac), R, K,
+          _stream(), nbytes=12.0 * R * K)
+
+
+def scan_lnbwd_gemm(dy, xhat, jac, gamma, rstd, dx, W, C, dgamma=None, dbeta=None):
+    """ln_act_bwd(act=True) from the precomputed factors (scan_ln_factors) and C += dx @ W (atomic) in ONE launch
+    (reverse observe scan).  W [K, N] may be a column slice of a wider [K, .] weight; C must hold the value being
+    added to."""
+    M, K, lddy = _rows2d(dy, "dy")
+    Md, Kd, lddx = _rows2d(dx, "dx")
+    Kw, N, ldb = _rows2d(W, "W")
+    Mc, Nc, ldc = _rows2d(C, "C")
+    if (Md, Kd) != (M, K) or Kw != K or (Mc, Nc) != (M, N):
+        raise ValueError("scan_lnbwd_gemm shapes mismatch")
+    if not scan_lnbwd_gemm_ok(K, N):
+        raise ValueError(f"scan_lnbwd_gemm: unsupported K={K} N={N}")
+    _contig(gamma, "gamma"), _contig(rstd, "rstd"), _contig(xhat, "xhat"), _contig(jac, "jac")
+    if gamma.numel() != K or rstd.numel() != M or xhat.numel() != M * K or jac.numel() != M * K:
+        raise ValueError("scan_lnbwd_gemm param sizes mismatch")
+    if (dgamma is None) != (dbeta is None):
+        raise ValueError("dgamma/dbeta: both or neither")
+    if dgamma is not None:
+        _contig(dgamma, "dgamma"), _contig(dbeta, "dbeta")
+        if dgamma.numel() != K or dbeta.numel() != K:
+            raise ValueError("scan_lnbwd_gemm dgamma size mismatch")
+    _call("dv3_scan_lnbwd_gemm", _ptr(dy), lddy, _ptr(xhat), _ptr(jac), _ptr(gamma), _ptr(rstd), _ptr(dx), lddx,
+          _ptr(dgamma), _ptr(dbeta), _ptr(W), ldb, _ptr(C), ldc, M, K, N, _stream(),
+          key="gemm_kernel<skinny16+lnbwd,tA=0,tB=0>", flops=2.0 * M * N * K, nbytes=4.0 * (N * K + M * (4 * K + 2 * N)))
+    return C
+
+
+def scan_carry_st_gemm_ok(S, D, N) -> bool:
+    return D == 32 and S % 8 == 0 and N % 64 == 0
+
+
+def scan_carry_st_gemm(gs, logit, dlogit, dlogit_out, W, C, *, unimix, carry=None):
+    """Reverse observe scan, first launch of a step: carry (optional) + straight-through gradient of the posterior
+    sample + C += dlogit_out @ W (atomic).  gs [B, S*D], logit / dlogit / dlogit_out [B, S, D] contiguous, W [S*D, N].
+    carry = (dsin [B, S*D], ddin [B, De], first [B], gd [B, De], dstoch0 [S*D], ddeter0 [De]) of the NEXT step."""
+    _contig(logit, "logit"), _contig(dlogit, "dlogit"), _contig(dlogit_out, "dlogit_out"), _contig(gs, "gs")
+    if logit.dim() != 3 or dlogit.shape != logit.shape or dlogit_out.shape != logit.shape:
+        raise ValueError("scan_carry_st_gemm: logit / dlogit [B,S,D]")
+    B, S, D = logit.shape
+    Kw, N, ldb = _rows2d(W, "W")
+    Mc, Nc, ldc = _rows2d(C, "C")
+    if Kw != S * D or (Mc, Nc) != (B, N) or gs.numel() != B * S * D:
+        raise ValueError("scan_carry_st_gemm shapes mismatch")
+    if not scan_carry_st_gemm_ok(S, D, N) or dlogit_out.data_ptr() == dlogit.data_ptr():
+        raise ValueError(f"scan_carry_st_gemm: unsupported S={S} D={D} N={N} (or aliased output)")
+    dsin = ddin = first = gd = ds0 = dd0 = None
+    ld_dsin = ld_ddin = De = 0
+    if carry is not None:
+        dsin, ddin, first, gd, ds0, dd0 = carry
+        Bs, SDs, ld_dsin = _rows2d(dsin, "dsin")
+        Bd, De, ld_ddin = _rows2d(ddin, "ddin")
+        _contig(first, "first"), _contig(gd, "gd"), _contig(ds0, "dstoch0"), _contig(dd0, "ddeter0")
+        if (Bs, SDs) != (B, S * D) or Bd != B or first.numel() != B or gd.numel() != B * De or ds0.numel() != S * D \
+                or dd0.numel() != De:
+            raise ValueError("scan_carry_st_gemm carry shapes mismatch")
+    _call("dv3_scan_carry_st_gemm", _ptr(dsin), ld_dsin, _ptr(ddin), ld_ddin, _ptr(first), _ptr(gs), _ptr(gd), _ptr(ds0),
+          _ptr(dd0), _ptr(logit), _ptr(dlogit), _ptr(dlogit_out), _ptr(W), ldb, _ptr(C), ldc, B, S, D, De, N,
+          float(unimix), _stream(), key="gemm_kernel<skinny16+carry_st,tA=0,tB=0>", flops=2.0 * B * N * S * D,
+          nbytes=4.0 * (N * S * D + B * (5 * S * D + 2 * N)))
+    return C
+
+
 def gru_bwd(dh_new, p, gamma, beta, h, mean, rstd, dp, dh, dgamma=None, dbeta=None, *, accumulate_dh=False):
     M, N3, ldp = _rows2d(p, "p")
     Mh, De, ldh = _rows2d(h, "h")

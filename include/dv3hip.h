@@ -346,6 +346,41 @@ int dv3_onehot_sample_linear_ln_fwd(const float* logit, const float* noise, cons
                                     long ldpre, const float* gamma, const float* beta, float* y, long ldy, float* mean,
                                     float* rstd, long M, int N, int act, void* stream);
 
+/* ---- few-row launches of the observe scan with the preceding row operation in the GEMM's prologue
+ * (csrc/scanops.hip; RSSM.obs_step, networks.py:174-206) ------------------------------------------------
+ * Every workgroup of the few-row GEMM recomputes the row sums of the (<= 16 per row block) complete rows and
+ * transforms only the A fragments it multiplies; workgroup column 0 stores the transformed rows.
+ * dv3_scan_ln_gemm_fwd: y = SiLU(LN(x)) (= dv3_ln_act_fwd), then C[M,N] (+)= y W^T + bias (RSSM._obs_stat_layer on
+ *   the output of _obs_out_layers, networks.py:197-200); bit-identical to the two launches it replaces.
+ *   K in {256, 512, 1024}; N % 16 == 0; y / mean / rstd optional. */
+int dv3_scan_ln_gemm_fwd(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy,
+                         float* mean, float* rstd, const float* W, long ldw, const float* bias, float* C, long ldc,
+                         int M, int K, int N, int accumulate, void* stream);
+
+/* Reverse observe scan (same file): the data-gradient few-row GEMMs dX = dY W (W [K][N] row-major; K split over
+ * workgroups, partial tiles added with atomics as dv3_gemm_f32 accumulate = 2 does) with the row operation that
+ * produces dY in their prologue.
+ * dv3_scan_ln_factors: xhat = (x - mean) rstd and jac = SiLU'(xhat gamma + beta), [R, K] contiguous: the factors of a
+ *   LayerNorm + SiLU layer's backward that depend on forward data only -- computed once per update for all T*B rows
+ *   in front of the reverse scan, so that the per-step prologue below is multiply-add only.
+ * dv3_scan_lnbwd_gemm: dx = rstd (dy jac gamma - mean_c(.) - xhat mean_c(. xhat)) (= dv3_ln_act_bwd, act = 1;
+ *   d-gamma / d-beta accumulated), then C[M,N] += dx W.  K in {256, 512, 1024}, N % 64 == 0.  Reverse of
+ *   RSSM._obs_out_layers / _img_in_layers inside obs_step (networks.py:195-197, 216-218).
+ * dv3_scan_carry_st_gemm: t = gs + dsin (1 - first) (the carry through the next step's reset blend,
+ *   networks.py:183-191; dstoch0 += sum_b dsin first; dsin == NULL: no carry, the scan's last step),
+ *   dlogit_out = dlogit + straight-through gradient of the posterior sample at t (tools.py:452-460; = dv3_onehot_st_bwd),
+ *   C[B,N] += dlogit_out W; extra workgroups add the deter carry gd += ddin (1 - first), ddeter0 += sum_b ddin first
+ *   (= dv3_obs_carry_st_bwd).  D == 32, S % 8 == 0, N % 64 == 0; dlogit_out must not alias dlogit. */
+int dv3_scan_ln_factors(const float* x, long ldx, const float* gamma, const float* beta, const float* mean,
+                        const float* rstd, float* xhat, float* jac, long R, int K, void* stream);
+int dv3_scan_lnbwd_gemm(const float* dy, long lddy, const float* xhat, const float* jac, const float* gamma,
+                        const float* rstd, float* dx, long lddx, float* dgamma, float* dbeta, const float* W, long ldb,
+                        float* C, long ldc, int M, int K, int N, void* stream);
+int dv3_scan_carry_st_gemm(const float* dsin, long ld_dsin, const float* ddin, long ld_ddin, const float* is_first,
+                           const float* gs, float* gd, float* dstoch0, float* ddeter0, const float* logit,
+                           const float* dlogit, float* dlogit_out, const float* W, long ldb, float* C, long ldc, int B,
+                           int S, int D, int De, int N, float unimix, void* stream);
+
 /* ---- row-fused layers of the imagination step (csrc/fusedops.hip) -----------------------------------
  * dv3_onehot_linear_ln_fwd: pre[M,N] = base + sum_s WT[s*D + idx[m][s]] + sum_a x2[m][a] * WT[S*D + a], then
  * y = act(LN(pre)) (y == NULL: pre only).  The Linear + LayerNorm + SiLU whose input is cat[stoch.flat, tail]

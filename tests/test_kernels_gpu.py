@@ -1188,3 +1188,101 @@ def test_gemm_sample_with_layernorm_on_load(ops, M, N, K):
     assert_close(lg1, ref, tol=2e-4, what="logits vs torch")
     assert (st1 != st0).any(-1).float().mean() <= 1e-3
 
+
+
+# ------------------------------------------------------------------------------------------ observe-scan fused launches
+@pytest.mark.parametrize("M,K,N", [(16, 512, 1024), (32, 1024, 1024), (7, 256, 48), (64, 512, 256), (1, 1024, 1024)])
+def test_scan_ln_gemm_equals_two_launches(ops, M, K, N):
+    """dv3_scan_ln_gemm_fwd == dv3_ln_act_fwd followed by the few-row GEMM with bias (bit-equal), and against the
+    plain math: SiLU(LN(x)) W^T + b (networks.py:197-200)."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = dev(torch.randn(M, K, generator=g) * 2 + 0.3)
+    gam, bet = dev(1 + 0.1 * torch.randn(K, generator=g)), dev(0.1 * torch.randn(K, generator=g))
+    W, bias = dev(torch.randn(N, K, generator=g) / math.sqrt(K)), dev(0.1 * torch.randn(N, generator=g))
+    mk = lambda *s: torch.full(s, float("nan"), device="cuda")
+    a = dict(y=mk(M, K), mean=mk(M), rstd=mk(M), C=mk(M, N))
+    b = dict(y=mk(M, K), mean=mk(M), rstd=mk(M), C=mk(M, N))
+    ops.ln_act_fwd(x, gam, bet, a["y"], a["mean"], a["rstd"], act=True)
+    ops.gemm(a["y"], W, a["C"], bias=bias)
+    ops.scan_ln_gemm(x, gam, bet, b["y"], b["mean"], b["rstd"], W, b["C"], bias=bias)
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, (a[k] - b[k]).abs().max().item())
+    ref_y = F.silu(O.layer_norm(x.cpu(), gam.cpu(), bet.cpu()))
+    assert_close(b["y"], ref_y, what="y")
+    assert_close(b["C"], ref_y @ W.cpu().T + bias.cpu(), tol=TOL * math.sqrt(K / 64), what="C")
+    # without the saved outputs, accumulating
+    C2 = a["C"].clone()
+    ops.scan_ln_gemm(x, gam, bet, None, None, None, W, C2, accumulate=True)
+    assert_close(C2, 2 * a["C"].cpu() - bias.cpu(), tol=TOL * math.sqrt(K / 64), what="accumulate")
+
+
+@pytest.mark.parametrize("M,K,N,pad", [(16, 512, 512, 4096), (16, 512, 1024, 6), (32, 1024, 1024, 18), (7, 256, 64, 0),
+                                         (64, 512, 512, 8)])
+def test_scan_lnbwd_gemm_equals_two_launches(ops, M, K, N, pad):
+    """dv3_scan_lnbwd_gemm == dv3_ln_act_bwd followed by the atomically accumulating few-row data-gradient GEMM:
+    dx and the LayerNorm parameter gradients to rounding, C += dx W (networks.py:195-197, 216-218 reversed)."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = dev(torch.randn(M, K, generator=g) * 1.5 + 0.2)
+    dy = dev(torch.randn(M, K + 64, generator=g))[:, :K]  # a row-strided view, as the GRU matmul's [dx1 | ddin] is
+    gam, bet = dev(1 + 0.1 * torch.randn(K, generator=g)), dev(0.1 * torch.randn(K, generator=g))
+    W = dev(torch.randn(K, N + pad, generator=g) / math.sqrt(K))[:, :N]  # column slice of a wider weight
+    C0 = dev(torch.randn(M, N, generator=g))
+    y, mean, rstd = torch.empty(M, K).cuda(), torch.empty(M).cuda(), torch.empty(M).cuda()
+    ops.ln_act_fwd(x, gam, bet, y, mean, rstd, act=True)
+    a = dict(dx=torch.empty(M, K).cuda(), dg=torch.ones(K).cuda(), db=torch.ones(K).cuda(), C=C0.clone())
+    b = dict(dx=torch.empty(M, K).cuda(), dg=torch.ones(K).cuda(), db=torch.ones(K).cuda(), C=C0.clone())
+    ops.ln_act_bwd(dy, x, gam, bet, mean, rstd, a["dx"], a["dg"], a["db"], act=True)
+    ops.gemm(a["dx"], W, a["C"], transB=False, accumulate="atomic")
+    xhat, jac = torch.empty(M, K).cuda(), torch.empty(M, K).cuda()
+    ops.scan_ln_factors(x, gam, bet, mean, rstd, xhat, jac)
+    ops.scan_lnbwd_gemm(dy, xhat, jac, gam, rstd, b["dx"], W, b["C"], b["dg"], b["db"])
+    assert_close(b["dx"], a["dx"].cpu(), tol=2e-6, what="dx")
+    assert_close(b["dg"], a["dg"].cpu(), tol=1e-5, what="dgamma"), assert_close(b["db"], a["db"].cpu(), tol=1e-5, what="dbeta")
+    assert_close(b["C"], a["C"].cpu(), tol=1e-5 * math.sqrt(K / 64), what="C")
+    # and against autograd on the plain math
+    xr = x.cpu().clone().requires_grad_(True)
+    gr, br = gam.cpu().clone().requires_grad_(True), bet.cpu().clone().requires_grad_(True)
+    F.silu(O.layer_norm(xr, gr, br)).backward(dy.cpu())
+    assert_close(b["dx"], xr.grad, tol=2e-5, what="dx vs autograd")
+    assert_close(b["dg"] - 1, gr.grad, tol=2e-4, what="dgamma vs autograd")
+    assert_close(b["C"], C0.cpu() + xr.grad @ W.cpu(), tol=TOL * math.sqrt(K / 64), what="C vs autograd")
+    # without parameter gradients
+    C2 = C0.clone()
+    ops.scan_lnbwd_gemm(dy, xhat, jac, gam, rstd, b["dx"], W, C2)
+    assert_close(C2, a["C"].cpu(), tol=1e-5 * math.sqrt(K / 64), what="C (no dgamma)")
+
+
+@pytest.mark.parametrize("B,S,De,N", [(16, 32, 512, 512), (32, 32, 1024, 512), (5, 8, 64, 64), (64, 32, 512, 1024)])
+@pytest.mark.parametrize("with_carry", [True, False])
+def test_scan_carry_st_gemm_equals_two_launches(ops, B, S, De, N, with_carry):
+    """dv3_scan_carry_st_gemm == dv3_obs_carry_st_bwd (resp. dv3_onehot_st_bwd at the scan's last step) followed by the
+    atomically accumulating few-row GEMM dx3 += dlogit W_obs."""
+    D = 32
+    SD = S * D
+    g = torch.Generator().manual_seed(B + S + De + N)
+    logit = dev(2 * torch.randn(B, S, D, generator=g))
+    dlogit = dev(torch.randn(B, S, D, generator=g))
+    gs = dev(torch.randn(B, SD, generator=g))
+    gd0 = dev(torch.randn(B, De, generator=g))
+    dsin = dev(torch.randn(B, SD, generator=g))
+    dxd = dev(torch.randn(B, 48 + De, generator=g))
+    ddin = dxd[:, 48:]  # strided view like dxd[t][:, Hd:]
+    first = dev((torch.rand(B, generator=g) < 0.4).float())
+    W = dev(torch.randn(SD, N, generator=g) / math.sqrt(SD))
+    C0 = dev(torch.randn(B, N, generator=g))
+    a = dict(gs=gs.clone(), gd=gd0.clone(), ds0=torch.zeros(SD).cuda(), dd0=torch.zeros(De).cuda(), dl=dlogit.clone(),
+             C=C0.clone())
+    if with_carry:
+        ops.obs_carry_st_bwd(dsin, ddin, first, a["gs"], a["gd"], a["ds0"], a["dd0"], logit, a["dl"], unimix=0.01)
+    else:
+        ops.onehot_st_bwd(logit, a["gs"].view(B, S, D), a["dl"], unimix=0.01, accumulate=True)
+    ops.gemm(a["dl"].view(B, SD), W, a["C"], transB=False, accumulate="atomic")
+    b = dict(gd=gd0.clone(), ds0=torch.zeros(SD).cuda(), dd0=torch.zeros(De).cuda(),
+             dl=torch.full((B, S, D), float("nan"), device="cuda"), C=C0.clone())
+    ops.scan_carry_st_gemm(gs, logit, dlogit, b["dl"], W, b["C"], unimix=0.01,
+                           carry=(dsin, ddin, first, b["gd"], b["ds0"], b["dd0"]) if with_carry else None)
+    assert_close(b["dl"], a["dl"].cpu(), tol=2e-6, what="dlogit")
+    assert_close(b["C"], a["C"].cpu(), tol=1e-5 * math.sqrt(SD / 64), what="C")
+    if with_carry:
+        assert torch.equal(b["gd"], a["gd"])
+        assert_close(b["ds0"], a["ds0"].cpu(), tol=1e-5, what="dstoch0"), assert_close(b["dd0"], a["dd0"].cpu(), tol=1e-5, what="ddeter0")
