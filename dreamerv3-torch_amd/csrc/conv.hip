@@ -981,6 +981,337 @@ __global__ __launch_bounds__(256) void convT_s2_c3_kernel(const float* __restric
   }
 }
 
+// The same layer on the matrix cores: an input pixel (iy, ix) contributes in[iy, ix, :] (CW) x Wm[CW][48] to the
+// 4 x 4 x 3 output patch at (2 iy - 1, 2 ix - 1) -- Wm[ci][(co, ky, kx)] is the ConvTranspose2d weight as stored.  That is
+// a dense GEMM M = pixels, K = CW, N = 48 (three 16-column MFMA blocks, no padding of the 3 output channels to 16) whose
+// A rows are the NHWC pixels themselves (one 16-byte global load per lane per 16-k chunk, all of a wave's row blocks
+// in flight together, no staging), followed by the overlap-add of the patches: a workgroup owns a 16 x 16 input tile
+// (+ one pixel of halo: 324 GEMM rows in 21 row blocks over its 4 waves), writes the products P[pixel][48] to LDS
+// and every thread then GATHERS the four terms of each of its 12 outputs of the 32 x 32 x 3 tile, stored as 384-byte
+// rows.  (Adding the patches into an LDS tile with ds_add_f32 instead measured 266 us: LDS float atomics retire about
+// two lanes per clock; the thread-per-pixel VALU form above: 178 us for 1024 frames; HBM floor of the layer: ~25 us.)
+template <int CW>
+__global__ __launch_bounds__(256) void convT_s2_c3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float out_add,
+                                                               float* __restrict__ y, int Nimg, int IH, int IW,
+                                                               int accumulate) {
+  constexpr int NCH = CW / 16;
+  constexpr int RB = (18 * 18 + 15) / 16;  // 21 row blocks of 16 tile pixels (halo included)
+  constexpr int LDP = 52;                  // row stride of P: the four 4-row groups of a store land 16 banks apart
+  __shared__ float P[RB * 16 * LDP];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int tx_n = IW / 16, ty_n = IH / 16;
+  const int img = blockIdx.x / (tx_n * ty_n), trem = blockIdx.x % (tx_n * ty_n);
+  const int ty = trem / tx_n, tx = trem % tx_n;
+  const float* xin = x + (long)img * IH * IW * CW;
+  // B fragments: Wm[k = 16 c + 4 q + g][n = 16 b + i]
+  f32x4 bf[NCH][3];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bf[c][b][g] = w[(long)(16 * c + 4 * q + g) * 48 + 16 * b + i];
+  constexpr int RPW = (RB + 3) / 4;        // row blocks per wave (6), loaded JB at a time: ONE memory round trip per batch
+  constexpr int JB = NCH <= 2 ? RPW : 2;
+  for (int j0 = 0; j0 < RPW; j0 += JB) {
+    f32x4 af[JB][NCH];
+    float msk[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const int pl = (wave + 4 * (j0 + j)) * 16 + i;  // the pixel this lane loads
+      const int ly = pl / 18, lx = pl % 18;
+      const int gy = ty * 16 + ly - 1, gx = tx * 16 + lx - 1;
+      const bool ok = pl < 18 * 18 && gy >= 0 && gy < IH && gx >= 0 && gx < IW;
+      const float* src = xin + ((long)(ok ? gy : 0) * IW + (ok ? gx : 0)) * CW + 4 * q;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) af[j][c] = *reinterpret_cast<const f32x4u*>(src + 16 * c);
+      msk[j] = ok ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+      const int rbk = wave + 4 * (j0 + j);
+      if (rbk >= RB) continue;  // wave-uniform
+      f32x4 acc[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int b = 0; b < 3; ++b)
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][c][g] * msk[j], bf[c][b][g], acc[b], 0, 0, 0);
+      // acc[b][r]: tile pixel rbk * 16 + 4 q + r, column 16 b + i
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) P[(rbk * 16 + 4 * q + r) * LDP + 16 * b + i] = acc[b][r];
+    }
+  }
+  __syncthreads();
+  // output (oy, ox, c) of the tile = sum over its two (ky, ly) x two (kx, lx) source pairs: oy = 2 ly - 3 + ky
+  const int OH = 2 * IH, OW = 2 * IW;
+  const float bb[3] = {(bias ? bias[0] : 0.f) + out_add, (bias ? bias[1] : 0.f) + out_add, (bias ? bias[2] : 0.f) + out_add};
+#pragma unroll 4
+  for (int f = tid; f < 32 * 32 * 3; f += 256) {
+    const int oy = f / 96, col = f % 96;
+    const int ox = col / 3, c = col % 3;
+    const int ky0 = (oy + 1) & 1, kx0 = (ox + 1) & 1;
+    float v = bb[c];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int ky = ky0 + 2 * dy, kx = kx0 + 2 * dx;
+        const int ly = (oy + 3 - ky) >> 1, lx = (ox + 3 - kx) >> 1;
+        v += P[(ly * 18 + lx) * LDP + c * 16 + ky * 4 + kx];
+      }
+    float* o = y + (((long)img * OH + 32 * ty + oy) * OW + 32 * tx) * 3 + col;
+    *o = accumulate ? (*o + v) : v;
+  }
+}
+
+// Weight gradient of the two image-side layers (encoder Conv2d 3 -> CW: coarse = dY, fine = image; decoder
+// ConvTranspose2d CW -> 3: coarse = layer input, fine = dOut), straight into the reference layout dw[CW][3][4][4]:
+//   dw[cc][(c, ky, kx)] += sum over coarse pixels (n, cy, cx) of coarse[n, cy, cx, cc] * fine[n, 2 cy - 1 + ky, 2 cx - 1 + kx, c]
+// = a GEMM M = CW, N = 48, K = coarse pixels.  HBM-side (184 MB per launch at 1024 frames against 3.2 GFLOP): a
+// workgroup walks 16 x 16 coarse-pixel tiles (grid-stride), stages the tile [256][CW] (row stride CW + 16: the four
+// k-lanes of a ds_read_b32 fragment read land in four different 16-bank windows) and the 34 x 34 x 3 fine window in LDS,
+// its 4 waves split the 256 pixels (16 k-steps x CW/16 x 3 MFMAs each), the NEXT tile's loads are in flight in
+// registers meanwhile, and the accumulators live across all the tiles of the workgroup: one LDS reduction over the
+// waves and CW x 48 atomics per workgroup at the end (no packed scratch, no unpack launch).
+template <int CW>
+__global__ __launch_bounds__(256) void conv_wgrad_c3_kernel(const float* __restrict__ coarse,
+                                                            const float* __restrict__ fine, float* __restrict__ dw,
+                                                            int Nimg, int H, int W) {
+  constexpr int MA = CW / 16, LDC = CW + 16;
+  constexpr int CV = 256 * (CW / 4) / 256;            // float4 of the coarse tile per thread
+  constexpr int FN = 34 * 34 * 3, FV = (FN + 255) / 256;  // floats of the fine window (per thread)
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  float* cs = wlds;               // [256][LDC]
+  float* fs = wlds + 256 * LDC;   // [34 * 34 * 3]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int OH = H / 2, OW = W / 2;
+  const int tx_n = OW / 16, ty_n = OH / 16;
+  const int tiles = Nimg * tx_n * ty_n;
+  f32x4 cv[CV];
+  float fv[FV];
+  auto gload = [&](int tile) {
+    const int img = tile / (tx_n * ty_n), trem = tile % (tx_n * ty_n);
+    const int ty = trem / tx_n, tx = trem % tx_n;
+    const float* cbase = coarse + (((long)img * OH + ty * 16) * OW + tx * 16) * CW;
+#pragma unroll
+    for (int j = 0; j < CV; ++j) {
+      const int f = tid + 256 * j;
+      const int pix = f / (CW / 4), c4 = (f % (CW / 4)) * 4;
+      cv[j] = *reinterpret_cast<const f32x4u*>(cbase + ((long)(pix >> 4) * OW + (pix & 15)) * CW + c4);
+    }
+    const float* fbase = fine + (long)img * H * W * 3;
+#pragma unroll
+    for (int j = 0; j < FV; ++j) {
+      const int f = tid + 256 * j;
+      const int fy = f / 102, fr = f % 102;  // 102 = 34 * 3 floats per window row
+      const int gy = 32 * ty - 1 + fy, gxc = (32 * tx - 1) * 3 + fr;
+      const bool ok = f < FN && gy >= 0 && gy < H && gxc >= 0 && gxc < 3 * W;
+      fv[j] = ok ? fbase[(long)gy * W * 3 + gxc] : 0.f;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < CV; ++j) {
+      const int f = tid + 256 * j;
+      *reinterpret_cast<f32x4*>(&cs[(f / (CW / 4)) * LDC + (f % (CW / 4)) * 4]) = cv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < FV; ++j) {
+      const int f = tid + 256 * j;
+      if (f < FN) fs[f] = fv[j];
+    }
+  };
+  f32x4 acc[MA][3];
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // this lane's B columns n = 16 b + i -> (c, ky, kx): offset of the patch element inside the fine window
+  int boff[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const int n = 16 * b + i;
+    boff[b] = (((n >> 2) & 3) * 34 + (n & 3)) * 3 + (n >> 4);
+  }
+  int tile = blockIdx.x;
+  if (tile < tiles) gload(tile);
+  for (; tile < tiles; tile += gridDim.x) {
+    __syncthreads();  // the previous tile's readers are done
+    lstore();
+    __syncthreads();
+    if (tile + (int)gridDim.x < tiles) gload(tile + gridDim.x);  // in flight during the MFMAs below
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int pk = wave * 64 + 4 * s + q;  // this lane's k (pixel of the tile) for the step
+      const int cy = pk >> 4, cx = pk & 15;
+      float av[MA], bv[3];
+#pragma unroll
+      for (int a = 0; a < MA; ++a) av[a] = cs[pk * LDC + 16 * a + i];
+      const int fo = (2 * cy * 34 + 2 * cx) * 3;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) bv[b] = fs[fo + boff[b]];
+#pragma unroll
+      for (int a = 0; a < MA; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  // reduce the four waves' CW x 48 partial sums through LDS (reusing cs), then one atomic per element
+  __syncthreads();
+  float* red = cs;  // [4][MA * 3 * 256]
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * MA * 3 + a * 3 + b) * 256 + r * 64 + lane] = acc[a][b][r];
+  __syncthreads();
+  for (int e = tid; e < MA * 3 * 256; e += 256) {
+    const int blk = e >> 8, x = e & 255;
+    const int a = blk / 3, b = blk % 3;
+    const int r = x >> 6, l = x & 63;
+    const int cc = 16 * a + 4 * (l >> 4) + r, n = 16 * b + (l & 15);
+    const float v = red[e] + red[MA * 3 * 256 + e] + red[2 * MA * 3 * 256 + e] + red[3 * MA * 3 * 256 + e];
+    atomicAdd(dw + (long)cc * 48 + n, v);
+  }
+}
+
+// Weight gradient of the narrow layer pair next to the image layers (fine 32 channels, coarse 64: encoder layer 2 /
+// decoder layer 3 at cnn_depth 32), the same tile walk with the WHOLE 64 x 512 gradient in the accumulators of one
+// workgroup: on the split-K 64 x 64 tiles every column tile re-reads the coarse rows and re-gathers its two taps of
+// the fine rows from L2 for 262 KFLOP per 16 KB (56 TFLOP/s, 39 % MFMA-busy, 307 us at 1024 frames).  Here a workgroup
+// (8 waves, two per SIMD) walks 8 x 8 coarse-pixel tiles: the tile [64][CC] (row stride CC + 16) and its 18 x 18 x CF
+// fine window (row stride CF + 8: the four k-lanes of a fragment read are two fine pixels apart = 16 banks) are
+// staged once and serve all 16 taps; wave w owns taps 2 w, 2 w + 1 (4 column blocks) x all CC rows: per k-step of
+// 4 pixels 4 + 4 ds_read_b32 feed 16 MFMAs; the next tile's loads are in flight in registers.  The per-workgroup
+// partial sums go to partial[workgroup][CC][16 CF] and conv_wgrad_tile_reduce_kernel adds them into the reference
+// layout dw[CC][CF][4][4] (two-stage: 32 K atomics per workgroup would serialise at the fabric).
+template <int CF, int CC>
+__global__ __launch_bounds__(512) void conv_wgrad_tile_kernel(const float* __restrict__ coarse,
+                                                              const float* __restrict__ fine, float* __restrict__ partial,
+                                                              int Nimg, int H, int W) {
+  constexpr int NT = 512, MA = CC / 16, NH = CF / 16, LDC = CC + 16, LDF = CF + 8;
+  constexpr int CVN = 64 * (CC / 4), CV = (CVN + NT - 1) / NT;        // float4 of the coarse tile (per thread)
+  constexpr int FVN = 18 * 18 * (CF / 4), FV = (FVN + NT - 1) / NT;   // float4 of the fine window (per thread)
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  float* cs = wlds;             // [64][LDC]
+  float* fs = wlds + 64 * LDC;  // [18 * 18][LDF]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int OH = H / 2, OW = W / 2;
+  const int tx_n = OW / 8, ty_n = OH / 8;
+  const int tiles = Nimg * tx_n * ty_n;
+  f32x4 cv[CV], fv[FV];
+  auto gload = [&](int tile) {
+    const int img = tile / (tx_n * ty_n), trem = tile % (tx_n * ty_n);
+    const int ty = trem / tx_n, tx = trem % tx_n;
+    const float* cbase = coarse + (((long)img * OH + ty * 8) * OW + tx * 8) * CC;
+#pragma unroll
+    for (int j = 0; j < CV; ++j) {
+      const int f = tid + NT * j;
+      const int pix = (f < CVN ? f : 0) / (CC / 4), c4 = (f % (CC / 4)) * 4;
+      cv[j] = *reinterpret_cast<const f32x4u*>(cbase + ((long)(pix >> 3) * OW + (pix & 7)) * CC + c4);
+    }
+    const float* fbase = fine + (long)img * H * W * CF;
+#pragma unroll
+    for (int j = 0; j < FV; ++j) {
+      const int f = tid + NT * j;
+      const int pix = f / (CF / 4), c4 = (f % (CF / 4)) * 4;
+      const int fy = pix / 18, fx = pix % 18;
+      const int gy = 16 * ty - 1 + fy, gx = 16 * tx - 1 + fx;
+      const bool ok = f < FVN && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      fv[j] = *reinterpret_cast<const f32x4u*>(fbase + ((long)(ok ? gy : 0) * W + (ok ? gx : 0)) * CF + c4);
+      if (!ok) fv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < CV; ++j) {
+      const int f = tid + NT * j;
+      if (f < CVN) *reinterpret_cast<f32x4*>(&cs[(f / (CC / 4)) * LDC + (f % (CC / 4)) * 4]) = cv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < FV; ++j) {
+      const int f = tid + NT * j;
+      if (f < FVN) *reinterpret_cast<f32x4*>(&fs[(f / (CF / 4)) * LDF + (f % (CF / 4)) * 4]) = fv[j];
+    }
+  };
+  f32x4 acc[MA][2 * NH];  // column block nb = 2-tap index * NH + channel half
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int b = 0; b < 2 * NH; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // this wave's taps: 2 wave + tt -> (ky, kx); fine-window offset of the tap for column block b
+  int boff[2 * NH];
+#pragma unroll
+  for (int b = 0; b < 2 * NH; ++b) {
+    const int tap = 2 * wave + b / NH;
+    boff[b] = ((tap >> 2) * 18 + (tap & 3)) * LDF + 16 * (b % NH) + i;
+  }
+  int tile = blockIdx.x;
+  if (tile < tiles) gload(tile);
+  for (; tile < tiles; tile += gridDim.x) {
+    __syncthreads();  // the previous tile's readers are done
+    lstore();
+    __syncthreads();
+    if (tile + (int)gridDim.x < tiles) gload(tile + gridDim.x);  // in flight during the MFMAs below
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int pk = 4 * s + q;  // this lane's k (coarse pixel of the tile) for the step
+      const int cy = pk >> 3, cx = pk & 7;
+      float av[MA], bv[2 * NH];
+#pragma unroll
+      for (int a = 0; a < MA; ++a) av[a] = cs[pk * LDC + 16 * a + i];
+      const int fo = (2 * cy * 18 + 2 * cx) * LDF;
+#pragma unroll
+      for (int b = 0; b < 2 * NH; ++b) bv[b] = fs[fo + boff[b]];
+#pragma unroll
+      for (int a = 0; a < MA; ++a)
+#pragma unroll
+        for (int b = 0; b < 2 * NH; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  // partial[blockIdx.x][cc][tap * CF + cf]
+  float* out = partial + (long)blockIdx.x * CC * 16 * CF;
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int b = 0; b < 2 * NH; ++b) {
+      const int tap = 2 * wave + b / NH, cf = 16 * (b % NH) + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(long)(16 * a + 4 * q + r) * (16 * CF) + tap * CF + cf] = acc[a][b][r];
+    }
+}
+
+// dw[cc][cf][ky][kx] += sum_g partial[g][cc][(ky, kx, cf)]
+__global__ __launch_bounds__(256) void conv_wgrad_tile_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                     int G, int CC, int CF) {
+  const int total = CC * 16 * CF;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int g = 0;
+  for (; g + 3 < G; g += 4) {
+    s0 += partial[(long)g * total + e];
+    s1 += partial[(long)(g + 1) * total + e];
+    s2 += partial[(long)(g + 2) * total + e];
+    s3 += partial[(long)(g + 3) * total + e];
+  }
+  for (; g < G; ++g) s0 += partial[(long)g * total + e];
+  const int cf = e % CF, tap = (e / CF) % 16, cc = e / (16 * CF);
+  dw[(((long)cc * CF + cf) * 4 + (tap >> 2)) * 4 + (tap & 3)] += (s0 + s1) + (s2 + s3);
+}
+
 using C128 = TileShape<2, 2, 2, 2, 16>;    // 128 x 128
 using C128K32 = TileShape<2, 2, 2, 2, 32>;  // 128 x 128, BK 32 (twice the loads in flight per barrier)
 using C64 = TileShape<2, 2, 1, 1, 32>;     // 64 x 64
@@ -1153,6 +1484,137 @@ __global__ __launch_bounds__(256) void conv_s2_l16_kernel(ConvParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Narrow transposed convolution, one 16 x 16 INPUT-pixel tile of one image per workgroup, all four parity classes:
+// the decoder layer in front of the image layer (64 -> 32 channels at 16 x 16 -> 32 x 32) and the encoder's second
+// layer read backwards.  With 32 output channels the register-direct kernel above re-reads every gathered input
+// element and the whole 32 KB weight image per wave from L1 / L2 (8 flop per cache byte: 63 TFLOP/s, 45 % MFMA-busy).
+// Here the tile and its one-pixel halo (18 x 18 x Ci floats, channel-contiguous, row stride Ci + 8: the
+// ds_read_b128 fragment reads of 16 pixels x 4 k-quads cover the 64 banks evenly) are staged in LDS ONCE and serve the
+// 4 taps x 4 classes = 16 gathers of every pixel; a class's weights [32][4 Ci] (stride 4 Ci + 8) sit beside it, the
+// next class's are prefetched into registers while the current class multiplies.  A wave owns 2 input rows (2 x 16
+// pixels) x 32 channels: per 16-k chunk 2 + 2 ds_read_b128 feed 16 v_mfma_f32_16x16x4_f32.  ~80 flop per byte
+// entering the CU.  CI = 16 .. 64 (multiple of 16), Co <= 32; IH, IW multiples of 16.
+// grid = Nimg * (IH / 16) * (IW / 16) workgroups of 8 waves (two per SIMD: one wave's LDS waits and stores are covered
+// by the other's MFMAs; the LDS footprint allows one workgroup per CU).
+// ------------------------------------------------------------------------------------------------
+template <int CI>
+__global__ __launch_bounds__(512) void convT_s2_tile_kernel(ConvParams p) {
+  constexpr int NT = 512, RPW = 2;  // 8 waves (two per SIMD), 2 input rows each
+  constexpr int LDX = CI + 8, K = 4 * CI, LDW = K + 8, NCH = CI / 16;
+  constexpr int XV = 18 * 18 * (CI / 4);     // float4 of the input tile
+  constexpr int XJ = (XV + NT - 1) / NT;     // ... per thread
+  constexpr int WV = 32 * (K / 4) / NT;      // float4 of one class's weights per thread
+  extern __shared__ __attribute__((aligned(16))) float tlds[];
+  float* xs = tlds;                  // [18 * 18][LDX]
+  float* ws = tlds + 18 * 18 * LDX;  // [32][LDW]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int tx_n = p.W / 16, ty_n = p.H / 16;
+  const int img = blockIdx.x / (tx_n * ty_n), trem = blockIdx.x % (tx_n * ty_n);
+  const int ty = trem / tx_n, tx = trem % tx_n;
+  const float* xin = p.x + (long)img * p.H * p.W * CI;
+  // weights of class `cls` for this thread: float4 f = tid + NT j -> channel f / (K / 4), k offset 4 (f % (K / 4));
+  // channels >= Co read channel 0 (their outputs are never stored)
+  f32x4 wr[WV];
+  auto wload = [&](int cls) {
+#pragma unroll
+    for (int j = 0; j < WV; ++j) {
+      const int f = tid + NT * j;
+      const int co = f / (K / 4), k4 = (f % (K / 4)) * 4;
+      wr[j] = *reinterpret_cast<const f32x4u*>(p.wp + ((long)cls * p.Co + (co < p.Co ? co : 0)) * K + k4);
+    }
+  };
+  auto wstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < WV; ++j) {
+      const int f = tid + NT * j;
+      *reinterpret_cast<f32x4*>(&ws[(f / (K / 4)) * LDW + (f % (K / 4)) * 4]) = wr[j];
+    }
+  };
+  wload(0);
+  // ---- stage the input tile + halo (zero outside the image): every load of the thread in flight before the first
+  // LDS write (a load-store-load-store loop pays the memory latency XJ times)
+  {
+    f32x4 xv[XJ];
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int f = tid + NT * j;
+      const int pix = f / (CI / 4), c4 = (f % (CI / 4)) * 4;
+      const int ly = pix / 18, lx = pix % 18;
+      const int gy = ty * 16 + ly - 1, gx = tx * 16 + lx - 1;
+      const bool ok = f < XV && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      xv[j] = *reinterpret_cast<const f32x4u*>(xin + ((long)(ok ? gy : 0) * p.W + (ok ? gx : 0)) * CI + c4);
+      if (!ok) xv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int f = tid + NT * j;
+      if (f < XV) *reinterpret_cast<f32x4*>(&xs[(f / (CI / 4)) * LDX + (f % (CI / 4)) * 4]) = xv[j];
+    }
+  }
+  wstore();
+  __syncthreads();
+  const int OH = 2 * p.H, OW = 2 * p.W;
+  const float bias0 = (p.bias && i < p.Co) ? p.bias[i] : 0.f;
+  const float bias1 = (p.bias && 16 + i < p.Co) ? p.bias[16 + i] : 0.f;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int py = cls >> 1, px = cls & 1;
+    if (cls < 3) wload(cls + 1);  // in flight while this class multiplies
+    f32x4 acc[RPW][2];
+#pragma unroll
+    for (int a = 0; a < RPW; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+      const int ta = tap >> 1, tb = tap & 1;
+      // input pixel of (row y = RPW wave + a, x = i): (y + py - ta, x + px - tb), + 1 for the halo
+      const int xoff = ((RPW * wave + py - ta + 1) * 18 + (i + px - tb + 1)) * LDX + 4 * q;
+      const int woff = i * LDW + tap * CI + 4 * q;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        f32x4 af[RPW], bf[2];
+#pragma unroll
+        for (int a = 0; a < RPW; ++a) af[a] = *reinterpret_cast<const f32x4*>(&xs[xoff + a * 18 * LDX + 16 * c]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const f32x4*>(&ws[woff + 16 * b * LDW + 16 * c]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int a = 0; a < RPW; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a][g], bf[b][g], acc[a][b], 0, 0, 0);
+      }
+    }
+    // acc[a][b][r]: input pixel (y = RPW wave + a, x = 4 q + r), channel 16 b + i -> output pixel (2 y + py, 2 x + px)
+#pragma unroll
+    for (int a = 0; a < RPW; ++a) {
+      const int oy = 2 * (ty * 16 + RPW * wave + a) + py;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ox = 2 * (tx * 16 + 4 * q + r) + px;
+        float* orow = p.y + (((long)img * OH + oy) * OW + ox) * p.Co;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int co = 16 * b + i;
+          if (co < p.Co) {
+            const float val = acc[a][b][r] + (b ? bias1 : bias0) + p.out_add;
+            orow[co] = p.accumulate ? (orow[co] + val) : val;
+          }
+        }
+      }
+    }
+    if (cls < 3) {
+      __syncthreads();  // every wave is done with this class's weights
+      wstore();
+      __syncthreads();
+    }
+  }
+}
+
+
 // Explicit im2col of Conv2d k4 s2 "same" (networks.py:771-798) for few-image batches -- the acting step (SURVEY
 // 8(f) N1) runs the encoder on 1-16 images, where the tiled implicit-GEMM kernels have 1-16 workgroups walking the
 // whole reduction (30-77 us per layer at one image); cols [N*OH*OW][(ci,ky,kx)] is in the reference weight's own
@@ -1249,6 +1711,24 @@ extern "C" int dv3_convT_s2_fwd(const float* x, const float* w_packed, const flo
     p.tiles_n = (Co + TS::BN - 1) / TS::BN;
     hipLaunchKernelGGL((convT_s2_kernel<TS>), dim3(p.tiles_m * p.tiles_n, 4), dim3(kThreads), 0, s, p);
   };
+  static const int env_tile = DV3_ENV_INT("DV3_CONVT_TILE", 1);
+  if (env_tile && Co <= 32 && (Ci == 16 || Ci == 32 || Ci == 48 || Ci == 64) && (IH % 16) == 0 && (IW % 16) == 0) {
+    // one 16 x 16 input tile per workgroup, all four classes (measured, 1024 frames 64 -> 32: see DESIGN.md)
+    const dim3 grid((unsigned)((long)Nimg * (IH / 16) * (IW / 16)));
+    const size_t lds = (size_t)(18 * 18 * (Ci + 8) + 32 * (4 * Ci + 8)) * sizeof(float);
+#define DV3_CT(CI_)                                                                                              \
+  {                                                                                                              \
+    static bool attr = false;                                                                                    \
+    if (!attr) {                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)convT_s2_tile_kernel<CI_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr = true;                                                                                               \
+    }                                                                                                            \
+    hipLaunchKernelGGL((convT_s2_tile_kernel<CI_>), grid, dim3(512), lds, s, p);                                  \
+  }
+    if (Ci == 16) DV3_CT(16) else if (Ci == 32) DV3_CT(32) else if (Ci == 48) DV3_CT(48) else DV3_CT(64)
+#undef DV3_CT
+    return (int)hipGetLastError();
+  }
   static const int env_l16 = DV3_ENV_INT("DV3_CONVT_L16", 1);
   // measured (tools/conv_bench.py, 1024 frames, us): Co 32: direct 247 / l16 278; Co 64: 195 / 195; Co 128: 183 / 178 --
   // the register-direct kernels keep the narrow layers, the LDS tile takes Co >= 128 (and everything wider, which
@@ -1292,6 +1772,24 @@ extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* 
   if (!coarse || !fine || !dw || !dw_packed || Cfine <= 0 || Ccoarse <= 0 || !pow2_spatial(H, W)) return DV3_ERR_ARG;
   const long rows = (long)Nimg * (H / 2) * (W / 2);
   if (rows > 0x7fffffffL - 4096) return DV3_ERR_ARG;
+  static const int env_c3w = DV3_ENV_INT("DV3_C3W_TILE", 1);
+  if (env_c3w && Cfine == 3 && (Ccoarse == 32 || Ccoarse == 96) && ((H / 2) % 16) == 0 && ((W / 2) % 16) == 0) {
+    // image-side layers: tile walk with the accumulators in registers, straight into dw (reference layout)
+    const long tiles = (long)Nimg * (H / 32) * (W / 32);
+    const size_t lds = (size_t)(256 * (Ccoarse + 16) + 34 * 34 * 3) * sizeof(float);
+    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
+    if (Ccoarse == 32) {
+      hipLaunchKernelGGL((conv_wgrad_c3_kernel<32>), dim3(grid), dim3(256), lds, (hipStream_t)stream, coarse, fine, dw, Nimg, H, W);
+    } else {
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_c3_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+      }
+      hipLaunchKernelGGL((conv_wgrad_c3_kernel<96>), dim3(grid), dim3(256), lds, (hipStream_t)stream, coarse, fine, dw, Nimg, H, W);
+    }
+    return (int)hipGetLastError();
+  }
   WgradParams p{coarse, fine, dw_packed, Nimg, H, W, Cfine, Ccoarse, 0, 0, 0, 0, 0};
   static const int env_group = DV3_ENV_INT("DV3_WGRAD_XCD", 1);
   auto go = [&](auto ts, long target_wgs) {
@@ -1339,6 +1837,32 @@ extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* 
   return (int)hipGetLastError();
 }
 
+// Narrow layers (Cfine 32, Ccoarse 64): tile walk with the whole gradient in one workgroup's accumulators, two-stage
+// reduction through `partial` (dv3_conv_s2_wgrad_tile_scratch floats).  Returns DV3_ERR_ARG for other shapes.
+extern "C" int dv3_conv_s2_wgrad_tile_scratch(int Nimg, int H, int W, int Cfine, int Ccoarse) {
+  if (Cfine != 32 || Ccoarse != 64 || H <= 0 || W <= 0 || (H % 16) != 0 || (W % 16) != 0 || Nimg <= 0) return 0;
+  const long tiles = (long)Nimg * (H / 16) * (W / 16);
+  return (int)((tiles < 256 ? tiles : 256) * (long)Ccoarse * 16 * Cfine);
+}
+extern "C" int dv3_conv_s2_wgrad_tile(const float* coarse, const float* fine, float* partial, float* dw, int Nimg, int H,
+                                      int W, int Cfine, int Ccoarse, void* stream) {
+  if (Nimg <= 0) return 0;
+  if (!coarse || !fine || !partial || !dw || dv3_conv_s2_wgrad_tile_scratch(Nimg, H, W, Cfine, Ccoarse) == 0)
+    return DV3_ERR_ARG;
+  const long tiles = (long)Nimg * (H / 16) * (W / 16);
+  const int G = (int)(tiles < 256 ? tiles : 256);
+  const size_t lds = (size_t)(64 * (64 + 16) + 18 * 18 * (32 + 8)) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_tile_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((conv_wgrad_tile_kernel<32, 64>), dim3(G), dim3(512), lds, s, coarse, fine, partial, Nimg, H, W);
+  hipLaunchKernelGGL(conv_wgrad_tile_reduce_kernel, dim3((64 * 16 * 32 + 255) / 256), dim3(256), 0, s, partial, dw, G, 64, 32);
+  return (int)hipGetLastError();
+}
+
 // Specialised image-side layers (3 channels on one side).  Weights in the REFERENCE layout (no packing):
 // conv: Conv2d weight [CW][3][4][4];  convT: ConvTranspose2d weight [CW][3][4][4] (in = CW, out = 3).
 extern "C" int dv3_conv_s2_c3_fwd(const float* x, const float* w, float* y, int Nimg, int H, int W, int CW,
@@ -1369,6 +1893,13 @@ extern "C" int dv3_convT_s2_c3_fwd(const float* x, const float* w, const float* 
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 16384) blocks = 16384;
   hipStream_t s = (hipStream_t)stream;
+  static const int env_c3t = DV3_ENV_INT("DV3_C3T_MFMA", 1);
+  if (env_c3t && (IH % 16) == 0 && (IW % 16) == 0 && (CW == 32 || CW == 96)) {
+    const dim3 grid((unsigned)((long)Nimg * (IH / 16) * (IW / 16)));
+    if (CW == 32) hipLaunchKernelGGL((convT_s2_c3_mfma_kernel<32>), grid, dim3(256), 0, s, x, w, bias, out_add, y, Nimg, IH, IW, accumulate);
+    else hipLaunchKernelGGL((convT_s2_c3_mfma_kernel<96>), grid, dim3(256), 0, s, x, w, bias, out_add, y, Nimg, IH, IW, accumulate);
+    return (int)hipGetLastError();
+  }
   if (CW == 32) hipLaunchKernelGGL((convT_s2_c3_kernel<32>), dim3(blocks), dim3(256), 0, s, x, w, bias, out_add, y, Nimg, IH, IW, accumulate);
   else if (CW == 96) hipLaunchKernelGGL((convT_s2_c3_kernel<96>), dim3(blocks), dim3(256), 0, s, x, w, bias, out_add, y, Nimg, IH, IW, accumulate);
   else return DV3_ERR_ARG;

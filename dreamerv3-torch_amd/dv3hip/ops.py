@@ -903,6 +903,7 @@ def convT_s2_fwd(x, wp, y, *, Ci, Co, bias=None, out_add=0.0, accumulate=False):
 
 
 _WGRAD_SCRATCH = {}
+_WGRAD_TILE = _dev.flag("DV3_WGRAD_TILE", True)
 
 
 def conv_s2_wgrad(coarse, fine, dw):
@@ -914,6 +915,19 @@ def conv_s2_wgrad(coarse, fine, dw):
     Cc = coarse.shape[3]
     if coarse.shape[0] != N or coarse.shape[1] * 2 != H or coarse.shape[2] * 2 != W or dw.numel() != 16 * Cc * Cf:
         raise ValueError("wgrad shapes mismatch")
+    flops = 2.0 * N * (H // 2) * (W // 2) * 16 * Cf * Cc
+    n_part = _lib.load().dv3_conv_s2_wgrad_tile_scratch(N, H, W, Cf, Cc) if _WGRAD_TILE else 0
+    if n_part > 0:
+        # narrow layer pair next to the image layers: tile walk + two-stage reduction (csrc/conv.hip)
+        key = ("tile", str(dw.device), n_part, _stream())  # per launch stream: graph branches must not share it
+        part = _WGRAD_SCRATCH.get(key)
+        if part is None:
+            part = torch.empty(n_part, dtype=F32, device=dw.device)
+            _WGRAD_SCRATCH[key] = part
+        _call("dv3_conv_s2_wgrad_tile", _ptr(coarse), _ptr(fine), _ptr(part), _ptr(dw), N, H, W, Cf, Cc, _stream(),
+              key="conv_wgrad_kernel<tile64x512>" + (f"[N{N} {H}x{W} Cf{Cf} Cc{Cc}]" if PROFILE.by_shape else ""),
+              flops=flops, nbytes=4.0 * (coarse.numel() + fine.numel() + dw.numel()))
+        return dw
     key = (str(dw.device), dw.data_ptr())  # one zero-initialised packed scratch per weight tensor
     scratch = _WGRAD_SCRATCH.get(key)
     if scratch is None or scratch.numel() != dw.numel():

@@ -211,6 +211,13 @@ int dv3_conv_s2_fwd(const float* x, const float* w_packed, float* y, int Nimg, i
                     int accumulate, void* stream);
 int dv3_convT_s2_fwd(const float* x, const float* w_packed, const float* bias, float out_add, float* y, int Nimg,
                      int IH, int IW, int Ci, int Co, int accumulate, void* stream);
+/* dv3_conv_s2_wgrad_tile: the same weight gradient for the narrow layer pair next to the image layers (Cfine 32,
+ * Ccoarse 64; H, W multiples of 16): a workgroup walks 8 x 8 coarse-pixel tiles with the whole [64][16 x 32] gradient in
+ * its accumulators; per-workgroup partial sums go to `partial` (dv3_conv_s2_wgrad_tile_scratch(...) floats; 0 = shape
+ * not supported) and a second launch adds them into dw.  dv3_conv_s2_wgrad remains the general entry point. */
+int dv3_conv_s2_wgrad_tile_scratch(int Nimg, int H, int W, int Cfine, int Ccoarse);
+int dv3_conv_s2_wgrad_tile(const float* coarse, const float* fine, float* partial, float* dw, int Nimg, int H, int W,
+                           int Cfine, int Ccoarse, void* stream);
 int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* dw_packed, float* dw, int Nimg, int H, int W,
                       int Cfine, int Ccoarse, void* stream);
 /* dw_packed: caller-owned scratch of Ccoarse*16*Cfine floats that must be ZERO on entry; partial sums land there

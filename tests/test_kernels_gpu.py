@@ -670,6 +670,7 @@ def test_adam_clip_matches_oracle(ops):
 CONV_CASES = [(4, 64, 64, 3, 32), (3, 32, 32, 32, 64), (2, 16, 16, 64, 128), (5, 8, 8, 128, 256),
               (3, 64, 64, 3, 2), (3, 32, 32, 2, 4), (2, 8, 8, 8, 16), (1, 4, 4, 6, 5),
               (2, 64, 64, 3, 32), (5, 2, 2, 3, 32), (2, 4, 4, 3, 96), (33, 8, 8, 3, 40),  # image-side wgrad path
+              (2, 64, 96, 3, 96), (3, 32, 64, 3, 32),  # ... its tile-walk kernel: several tiles, non-square, width 96
               (2, 16, 16, 96, 192), (3, 8, 8, 64, 160), (1, 4, 4, 32, 72)]  # k-contiguous LDS tile path, crafter widths / ragged Co
 
 
@@ -706,7 +707,10 @@ def test_conv_s2_fwd_dgrad_wgrad(ops, N, H, W, Ci, Co):
 
 @pytest.mark.parametrize("N,H,W,Ci,Co", [(4, 4, 4, 256, 128), (3, 8, 8, 128, 64), (2, 16, 16, 64, 32),
                                          (3, 32, 32, 32, 3), (2, 4, 4, 16, 8), (2, 32, 32, 2, 3),
-                                         (2, 4, 4, 384, 192), (3, 4, 4, 64, 160), (1, 8, 8, 32, 256)])
+                                         (2, 4, 4, 384, 192), (3, 4, 4, 64, 160), (1, 8, 8, 32, 256),
+                                         # the 16 x 16 input-tile kernel (Co <= 32, Ci in 16..64): several tiles per image
+                                         # (halo across tile edges), ragged channel counts, non-square
+                                         (2, 32, 32, 64, 32), (3, 16, 48, 32, 24), (1, 32, 16, 48, 7), (5, 16, 16, 16, 32)])
 def test_convT_s2_fwd_dgrad_wgrad(ops, N, H, W, Ci, Co):
     """Decoder layer: ConvTranspose2d(k4,s2,p1) + bias + 0.5, its input gradient (= conv with the
     same weight) and its weight gradient."""
@@ -723,6 +727,9 @@ def test_convT_s2_fwd_dgrad_wgrad(ops, N, H, W, Ci, Co):
     y = torch.empty(N, 2 * H, 2 * W, Co).cuda()
     ops.convT_s2_fwd(xd, wpt, y, Ci=Ci, Co=Co, bias=dev(b), out_add=0.5)
     assert_close(y, nhwc(y_ref), what="convT fwd")
+    y2 = y.clone()
+    ops.convT_s2_fwd(xd, wpt, y2, Ci=Ci, Co=Co, accumulate=True)  # += the plain product
+    assert_close(y2, nhwc(2 * y_ref - 0.5 - b.view(1, -1, 1, 1)), tol=2e-4, what="convT fwd accumulate")
     # dgrad: Conv2d over dOut with the ConvTranspose2d weight read as [out=Ci][in=Co]
     wp = torch.empty(Ci, 16 * Co).cuda()
     ops.pack_conv_weight(wd, wp, transposed=False)

@@ -81,7 +81,17 @@ def main():
             M, Nn, K = N * (H // 2) ** 2, Cf, 4 * Cc
             du, dt = dense(M * 4, Nn, K)
             print(f"convT_s2 {H // 2:2d}x{H // 2:<2d} {Cc:3d}->{Cf:<3d} (x4 cls) {M:8d} {Nn:5d} {K:5d} {us:8.1f} {flops / us / 1e6:7.1f} | {du:8.1f} {dt:7.1f}")
-        if args.only and args.only not in "conv_wgrad":
+        if Cf == 3 and (not args.only or args.only in "conv_s2 convT_s2 c3") and Cc in ops.C3_WIDTHS:
+            # the 3-channel image layers: encoder conv 3 -> d, decoder convT d -> 3 (weights in the reference layout)
+            y = torch.empty_like(coarse)
+            us = graph_us(lambda: ops.conv_s2_c3_fwd(fine, w, y, CW=Cc), args.reps)
+            gb = 4.0 * (fine.numel() + coarse.numel()) / 1e9
+            print(f"conv_s2_c3  {H:2d}x{H:<2d} 3->{Cc:<3d}     {N * (H // 2) ** 2:8d} {Cc:5d} {48:5d} {us:8.1f} {flops / us / 1e6:7.1f} | {gb / us * 1e6:6.0f} GB/s")
+            wt = r(Cc, 3, 4, 4)
+            yo = torch.empty(N, H, H, 3, device="cuda")
+            us = graph_us(lambda: ops.convT_s2_c3_fwd(coarse, wt, yo, CW=Cc, out_add=0.5), args.reps)
+            print(f"convT_s2_c3 {H // 2:2d}x{H // 2:<2d} {Cc:3d}->3      {N * (H // 2) ** 2:8d} {3:5d} {4 * Cc:5d} {us:8.1f} {flops / us / 1e6:7.1f} | {gb / us * 1e6:6.0f} GB/s")
+        if args.only and args.only not in "conv_wgrad" and not (args.only == "c3" and Cf == 3):
             continue
         dw = torch.zeros(Cc, Cf, 4, 4, device="cuda")
         us = graph_us(lambda: ops.conv_s2_wgrad(coarse, fine, dw), args.reps)
