@@ -122,6 +122,11 @@ def kernel_symbol(key: str) -> str:
                     17: "void dv3::gemm_l16_kernel<64, 128, 1, 0>(dv3::GemmParams)"}.get(
                         tile, "void dv3::gemm_l16_kernel<32, 64, 1, 0>(dv3::GemmParams)")
         return f"void dv3::gemm_kernel<dv3::TileShape<{_TILE_TEMPLATES[tile]}>, {ta}, {tb}>(dv3::GemmParams)"
+    if key.startswith("conv_wgrad_tile_kernel"):
+        return "void dv3::conv_wgrad_tile_kernel<32, 64>(float const*, float const*, float*, int, int, int)"
+    m = re.match(r"conv_wgrad_c3_kernel<(\d+)>", key)
+    if m:
+        return f"void dv3::conv_wgrad_c3_kernel<{m.group(1)}>(float const*, float const*, float*, int, int, int)"
     m = re.match(r"conv_wgrad_kernel<([^,>]+)(,c3)?>", key)
     if m:
         tile = {v: k for k, v in _TILE_NAMES.items()}[m.group(1)]
@@ -925,7 +930,7 @@ def conv_s2_wgrad(coarse, fine, dw):
             part = torch.empty(n_part, dtype=F32, device=dw.device)
             _WGRAD_SCRATCH[key] = part
         _call("dv3_conv_s2_wgrad_tile", _ptr(coarse), _ptr(fine), _ptr(part), _ptr(dw), N, H, W, Cf, Cc, _stream(),
-              key="conv_wgrad_kernel<tile64x512>" + (f"[N{N} {H}x{W} Cf{Cf} Cc{Cc}]" if PROFILE.by_shape else ""),
+              key="conv_wgrad_tile_kernel<32,64>" + (f"[N{N} {H}x{W} Cf{Cf} Cc{Cc}]" if PROFILE.by_shape else ""),
               flops=flops, nbytes=4.0 * (coarse.numel() + fine.numel() + dw.numel()))
         return dw
     key = (str(dw.device), dw.data_ptr())  # one zero-initialised packed scratch per weight tensor
@@ -933,9 +938,12 @@ def conv_s2_wgrad(coarse, fine, dw):
     if scratch is None or scratch.numel() != dw.numel():
         scratch = torch.zeros(dw.numel(), dtype=F32, device=dw.device)
         _WGRAD_SCRATCH[key] = scratch
+    c3_tile = Cf == 3 and Cc in (32, 96) and (H // 2) % 16 == 0 and (W // 2) % 16 == 0  # csrc/conv.hip dv3_conv_s2_wgrad
+    name = (f"conv_wgrad_c3_kernel<{Cc}>" if c3_tile else
+            f"conv_wgrad_kernel<{'128x128x16' if Cc >= 128 else '32x64x64s2' if Cc <= 32 else '64x64x32'}"
+            f"{',c3' if Cf == 3 else ''}>")
     _call("dv3_conv_s2_wgrad", _ptr(coarse), _ptr(fine), _ptr(scratch), _ptr(dw), N, H, W, Cf, Cc, _stream(),
-          key=f"conv_wgrad_kernel<{'128x128x16' if Cc >= 128 else '32x64x64s2' if Cc <= 32 else '64x64x32'}"
-              f"{',c3' if Cf == 3 else ''}>" + (f"[N{N} {H}x{W} Cf{Cf} Cc{Cc}]" if PROFILE.by_shape else ""),
+          key=name + (f"[N{N} {H}x{W} Cf{Cf} Cc{Cc}]" if PROFILE.by_shape else ""),
           flops=2.0 * N * (H // 2) * (W // 2) * 16 * Cf * Cc,
           nbytes=4.0 * (coarse.numel() + fine.numel() + dw.numel()))
     return dw

@@ -201,7 +201,8 @@ def test_dev_switch_variants():
     dev_lib = os.path.join(repo, "dreamerv3-torch_amd", "dv3hip", "libdv3hip_dev.so")
     assert os.path.exists(dev_lib), "run __graft_entry__.build() (builds libdv3hip_dev.so as well)"
     off = dict(DV3_FUSED_IMAG="0", DV3_GATHER_OBS="0", DV3_FUSE_BLEND="0", DV3_FUSE_SAMPLE="0", DV3_FUSE_SAMPLE_IN="0",
-               DV3_FUSE_CARRY="0", DV3_FUSE_SCAN_ROW="0", DV3_STACK_DETER="0", DV3_C3_MFMA="0", DV3_CONV_L16="0", DV3_CONVT_L16="0",
+               DV3_FUSE_CARRY="0", DV3_FUSE_SCAN_ROW="0", DV3_STACK_DETER="0", DV3_C3_MFMA="0", DV3_CONV_L16="0", DV3_CONVT_L16="0", DV3_CONVT_TILE="0",
+               DV3_C3T_MFMA="0", DV3_C3W_TILE="0", DV3_WGRAD_TILE="0",
                DV3_SIDE_STREAM="1")
     probe = ("import sys; sys.path[:0] = [%r, %r]; from dv3hip import _dev, engine; import models; "
              "print(int(_dev.enabled()), int(engine._GATHER_OBS), int(models._FUSED_IMAG))"

@@ -4,7 +4,7 @@ TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --also none"
+CMD="python3 bench.py --plain --steps 6 --warmup 2"  # update replays only: every traced launch belongs to an update
 # counter passes run for minutes without output: keep gpurun's silence watchdog fed
 ( while true; do date >> $OUT/heartbeat.log; sleep 45; done ) &
 HB=$!
