@@ -305,6 +305,175 @@ __global__ __launch_bounds__(64 * kScanWaves) void scan_lnbwd_gemm_kernel(ScanLn
   scan_tile64_out(acc, red, rb, n0, p.M, p.C, p.ldc);
 }
 
+// GRU cell backward in the prologue of the data-gradient GEMM of its Linear (networks.py:760-768 reversed;
+// = gru_bwd_vec_kernel + gemm_skinny_nn64_kernel).  Everything transcendental in the cell's backward depends on forward
+// data only, so it is computed for all T*B rows at once in front of the reverse scan (scan_gru_factors_kernel):
+//   dy_k = g_j A_k  for the three gate parts k = (r, c, u) x j,   dh_direct = g_j Ah_j,
+//   the LayerNorm row sums collapse to two dot products over the hidden units: s1 = g . P1 / N, s2 = g . P2 / N
+// (P1_j = sum_parts A gamma, P2_j = sum_parts A gamma xhat).  The per-step prologue reads g, P1, P2 of the 16 rows
+// (3 De floats per row instead of the 3 De pre-activations + De state + their 3 transcendentals per unit) and the
+// factors of its own K slice.
+struct ScanGruBwdParams {
+  const float* g;  // [M, De] gradient on the new deter
+  long ldg;
+  const float* xh;  // [M, 3 De] xhat of the LayerNorm           }
+  const float* af;  // [M, 3 De] A_k                              } scan_gru_factors_kernel
+  const float* p1;  // [M, De]                                    }
+  const float* p2;
+  const float* ah;     // [M, De] 1 - update gate
+  const float* gamma;  // [3 De]
+  const float* rstd;   // [M]
+  float* dp;           // [M, 3 De] gradient on the GEMM output of the forward pass (saved: weight gradient after the scan)
+  float* dh;           // [M, De] (ld) += g Ah (atomic: the GEMM below accumulates onto the same buffer)
+  long lddh;
+  float* dgamma;  // [3 De] accumulated (optional)
+  float* dbeta;
+  const float* W;  // [3 De, >= N]
+  long ldb;
+  float* C;  // [M, N]  C += dp W (atomic)
+  long ldc;
+  int M, De, N;
+};
+
+__global__ __launch_bounds__(256) void scan_gru_factors_kernel(const float* __restrict__ p, long ldp,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ h, long ldh,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ xh,
+                                                               float* __restrict__ af, float* __restrict__ p1,
+                                                               float* __restrict__ p2, float* __restrict__ ah, long R,
+                                                               int De) {
+  const long total = R * De;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / De;
+    const int j = (int)(e % De);
+    const float mu = mean[r], rs = rstd[r];
+    const float* pr = p + r * ldp;
+    const float xr = (pr[j] - mu) * rs, xc = (pr[De + j] - mu) * rs, xu = (pr[2 * De + j] - mu) * rs;
+    const float gr = gamma[j], gc = gamma[De + j], gu = gamma[2 * De + j];
+    const float yr = xr * gr + beta[j], yc = xc * gc + beta[De + j], yu = xu * gu + beta[2 * De + j];
+    const float rg = sigmoidf_(yr);
+    const float cg = tanhf(rg * yc);
+    const float ug = sigmoidf_(yu - 1.f);
+    const float drc = ug * (1.f - cg * cg);
+    const float a_r = drc * yc * rg * (1.f - rg), a_c = drc * rg, a_u = (cg - h[r * ldh + j]) * ug * (1.f - ug);
+    float* xo = xh + r * 3 * De;
+    float* ao = af + r * 3 * De;
+    xo[j] = xr; xo[De + j] = xc; xo[2 * De + j] = xu;
+    ao[j] = a_r; ao[De + j] = a_c; ao[2 * De + j] = a_u;
+    p1[e] = a_r * gr + a_c * gc + a_u * gu;
+    p2[e] = a_r * gr * xr + a_c * gc * xc + a_u * gu * xu;
+    ah[e] = 1.f - ug;
+  }
+}
+
+// grid (N / 64, 3 De / (16 * 8 * CH), ceil(M / 16)), 512 threads: a workgroup owns 8 CH 16-k chunks, CH per wave.
+template <int NVD, int CH>  // De = 256 NVD
+__global__ __launch_bounds__(64 * kScanWaves) void scan_grubwd_gemm_kernel(ScanGruBwdParams p) {
+  __shared__ float red[kScanWaves][4][257];
+  __shared__ float sst[2][16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 64, rb = blockIdx.z * 16;
+  const int De = p.De;
+  const int row = rb + i;
+  const bool rowok = row < p.M;
+  const int rr0 = rowok ? row : 0;
+  const float rstd = p.rstd[rr0];
+  // this wave's chunks: everything in flight before the row-sum pass waits
+  f32x4 b[CH][4], gq[CH], afq[CH], xhq[CH], gam[CH], ahq[CH];
+  int kk[CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) {
+    const int k = (((blockIdx.y * kScanWaves + wave) * CH + u) << 4) + 4 * q;
+    kk[u] = k;
+    const int part = k / De, j = k - part * De;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b[u][g] = *reinterpret_cast<const f32x4u*>(p.W + (long)(k + g) * p.ldb + n0 + 4 * i);
+    gq[u] = *reinterpret_cast<const f32x4u*>(p.g + (long)rr0 * p.ldg + j);
+    afq[u] = *reinterpret_cast<const f32x4u*>(p.af + (long)rr0 * 3 * De + k);
+    xhq[u] = *reinterpret_cast<const f32x4u*>(p.xh + (long)rr0 * 3 * De + k);
+    gam[u] = *reinterpret_cast<const f32x4u*>(p.gamma + k);
+    ahq[u] = *reinterpret_cast<const f32x4u*>(p.ah + (long)rr0 * De + j);
+  }
+  // row sums of rows 2 wave, 2 wave + 1: two dot products over the hidden units
+  const float inv_n = 1.f / (float)(3 * De);
+  {
+    f32x4 g2[2][NVD], a2[2][NVD], c2[2][NVD];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = min(rb + 2 * wave + rr, p.M - 1);
+#pragma unroll
+      for (int v = 0; v < NVD; ++v) {
+        const int c = 4 * (lane + 64 * v);
+        g2[rr][v] = *reinterpret_cast<const f32x4u*>(p.g + (long)r * p.ldg + c);
+        a2[rr][v] = *reinterpret_cast<const f32x4u*>(p.p1 + (long)r * De + c);
+        c2[rr][v] = *reinterpret_cast<const f32x4u*>(p.p2 + (long)r * De + c);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int v = 0; v < NVD; ++v) {
+        s1 += hsum4(g2[rr][v] * a2[rr][v]);
+        s2 += hsum4(g2[rr][v] * c2[rr][v]);
+      }
+      s1 = group_sum<64>(s1) * inv_n;
+      s2 = group_sum<64>(s2) * inv_n;
+      if (lane == 0) {
+        sst[0][2 * wave + rr] = s1;
+        sst[1][2 * wave + rr] = s2;
+      }
+    }
+  }
+  __syncthreads();
+  const float s1 = sst[0][rowok ? i : 0], s2 = sst[1][rowok ? i : 0];
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < CH; ++u) {
+    const int k = kk[u];
+    const f32x4 dz = rowok ? gq[u] * afq[u] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 dxh = dz * gam[u];
+    f32x4 d = (dxh - s1 - xhq[u] * s2) * rstd;
+    if (!rowok) d = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (blockIdx.x == 0) {
+      if (rowok) {
+        *reinterpret_cast<f32x4u*>(p.dp + (long)row * 3 * De + k) = d;
+        if (k < De) {  // the direct path of the state: dh += g (1 - u), once per hidden unit (the r-gate chunks)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(p.dh + (long)row * p.lddh + k + e, gq[u][e] * ahq[u][e]);
+        }
+      }
+      if (p.dgamma) {  // column sums over the 16 rows of the block
+        f32x4 pg = dz * xhq[u], pb = dz;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            pg[e] += __shfl_xor(pg[e], o, 64);
+            pb[e] += __shfl_xor(pb[e], o, 64);
+          }
+        if (i == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            atomicAdd(p.dgamma + k + e, pg[e]);
+            atomicAdd(p.dbeta + k + e, pb[e]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[g], b[u][g][j], acc[j], 0, 0, 0);
+  }
+  scan_tile64_out(acc, red, rb, n0, p.M, p.C, p.ldc);
+}
+
 struct ScanCarryParams {
   const float* dsin;  // [B, SD] gradient on the NEXT step's blended stoch input (null: no carry, last step)
   long ld_dsin;
@@ -494,5 +663,44 @@ extern "C" int dv3_scan_carry_st_gemm(const float* dsin, long ld_dsin, const flo
                     C, ldc, B, S, De, N, unimix, tiles};
   const dim3 grid(tiles + (int)nb_d, S / kScanWaves, (B + 15) / 16), block(64 * kScanWaves);
   hipLaunchKernelGGL(scan_carry_st_gemm_kernel, grid, block, 0, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_scan_gru_factors(const float* p, long ldp, const float* gamma, const float* beta, const float* h,
+                                    long ldh, const float* mean, const float* rstd, float* xhat, float* afac, float* p1,
+                                    float* p2, float* ah, long R, int De, void* stream) {
+  if (R <= 0) return 0;
+  if (!p || !gamma || !beta || !h || !mean || !rstd || !xhat || !afac || !p1 || !p2 || !ah || De <= 0 || ldp < 3 * De ||
+      ldh < De)
+    return DV3_ERR_ARG;
+  long blocks = (R * De + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scan_gru_factors_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, ldp, gamma, beta,
+                     h, ldh, mean, rstd, xhat, afac, p1, p2, ah, R, De);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_scan_grubwd_gemm(const float* g, long ldg, const float* xhat, const float* afac, const float* p1,
+                                    const float* p2, const float* ah, const float* gamma, const float* rstd, float* dp,
+                                    float* dh, long lddh, float* dgamma, float* dbeta, const float* W, long ldb, float* C,
+                                    long ldc, int M, int De, int N, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (!g || !xhat || !afac || !p1 || !p2 || !ah || !gamma || !rstd || !dp || !dh || !W || !C ||
+      ((dgamma == nullptr) != (dbeta == nullptr)))
+    return DV3_ERR_ARG;
+  if ((De != 256 && De != 512 && De != 1024) || N % 64 != 0 || ldg < De || lddh < De || ldb < N || ldc < N)
+    return DV3_ERR_ARG;
+  ScanGruBwdParams p{g, ldg, xhat, afac, p1, p2, ah, gamma, rstd, dp, dh, lddh, dgamma, dbeta, W, ldb, C, ldc, M, De, N};
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = 3 * De / 16;
+  // one 16-k chunk per wave at De 256 / 512 (6 / 12 K-splits), two at De 1024 (12): 96 .. 288 workgroups
+  if (De == 1024) {
+    const dim3 grid(N / 64, chunks / (kScanWaves * 2), (M + 15) / 16);
+    hipLaunchKernelGGL((scan_grubwd_gemm_kernel<4, 2>), grid, dim3(64 * kScanWaves), 0, s, p);
+  } else {
+    const dim3 grid(N / 64, chunks / kScanWaves, (M + 15) / 16);
+    if (De == 512) hipLaunchKernelGGL((scan_grubwd_gemm_kernel<2, 1>), grid, dim3(64 * kScanWaves), 0, s, p);
+    else hipLaunchKernelGGL((scan_grubwd_gemm_kernel<1, 1>), grid, dim3(64 * kScanWaves), 0, s, p);
+  }
   return (int)hipGetLastError();
 }

@@ -43,6 +43,7 @@ _FUSE_SCAN_ROW = _dev.flag("DV3_FUSE_SCAN_ROW", True)
 _FUSE_SCAN_LN = _dev.flag("DV3_FUSE_SCAN_LN", True)  # ... forward: obs_out LayerNorm + posterior-logit GEMM
 _FUSE_SCAN_LNBWD = _dev.flag("DV3_FUSE_SCAN_LNBWD", True)  # ... reverse: the two LayerNorm backward + data-gradient GEMMs
 _FUSE_SCAN_CS = _dev.flag("DV3_FUSE_SCAN_CS", True)  # ... reverse: carry + straight-through + logit data-gradient GEMM
+_FUSE_SCAN_GRUBWD = _dev.flag("DV3_FUSE_SCAN_GRUBWD", True)  # ... reverse: GRU cell backward + the data-gradient GEMM of its Linear
 
 
 class SideStream:
@@ -522,6 +523,16 @@ class RSSMEngine:
         # (the fused first launch re-reads its inputs from every column tile: the finished logit gradient goes to its
         # own buffer instead of in place)
         dpl_out = g("obs.dpl_out", (T, B, S, D)) if fuse_cs else dpost_logit
+        # (measured, world-model update: cfg 2 (De 512, 16 rows) 10.30 -> 10.15 ms; cfg 3 (De 1024, 32 rows) 17.19 -> 17.48:
+        # 288 workgroups x 2 row blocks each re-reading 192 KB of factors -- the wide cell keeps its own launch)
+        fuse_gru = (_FUSE_SCAN_ROW and _FUSE_SCAN_GRUBWD and B <= 32 and De <= 512
+                    and ops.scan_grubwd_gemm_ok(De, Hd + De))
+        if fuse_gru:
+            # ... and the GRU cell's backward: every transcendental factor for all steps in one launch
+            xhg, afg = g("obs.xhg", (T, B, 3 * De)), g("obs.afg", (T, B, 3 * De))
+            p1g, p2g, ahg = g("obs.p1g", (T, B, De)), g("obs.p2g", (T, B, De)), g("obs.ahg", (T, B, De))
+            ops.scan_gru_factors(v2(gpre, 3 * De), P.gru.g, P.gru.b, v2(din, De), mg.view(TB), rg.view(TB), xhg, afg, p1g,
+                                 p2g, ahg)
         if fuse_row:
             # what the two LayerNorm + SiLU backward prologues need from the forward pass, for all steps at once
             xh3, jc3 = g("obs.xh3", (T, B, Hd)), g("obs.jc3", (T, B, Hd))
@@ -547,9 +558,13 @@ class RSSMEngine:
             else:
                 dense_ln_bwd_pre(P.obs_out, dx3[t], x3pre[t], m3[t], r3[t], dx3pre[t], wgrad=True)
                 ops.gemm(dx3pre[t], P.obs_out.W[:, :De], gd_t, transB=False, accumulate="atomic")
-            ops.gru_bwd(gd_t, gpre[t], P.gru.g, P.gru.b, din[t], mg[t], rg[t], dgpre[t], ddin, _g(P.gru.g),
-                        _g(P.gru.b))
-            ops.gemm(dgpre[t], P.gru.W, dxd[t], transB=False, accumulate="atomic")
+            if fuse_gru:
+                ops.scan_grubwd_gemm(gd_t, xhg[t], afg[t], p1g[t], p2g[t], ahg[t], P.gru.g, rg[t], dgpre[t], ddin, P.gru.W,
+                                     dxd[t], _g(P.gru.g), _g(P.gru.b))
+            else:
+                ops.gru_bwd(gd_t, gpre[t], P.gru.g, P.gru.b, din[t], mg[t], rg[t], dgpre[t], ddin, _g(P.gru.g),
+                            _g(P.gru.b))
+                ops.gemm(dgpre[t], P.gru.W, dxd[t], transB=False, accumulate="atomic")
             if fuse_row:
                 ops.scan_lnbwd_gemm(dx1, xh1[t], jc1[t], P.img_in.g, r1[t], dx1pre[t], P.img_in.W[:, :SD], dsin[t],
                                     _g(P.img_in.g), _g(P.img_in.b))

@@ -517,6 +517,57 @@ def scan_lnbwd_gemm(dy, xhat, jac, gamma, rstd, dx, W, C, dgamma=None, dbeta=Non
     return C
 
 
+def scan_grubwd_gemm_ok(De, N) -> bool:
+    return De in (256, 512, 1024) and N % 64 == 0
+
+
+def scan_gru_factors(p, gamma, beta, h, mean, rstd, xhat, afac, p1, p2, ah):
+    """What GRUCell's backward needs from the forward pass, for all rows at once (scan_grubwd_gemm reads it):
+    xhat / afac [R, 3 De], p1 / p2 / ah [R, De]."""
+    R, N3, ldp = _rows2d(p, "p")
+    Rh, De, ldh = _rows2d(h, "h")
+    for t, nm, n in ((gamma, "gamma", N3), (beta, "beta", N3), (mean, "mean", R), (rstd, "rstd", R),
+                     (xhat, "xhat", R * N3), (afac, "afac", R * N3), (p1, "p1", R * De), (p2, "p2", R * De),
+                     (ah, "ah", R * De)):
+        _contig(t, nm)
+        if t.numel() != n:
+            raise ValueError(f"scan_gru_factors: {nm} size mismatch")
+    if N3 != 3 * De or Rh != R:
+        raise ValueError("scan_gru_factors shapes mismatch")
+    _call("dv3_scan_gru_factors", _ptr(p), ldp, _ptr(gamma), _ptr(beta), _ptr(h), ldh, _ptr(mean), _ptr(rstd), _ptr(xhat),
+          _ptr(afac), _ptr(p1), _ptr(p2), _ptr(ah), R, De, _stream(), nbytes=4.0 * R * De * 13)
+
+
+def scan_grubwd_gemm(g, xhat, afac, p1, p2, ah, gamma, rstd, dp, dh, W, C, dgamma=None, dbeta=None):
+    """gru_bwd from the precomputed factors and C += dp @ W (atomic) in ONE launch (reverse observe scan).  dh [M, De]
+    (may be a column slice of C) receives the direct path g * (1 - u) with atomic adds: it must hold the value being
+    added to, like C."""
+    M, De, ldg = _rows2d(g, "g")
+    Md, Dd, lddh = _rows2d(dh, "dh")
+    Kw, N, ldb = _rows2d(W, "W")
+    Mc, Nc, ldc = _rows2d(C, "C")
+    if (Md, Dd) != (M, De) or Kw != 3 * De or (Mc, Nc) != (M, N):
+        raise ValueError("scan_grubwd_gemm shapes mismatch")
+    if not scan_grubwd_gemm_ok(De, N):
+        raise ValueError(f"scan_grubwd_gemm: unsupported De={De} N={N}")
+    for t, nm, n in ((xhat, "xhat", 3 * M * De), (afac, "afac", 3 * M * De), (p1, "p1", M * De), (p2, "p2", M * De),
+                     (ah, "ah", M * De), (gamma, "gamma", 3 * De), (rstd, "rstd", M), (dp, "dp", 3 * M * De)):
+        _contig(t, nm)
+        if t.numel() != n:
+            raise ValueError(f"scan_grubwd_gemm: {nm} size mismatch")
+    if (dgamma is None) != (dbeta is None):
+        raise ValueError("dgamma/dbeta: both or neither")
+    if dgamma is not None:
+        _contig(dgamma, "dgamma"), _contig(dbeta, "dbeta")
+        if dgamma.numel() != 3 * De or dbeta.numel() != 3 * De:
+            raise ValueError("scan_grubwd_gemm dgamma size mismatch")
+    _call("dv3_scan_grubwd_gemm", _ptr(g), ldg, _ptr(xhat), _ptr(afac), _ptr(p1), _ptr(p2), _ptr(ah), _ptr(gamma), _ptr(rstd),
+          _ptr(dp), _ptr(dh), lddh, _ptr(dgamma), _ptr(dbeta), _ptr(W), ldb, _ptr(C), ldc, M, De, N, _stream(),
+          key="gemm_kernel<skinny16+grubwd,tA=0,tB=0>", flops=2.0 * M * N * 3 * De,
+          nbytes=4.0 * (N * 3 * De + M * (12 * De + 2 * N)))
+    return C
+
+
 def scan_carry_st_gemm_ok(S, D, N) -> bool:
     return D == 32 and S % 8 == 0 and N % 64 == 0
 

@@ -378,6 +378,19 @@ int dv3_scan_ln_gemm_fwd(const float* x, long ldx, const float* gamma, const flo
  *   dlogit_out = dlogit + straight-through gradient of the posterior sample at t (tools.py:452-460; = dv3_onehot_st_bwd),
  *   C[B,N] += dlogit_out W; extra workgroups add the deter carry gd += ddin (1 - first), ddeter0 += sum_b ddin first
  *   (= dv3_obs_carry_st_bwd).  D == 32, S % 8 == 0, N % 64 == 0; dlogit_out must not alias dlogit. */
+/* dv3_scan_gru_factors / dv3_scan_grubwd_gemm: the same for the GRU cell (GRUCell.forward reversed,
+ *   networks.py:760-768; = dv3_gru_bwd followed by the data-gradient GEMM of its Linear).  Factors per row, computed
+ *   once per update: xhat [R, 3 De], afac [R, 3 De] (d gate pre-activation / d new state), p1, p2 [R, De] (the two
+ *   LayerNorm row sums as dot products with the state gradient), ah [R, De] (1 - update gate).  The per-step launch
+ *   writes dp [M, 3 De] (gradient on the Linear's output), adds g * ah onto dh (atomic) and C[M,N] += dp W (atomic);
+ *   d-gamma / d-beta accumulated.  De in {256, 512, 1024}, N % 64 == 0. */
+int dv3_scan_gru_factors(const float* p, long ldp, const float* gamma, const float* beta, const float* h, long ldh,
+                         const float* mean, const float* rstd, float* xhat, float* afac, float* p1, float* p2,
+                         float* ah, long R, int De, void* stream);
+int dv3_scan_grubwd_gemm(const float* g, long ldg, const float* xhat, const float* afac, const float* p1,
+                         const float* p2, const float* ah, const float* gamma, const float* rstd, float* dp, float* dh,
+                         long lddh, float* dgamma, float* dbeta, const float* W, long ldb, float* C, long ldc, int M,
+                         int De, int N, void* stream);
 int dv3_scan_ln_factors(const float* x, long ldx, const float* gamma, const float* beta, const float* mean,
                         const float* rstd, float* xhat, float* jac, long R, int K, void* stream);
 int dv3_scan_lnbwd_gemm(const float* dy, long lddy, const float* xhat, const float* jac, const float* gamma,

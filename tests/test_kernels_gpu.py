@@ -1293,3 +1293,31 @@ def test_scan_carry_st_gemm_equals_two_launches(ops, B, S, De, N, with_carry):
     if with_carry:
         assert torch.equal(b["gd"], a["gd"])
         assert_close(b["ds0"], a["ds0"].cpu(), tol=1e-5, what="dstoch0"), assert_close(b["dd0"], a["dd0"].cpu(), tol=1e-5, what="ddeter0")
+
+
+@pytest.mark.parametrize("M,De,Hd", [(16, 512, 512), (32, 1024, 512), (5, 256, 64), (64, 512, 1024)])
+def test_scan_grubwd_gemm_equals_two_launches(ops, M, De, Hd):
+    """dv3_scan_gru_factors + dv3_scan_grubwd_gemm == dv3_gru_bwd followed by the atomically accumulating few-row GEMM
+    dxd += dgpre W_gru, whose right half the cell's direct path pre-loads (networks.py:760-768 reversed)."""
+    g = torch.Generator().manual_seed(M + De + Hd)
+    N = Hd + De
+    gpre = dev(torch.randn(M, 3 * De, generator=g))
+    gam, bet = dev(1 + 0.1 * torch.randn(3 * De, generator=g)), dev(0.1 * torch.randn(3 * De, generator=g))
+    h = dev(torch.randn(M, De, generator=g))
+    gd = dev(torch.randn(M, De + 32, generator=g))[:, :De]  # row-strided view
+    W = dev(torch.randn(3 * De, N, generator=g) / math.sqrt(3 * De))
+    hn, mean, rstd = torch.empty(M, De).cuda(), torch.empty(M).cuda(), torch.empty(M).cuda()
+    ops.gru_fwd(gpre, gam, bet, h, hn, mean, rstd)
+    a = dict(dp=torch.empty(M, 3 * De).cuda(), dxd=torch.zeros(M, N).cuda(), dg=torch.ones(3 * De).cuda(),
+             db=torch.ones(3 * De).cuda())
+    b = dict(dp=torch.empty(M, 3 * De).cuda(), dxd=torch.zeros(M, N).cuda(), dg=torch.ones(3 * De).cuda(),
+             db=torch.ones(3 * De).cuda())
+    ops.gru_bwd(gd, gpre, gam, bet, h, mean, rstd, a["dp"], a["dxd"][:, Hd:], a["dg"], a["db"])
+    ops.gemm(a["dp"], W, a["dxd"], transB=False, accumulate="atomic")
+    fac = [torch.empty(M, 3 * De).cuda(), torch.empty(M, 3 * De).cuda(), torch.empty(M, De).cuda(),
+           torch.empty(M, De).cuda(), torch.empty(M, De).cuda()]
+    ops.scan_gru_factors(gpre, gam, bet, h, mean, rstd, *fac)
+    ops.scan_grubwd_gemm(gd, *fac, gam, rstd, b["dp"], b["dxd"][:, Hd:], W, b["dxd"], b["dg"], b["db"])
+    assert_close(b["dp"], a["dp"].cpu(), tol=5e-6, what="dp")
+    assert_close(b["dxd"], a["dxd"].cpu(), tol=1e-5 * math.sqrt(3 * De / 64), what="dxd")
+    assert_close(b["dg"], a["dg"].cpu(), tol=2e-5, what="dgamma"), assert_close(b["db"], a["db"].cpu(), tol=2e-5, what="dbeta")
