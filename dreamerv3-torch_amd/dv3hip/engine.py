@@ -680,6 +680,10 @@ class RSSMEngine:
                 ops.gemm(scratch["dgpre"], wt["gru"][:Hd], scratch["dx1"])
             dense_ln_bwd_pre(P.img_in, scratch["dx1"], bufs["x1pre"], bufs["m1"], bufs["r1"], scratch["dx1pre"],
                              wgrad=False)
+            if daction is not None and M > 128 and SD % 16 == 0 and ops.gemm_split_ok(scratch["dx1pre"], wt["in"]):
+                # [dstoch | daction] = dx1pre W_in in one launch (the action's few columns ride in the last column tile)
+                ops.gemm_split(scratch["dx1pre"], wt["in"], dprev_stoch, daction, accumulate=accumulate_prev)
+                return
             ops.gemm(scratch["dx1pre"], wt["in"][:SD], dprev_stoch, accumulate=accumulate_prev)
             if daction is not None:
                 ops.gemm(scratch["dx1pre"], wt["in"][SD:], daction)
