@@ -32,7 +32,8 @@ def hipcc() -> str:
 
 def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
     """dev=True: -DDV3_DEV_SWITCHES (the DV3_* A/B switches of tools/*_bench.py become live) into libdv3hip_dev.so,
-    which dv3hip._lib loads only when DV3HIP_LIB points at it."""
+    which dv3hip._lib loads only when DV3HIP_LIB points at it.  DV3_DEV_DEFINES="-DFOO ..." adds compile-time
+    definitions to the dev build only (A/B of source-level variants against the shipped library)."""
     global OUT, OBJ
     if dev:
         OUT, OBJ = OUT.replace("libdv3hip.so", "libdv3hip_dev.so"), os.path.join(HERE, "_obj_dev")
@@ -52,7 +53,7 @@ def build(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
 
     def compile_one(job):
         s, o = job
-        cmd = [cc] + FLAGS + (["-DDV3_DEV_SWITCHES"] if dev else []) + ["-c", s, "-o", o]
+        cmd = [cc] + FLAGS + (["-DDV3_DEV_SWITCHES"] + os.environ.get("DV3_DEV_DEFINES", "").split() if dev else []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr}")
