@@ -492,6 +492,41 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
   }
 }
 
+// Up to kTrJobs transposes in ONE launch: the per-update re-packing of the weights the gathers and the reverse rollout
+// read (engine.MLPEngine.pack_onehot, RSSMEngine.pack_img_in / pack_bwd) is 9-10 small launches otherwise.
+constexpr int kTrJobs = 12;
+struct TrJobs {
+  const float* src[kTrJobs];
+  float* dst[kTrJobs];
+  long lds[kTrJobs], ldd[kTrJobs];
+  int R[kTrJobs], C[kTrJobs], tiles_c[kTrJobs];
+  int tile0[kTrJobs + 1];  // first workgroup of job k; tile0[n] = grid size
+  int n;
+};
+__global__ __launch_bounds__(256) void transpose2d_many_kernel(TrJobs jb) {
+  __shared__ float tile[32][33];
+  int k = 0;
+  while (k + 1 < jb.n && (int)blockIdx.x >= jb.tile0[k + 1]) ++k;
+  const int t = blockIdx.x - jb.tile0[k];
+  const float* __restrict__ src = jb.src[k];
+  float* __restrict__ dst = jb.dst[k];
+  const long lds_ = jb.lds[k], ldd = jb.ldd[k];
+  const int R = jb.R[k], C = jb.C[k];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = (t % jb.tiles_c[k]) * 32, r0 = (t / jb.tiles_c[k]) * 32;
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int r = r0 + ty + j, c = c0 + tx;
+    tile[ty + j][tx] = (r < R && c < C) ? src[(long)r * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int c = c0 + ty + j, r = r0 + tx;
+    if (c < C && r < R) dst[(long)c * ldd + r] = tile[tx][ty + j];
+  }
+}
+
 // class index of every one-hot group: idx[g] = argmax_d x[g][d] (lowest index on ties).  G = pow2 >= D lanes per
 // group, one class per lane (coalesced), shuffle argmax.
 template <int G>
@@ -616,6 +651,32 @@ extern "C" int dv3_transpose2d(const float* src, long lds, int R, int C, float* 
   if (!src || !dst || lds < C || ldd < R) return DV3_ERR_ARG;
   hipLaunchKernelGGL(transpose2d_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
                      lds, R, C, dst, ldd);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_transpose2d_many(int njobs, const unsigned long long* jobs_host, void* stream) {
+  // jobs_host: HOST array of njobs x 6 values {src, dst, lds, ldd, R, C} (device pointers as integers): consumed
+  // before the call returns (the descriptors travel as kernel arguments)
+  if (njobs <= 0) return 0;
+  if (!jobs_host || njobs > kTrJobs) return DV3_ERR_ARG;
+  TrJobs jb;
+  int tiles = 0;
+  for (int k = 0; k < njobs; ++k) {
+    const unsigned long long* j = jobs_host + 6 * k;
+    jb.src[k] = (const float*)(uintptr_t)j[0];
+    jb.dst[k] = (float*)(uintptr_t)j[1];
+    jb.lds[k] = (long)j[2];
+    jb.ldd[k] = (long)j[3];
+    jb.R[k] = (int)j[4];
+    jb.C[k] = (int)j[5];
+    if (!jb.src[k] || !jb.dst[k] || jb.R[k] <= 0 || jb.C[k] <= 0 || jb.lds[k] < jb.C[k] || jb.ldd[k] < jb.R[k]) return DV3_ERR_ARG;
+    jb.tiles_c[k] = (jb.C[k] + 31) / 32;
+    jb.tile0[k] = tiles;
+    tiles += jb.tiles_c[k] * ((jb.R[k] + 31) / 32);
+  }
+  for (int k = njobs; k <= kTrJobs; ++k) jb.tile0[k] = tiles;
+  jb.n = njobs;
+  hipLaunchKernelGGL(transpose2d_many_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, jb);
   return (int)hipGetLastError();
 }
 

@@ -111,6 +111,24 @@ class Workspace:
         t.zero_()
         return t
 
+    def zeros_many(self, name, shapes):
+        """Several zero-initialised float32 buffers carved out of ONE allocation and cleared by ONE fill (offsets rounded
+        up to 64 floats): the accumulation targets of the reverse observe scan are five buffers per update."""
+        shapes = [tuple(int(s) for s in sh) for sh in shapes]
+        sizes = []
+        for sh in shapes:
+            n = 1
+            for d in sh:
+                n *= d
+            sizes.append(n)
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 63) // 64 * 64
+        flat = self.get(name, (total,))
+        flat.zero_()
+        return [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
+
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self._b.values())
 
@@ -202,12 +220,16 @@ class MLPEngine:
         out2 = ws.get(f"{nm}.out2", (total, P.out2.W.shape[0])) if P.out2 is not None else None
         return acts, out, out2
 
-    def pack_onehot(self, SD: int):
+    def pack_onehot(self, SD: int, defer=None):
         """Transposed copy of the first layer's stoch columns, W0[:, :SD] -> [SD, U], for the one-hot gather
-        (ops.onehot_linear_ln).  Call once per update, after the optimizer step that changed W0."""
+        (ops.onehot_linear_ln).  Call once per update, after the optimizer step that changed W0.  defer: a list that
+        receives the (src, dst) pair instead of launching (ops.transpose2d_many runs several packs as one launch)."""
         W0 = self.P.layers[0].W
         wt = self.ws.get(f"{self.name}.wt0", (SD, W0.shape[0]))
-        ops.transpose2d(W0[:, :SD], wt)
+        if defer is not None:
+            defer.append((W0[:, :SD], wt))
+        else:
+            ops.transpose2d(W0[:, :SD], wt)
         return wt
 
     def forward(self, x1, x2=None, *, row0=0, total=None, idx=None, D=0, head=None, base0=None):
@@ -508,13 +530,11 @@ class RSSMEngine:
         # accumulate="atomic" may split K over workgroups (atomics onto C), which is what fills the chip at B rows.  The two
         # data gradients of the GRU matmul share one GEMM: dxd[t] = [dx1 | ddin], whose right half gru_bwd
         # pre-loads with the direct dh path.
-        dx3 = ws.zeros("obs.dx3", (T, B, Hd))
+        dx3, dxd, dsin, dstoch0, ddeter0 = ws.zeros_many(
+            "obs.zeroed", [(T, B, Hd), (T, B, Hd + De), (T, B, SD), (SD,), (De,)])
         dx3pre = g("obs.dx3pre", (T, B, Hd))
         dgpre = g("obs.dgpre", (T, B, 3 * De))
-        dxd = ws.zeros("obs.dxd", (T, B, Hd + De))
         dx1pre = g("obs.dx1pre", (T, B, Hd))
-        dsin = ws.zeros("obs.dsin", (T, B, SD))
-        dstoch0, ddeter0 = ws.zeros("obs.dstoch0", (SD,)), ws.zeros("obs.ddeter0", (De,))
         fuse_carry = _FUSE_CARRY
         # row operations in the prologue of the few-row GEMM that consumes them (csrc/scanops.hip): 5 launches per step
         fuse_row = (_FUSE_SCAN_ROW and _FUSE_SCAN_LNBWD and B <= 64 and ops.scan_lnbwd_gemm_ok(Hd, De)
@@ -597,12 +617,15 @@ class RSSMEngine:
         return side
 
     # -- one img_step on a row block (networks.py:208-233), used by the policy path and imagine ---------
-    def pack_img_in(self):
+    def pack_img_in(self, defer=None):
         """Transposed copy of the img_in weight, [Hd, SD+A] -> [SD+A, Hd], for the one-hot gather path of img_step
         (once per update: the world model's weights are frozen during imagination, models.py:335)."""
         W = self.P.img_in.W
         wt = self.ws.get("rssm.img_in_wt", (W.shape[1], W.shape[0]))
-        ops.transpose2d(W, wt)
+        if defer is not None:
+            defer.append((W, wt))
+        else:
+            ops.transpose2d(W, wt)
         return wt
 
     def img_step_fwd(self, stoch, deter, action, bufs, *, noise=None, rng=None, sample=True, forced=None,
@@ -642,16 +665,19 @@ class RSSMEngine:
             ops.onehot_sample(bufs["logit"], bufs["stoch"], noise=noise, rng=rng, unimix=self.unimix, mode=not sample,
                               forced=forced, flips=flips, idx=io)
 
-    def pack_bwd(self):
+    def pack_bwd(self, defer=None):
         """Transposed copies of the four img_step weights for its data gradients: dX = dY W is then the y = x B^T form
         with B = W^T [K_in, N_out] (k-contiguous rows: 16-byte operand loads in the register-direct kernel, and the
         6-column action gradient takes the narrow-output path).  Once per behaviour update: the world model's weights
         are frozen while it runs (models.py:335), the 14 steps of the reverse rollout share the copies."""
         P, ws = self.P, self.ws
-        wt = {"in": self.pack_img_in()}
+        wt = {"in": self.pack_img_in(defer=defer)}
         for nm, W in (("gru", P.gru.W), ("out", P.img_out.W), ("ims", P.ims.W)):
             t = ws.get(f"rssm.{nm}_wt", (W.shape[1], W.shape[0]))
-            ops.transpose2d(W, t)
+            if defer is not None:
+                defer.append((W, t))
+            else:
+                ops.transpose2d(W, t)
             wt[nm] = t
         return wt
 

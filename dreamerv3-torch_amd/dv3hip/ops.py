@@ -1295,6 +1295,23 @@ def convT_s2_c3_fwd(x, w, y, *, CW, bias=None, out_add=0.0, accumulate=False):
 # ---------------------------------------------------------------------------------------------
 # row-fused layers of the imagination step (csrc/fusedops.hip)
 # ---------------------------------------------------------------------------------------------
+def transpose2d_many(pairs):
+    """dst[c][r] = src[r][c] for every (src, dst) pair, 12 per launch (weights re-packed once per update)."""
+    import numpy as np
+
+    pairs = list(pairs)
+    for k0 in range(0, len(pairs), 12):
+        chunk = pairs[k0:k0 + 12]
+        jobs = np.empty((len(chunk), 6), dtype=np.uint64)
+        for k, (src, dst) in enumerate(chunk):
+            R, C, lds = _rows2d(src, "src")
+            Cd, Rd, ldd = _rows2d(dst, "dst")
+            if (Rd, Cd) != (R, C):
+                raise ValueError(f"transpose2d_many: src {tuple(src.shape)} dst {tuple(dst.shape)}")
+            jobs[k] = (src.data_ptr(), dst.data_ptr(), lds, ldd, R, C)
+        _call("dv3_transpose2d_many", len(chunk), jobs.ctypes.data, _stream(), key="dv3_transpose2d")
+
+
 def transpose2d(src, dst):
     """dst [C,R] = src [R,C]^T (src may be a column slice of a wider matrix)."""
     R, C, lds = _rows2d(src, "src")

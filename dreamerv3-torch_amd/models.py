@@ -459,7 +459,7 @@ class ImagBehavior(nn.Module):
         return (torch.stack(feats, 0), {k: torch.stack([s_[k] for s_ in states], 0) for k in states[0]},
                 torch.stack(actions, 0))
 
-    def _imagine_fwd(self, start, horizon, noise=None):
+    def _imagine_fwd(self, start, horizon, noise=None, packed=False):
         cfg = self._config
         dyn = self._world_model.dynamics
         rssm = dyn.engine
@@ -499,9 +499,11 @@ class ImagBehavior(nn.Module):
         # that reads it (actor layer 0, img_in) gather weight columns instead of multiplying zeros (engine.py).
         idx = g("im.idx", (H, N, S), torch.int32)
         ops.onehot_to_idx(stoch[0].view(N, S, D), idx[0].view(-1))  # class indices of the start states
-        if _FUSED_IMAG:
-            actor_eng.pack_onehot(SD)
-            rssm.pack_img_in()
+        if _FUSED_IMAG and not packed:
+            tr = []
+            actor_eng.pack_onehot(SD, defer=tr)
+            rssm.pack_img_in(defer=tr)
+            ops.transpose2d_many(tr)
 
         def run_chain(rc):
             """The H-step rollout of the row range rc (rows are independent: models.py:450-451 flattens [B,T])."""
@@ -631,7 +633,26 @@ class ImagBehavior(nn.Module):
         self._update_slow_target()
         self._actor_opt.begin()
         self._value_opt.begin()
-        self._imagine_fwd(start, H, noise)
+        reng = wm.heads["reward"].engine_for(".imag")
+        ceng = wm.heads["cont"].engine_for(".imag")
+        veng = self.value.engine_for(".imag")
+        seng = networks.MLP.engine_for(self._slow_value, ".imag")
+        self._slow_bucket()
+        wt_bwd = None
+        if _FUSED_IMAG:
+            # every transposed weight copy of this update (the one-hot gathers of the actor, img_in and the four heads,
+            # the reverse rollout's data-gradient operands) in ONE launch: the world model is frozen from here on
+            # (models.py:335) and the actor / critic step only after the backward below
+            tr = []
+            self.actor.engine_for(".imag").pack_onehot(SD, defer=tr)
+            for e in (reng, ceng, veng, seng):
+                e.pack_onehot(SD, defer=tr)
+            if cfg.imag_gradient in ("dynamics", "both"):
+                wt_bwd = rssm.pack_bwd(defer=tr)
+            else:
+                rssm.pack_img_in(defer=tr)
+            ops.transpose2d_many(tr)
+        self._imagine_fwd(start, H, noise, packed=True)
         im = self._im
         N = im["N"]
         HN, H1N = H * N, (H - 1) * N
@@ -641,14 +662,6 @@ class ImagBehavior(nn.Module):
         # ---- heads over all H*N imagined states
         # first layers read feat = [stoch | deter]: deter through the MFMA GEMM, the one-hot stoch as a gather
         fidx = im["idx"].view(HN, S) if _FUSED_IMAG else None
-        reng = wm.heads["reward"].engine_for(".imag")
-        ceng = wm.heads["cont"].engine_for(".imag")
-        veng = self.value.engine_for(".imag")
-        seng = networks.MLP.engine_for(self._slow_value, ".imag")
-        self._slow_bucket()
-        if _FUSED_IMAG:
-            for e in (reng, ceng, veng, seng):
-                e.pack_onehot(SD)
         use_dyn = cfg.imag_gradient in ("dynamics", "both")
         reward = g("bh.reward", (H, N))
         custom = objective is not None and self.__dict__.get("_objective_kinds", {}).get(
@@ -755,7 +768,6 @@ class ImagBehavior(nn.Module):
             scratch = dict(dlogit=g("bh.s.dlogit", (N, SD)), dx2=g("bh.s.dx2", (N, Hd)), dx2pre=g("bh.s.dx2pre", (N, Hd)),
                            dgpre=g("bh.s.dgpre", (N, 3 * De)), dx1=g("bh.s.dx1", (N, Hd)),
                            dx1pre=g("bh.s.dx1pre", (N, Hd)))
-            wt_bwd = rssm.pack_bwd() if _FUSED_IMAG else None
             for t in range(H - 1, 0, -1):
                 b = {k: v[t - 1] for k, v in im["step"].items()}
                 b.update(logit=im["logit"][t].view(N, S, D))

@@ -428,6 +428,10 @@ int dv3_actor_head_fwd(const float* pre, long ldpre, const float* gamma, const f
                        const int* forced, unsigned int* flips, long M, int U, int A, float min_std, float max_std,
                        float unimix, int onehot, void* stream);
 int dv3_transpose2d(const float* src, long lds, int R, int C, float* dst, long ldd, void* stream);
+/* Up to 12 transposes in one launch (the per-update re-packing of the weights the one-hot gathers and the reverse
+ * imagination rollout read).  jobs_host: HOST array of njobs x 6 unsigned 64-bit values {src, dst, lds, ldd, R, C}
+ * (device pointers as integers), consumed before the call returns. */
+int dv3_transpose2d_many(int njobs, const unsigned long long* jobs_host, void* stream);
 int dv3_onehot_to_idx(const float* onehot, int* idx, long R, int D, void* stream);
 
 #ifdef __cplusplus
