@@ -285,6 +285,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if os.environ.get("DV3_BENCH_OWN_STREAM"):  # experiment: the update on a non-blocking stream instead of the NULL stream
+        torch.cuda.set_stream(torch.cuda.Stream(device))
     for _ in range(args.warmup):
         runner.step(data)
     sync()

@@ -27,6 +27,7 @@ _CTYPES = {
     "int*": ctypes.c_void_p,
     "const int*": ctypes.c_void_p,
     "unsigned int*": ctypes.c_void_p,
+    "const unsigned int*": ctypes.c_void_p,
     "void*": ctypes.c_void_p,
     "unsigned long long": ctypes.c_ulonglong,
     "long": ctypes.c_long,

@@ -46,43 +46,183 @@ _FUSE_SCAN_CS = _dev.flag("DV3_FUSE_SCAN_CS", True)  # ... reverse: carry + stra
 _FUSE_SCAN_GRUBWD = _dev.flag("DV3_FUSE_SCAN_GRUBWD", True)  # ... reverse: GRU cell backward + the data-gradient GEMM of its Linear
 
 
-class SideStream:
-    """Second HIP stream for work that is off the critical path (weight gradients, the critic branch) so it
-    runs beside the latency-bound scans, whose small launches leave most CUs idle.  fork() makes the side
-    stream wait for everything enqueued so far; join() makes the main stream wait for the side work.  Under
-    hipGraph capture the two streams become parallel branches of the graph."""
+class Lanes:
+    """Two HIP streams whose hardware queues own complementary sets of compute units (csrc/streams.hip): "scan" for a
+    chain of dependent few-row launches, "side" for chip-filling work nothing waits for until the chain is over.
 
-    # Measured on MI355X at cfg 2 (r01): OFF is faster (27.7 vs 29.8 ms/update).  The heavy side kernels
-    # (conv wgrads) take every CU and each of the ~640 latency-critical scan launches then queues behind
-    # them.  Kept as a switch: it needs a CU-masked side stream to pay (DESIGN.md §7).
-    enabled = _dev.flag("DV3_SIDE_STREAM", False)
+    Measured (tools/cumask_probe.py, MI355X): the chain of 16-row GEMMs takes 7.7 us per launch on the whole chip AND on
+    128 of its 256 CUs (10.3 on 64); beside 4096^3 GEMMs on the complementary mask it still takes 7.7 and the GEMMs lose
+    nothing but the CUs they gave up -- whereas beside the same GEMMs on an UNMASKED second queue the chain makes no
+    progress until they are over (its workgroups are placed behind theirs), which is why r01/r02 measured the plain
+    second stream slower than no overlap at all.  A hipGraph launched on a masked stream inherits the mask; graph
+    BRANCHES do not (they run on streams of the runtime's own), so a captured update is cut into one graph per lane
+    (graph.SegmentRecorder)."""
+
+    _by_dev: Dict[str, "Lanes"] = {}
+
+    @classmethod
+    def get(cls, device) -> "Lanes":
+        key = str(torch.device(device))
+        if key not in cls._by_dev:
+            cls._by_dev[key] = Lanes(device, _dev.value("DV3_LANES_SCAN_CUS", 128))
+        return cls._by_dev[key]
+
+    def __init__(self, device, scan_cus: int):
+        from . import _lib  # (ops imports engine's siblings; keep the loader import local)
+        import ctypes
+
+        lib = _lib.load()
+        with torch.cuda.device(device):
+            n = ctypes.c_int()
+            _lib.check(lib.dv3_device_cu_count(ctypes.byref(n)), "dv3_device_cu_count")
+            n_cu = n.value
+            if not 8 <= scan_cus <= n_cu - 8:
+                raise ValueError(f"scan lane of {scan_cus} CUs on a {n_cu}-CU device")
+            # groups of 8 mask bits dealt out evenly: every XCD gives the same share of its CUs to each lane whether the
+            # mask's bits run XCD-major or XCD-interleaved
+            groups, want = n_cu // 8, scan_cus // 8
+            scan_bits = [((g + 1) * want) // groups != (g * want) // groups for g in range(groups)]
+            words = (n_cu + 31) // 32
+            self.cus = {"scan": 8 * sum(scan_bits), "side": n_cu - 8 * sum(scan_bits), "whole": n_cu}
+            self._handles, self.streams = {}, {}
+            for lane in ("scan", "side", "whole"):
+                mask = (ctypes.c_uint32 * words)()
+                for i in range(n_cu):
+                    g = i // 8
+                    mine = lane == "whole" or (scan_bits[g] if g < groups else False) == (lane == "scan")
+                    if mine:
+                        mask[i // 32] |= 1 << (i % 32)
+                out = ctypes.c_ulonglong()
+                _lib.check(lib.dv3_stream_create_cu_masked(words, mask, ctypes.byref(out)), "dv3_stream_create_cu_masked")
+                self._handles[lane] = out.value
+                self.streams[lane] = torch.cuda.ExternalStream(out.value, device=device)
+
+
+    # (Lanes) --------------------------------------------------------------------------------------------------------
+    def whole_chip_stream(self):
+        """A blocking stream over every CU (what UpdateRunner runs an update on when its caller sits on the NULL stream)."""
+        return self.streams["whole"]
+
+
+class SideStream:
+    """Work that is off the critical path (weight gradients) beside a latency-bound chain of few-row launches.
+
+        side.run(fns)            # the deferred launches
+        with side.chain():       # the chain they run beside
+            ...
+        side.join()              # both are over before anything that follows
+
+    mode "lanes" (default): fns on the "side" lane, the chain on the "scan" lane (Lanes: complementary CU masks).  Under
+    hipGraph capture the cut points are handed to graph.SegmentRecorder (one graph per lane); captured by anything else
+    (tools that capture a phase in one graph) the work runs inline, because graph branches lose the masks.
+    mode "plain" (DV3_SIDE_STREAM=1, dev): one unmasked second stream -- measured slower than inline in r01, r02 and r03.
+    mode "off" (DV3_LANES=0, dev): inline."""
+
+    # r01 (cfg 2): plain second stream 29.8 vs 27.7 ms/update; r02 20.0 vs 18.6; r03 world model 10.69 vs 10.30 ms.
+    plain = _dev.flag("DV3_SIDE_STREAM", False)
+    lanes = _dev.flag("DV3_LANES", True)
+    recorder = None  # graph.SegmentRecorder while UpdateRunner captures
     _streams: Dict[str, "torch.cuda.Stream"] = {}
 
     def __init__(self, device):
-        key = str(device)
-        if key not in SideStream._streams:
-            SideStream._streams[key] = torch.cuda.Stream(device=device)
-        self.stream = SideStream._streams[key]
-        self._forked = False
+        self.device = device
+        self._forked = []
+        self._mode = "plain" if SideStream.plain else ("lanes" if SideStream.lanes else "off")
+        if self._mode != "off" and SideStream.recorder is None and torch.cuda.is_current_stream_capturing():
+            self._mode = "plain" if self._mode == "plain" else "off"
+        if self._mode == "plain":
+            key = str(device)
+            if key not in SideStream._streams:
+                SideStream._streams[key] = torch.cuda.Stream(device=device)
+            self.stream = SideStream._streams[key]
+        self._main = None
+        self._cut = False
 
-    def run(self, fns):
-        """Run the deferred callables on the side stream (or inline when disabled)."""
+    @staticmethod
+    def host_sync_point():
+        """Marks where a captured update lets the host wait before it launches the lane segments (graph.SegmentRecorder)."""
+        if SideStream.recorder is not None and SideStream.lanes and not SideStream.plain:
+            SideStream.recorder.sync_point()
+
+    def run(self, fns, chain: bool = True):
+        """Run the deferred callables beside what follows.  chain=False: what follows fills the chip itself (the encoder
+        backward), so in lanes mode the callables simply run in line."""
         if not fns:
             return
-        if not SideStream.enabled:
+        if self._mode == "off" or (self._mode == "lanes" and not chain):
             for f in fns:
                 f()
             return
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
+        if self._mode == "plain":
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for f in fns:
+                    f()
+            self._forked.append(self.stream)
+            return
+        self._on_lane("side", fns)
+
+    def _on_lane(self, lane, fns):
+        rec = SideStream.recorder
+        if rec is not None:
+            rec.cut(lane)
+            self._cut = True
             for f in fns:
                 f()
-        self._forked = True
+            return
+        ln = Lanes.get(self.device)
+        if self._main is None:
+            self._main = torch.cuda.current_stream()
+        s = ln.streams[lane]
+        s.wait_stream(self._main)
+        with torch.cuda.stream(s):
+            for f in fns:
+                f()
+        self._forked.append(s)
+
+    class _Chain:
+        def __init__(self, side):
+            self.side, self.ctx = side, None
+
+        def __enter__(self):
+            side = self.side
+            if side._mode != "lanes":
+                return self
+            rec = SideStream.recorder
+            if rec is not None:
+                rec.cut("scan")
+                side._cut = True
+                return self
+            ln = Lanes.get(side.device)
+            if side._main is None:
+                side._main = torch.cuda.current_stream()
+            s = ln.streams["scan"]
+            s.wait_stream(side._main)
+            self.ctx = torch.cuda.stream(s)
+            self.ctx.__enter__()
+            side._forked.append(s)
+            return self
+
+        def __exit__(self, *exc):
+            if self.ctx is not None:
+                self.ctx.__exit__(*exc)
+            return False
+
+    def chain(self):
+        return SideStream._Chain(self)
 
     def join(self):
-        if self._forked:
-            torch.cuda.current_stream().wait_stream(self.stream)
-            self._forked = False
+        rec = SideStream.recorder
+        if self._mode == "lanes" and rec is not None:
+            if self._cut:
+                rec.cut("main")
+            self._cut = False
+            return
+        cur = self._main if self._main is not None else torch.cuda.current_stream()
+        for s in self._forked:
+            cur.wait_stream(s)
+        self._forked = []
+        self._main = None
 
 
 class Workspace:
@@ -525,82 +665,83 @@ class RSSMEngine:
             lin_wgrad(P.img_out.W, dx2pre, v2(deter, De))
 
         side.run((extra_side or []) + [_prior_wgrads])  # beside the reverse scan below
-        # ---- reverse scan
-        # Every GEMM of the reverse scan ACCUMULATES into buffers zeroed here in bulk: a few-row GEMM with
-        # accumulate="atomic" may split K over workgroups (atomics onto C), which is what fills the chip at B rows.  The two
-        # data gradients of the GRU matmul share one GEMM: dxd[t] = [dx1 | ddin], whose right half gru_bwd
-        # pre-loads with the direct dh path.
-        dx3, dxd, dsin, dstoch0, ddeter0 = ws.zeros_many(
-            "obs.zeroed", [(T, B, Hd), (T, B, Hd + De), (T, B, SD), (SD,), (De,)])
-        dx3pre = g("obs.dx3pre", (T, B, Hd))
-        dgpre = g("obs.dgpre", (T, B, 3 * De))
-        dx1pre = g("obs.dx1pre", (T, B, Hd))
-        fuse_carry = _FUSE_CARRY
-        # row operations in the prologue of the few-row GEMM that consumes them (csrc/scanops.hip): 5 launches per step
-        fuse_row = (_FUSE_SCAN_ROW and _FUSE_SCAN_LNBWD and B <= 64 and ops.scan_lnbwd_gemm_ok(Hd, De)
-                    and ops.scan_lnbwd_gemm_ok(Hd, SD))
-        fuse_cs = (_FUSE_SCAN_ROW and _FUSE_SCAN_CS and B <= 64 and fuse_carry and ops.scan_carry_st_gemm_ok(S, D, Hd))
-        # (the fused first launch re-reads its inputs from every column tile: the finished logit gradient goes to its
-        # own buffer instead of in place)
-        dpl_out = g("obs.dpl_out", (T, B, S, D)) if fuse_cs else dpost_logit
-        # (measured, world-model update: cfg 2 (De 512, 16 rows) 10.30 -> 10.15 ms; cfg 3 (De 1024, 32 rows) 17.19 -> 17.48:
-        # 288 workgroups x 2 row blocks each re-reading 192 KB of factors -- the wide cell keeps its own launch)
-        fuse_gru = (_FUSE_SCAN_ROW and _FUSE_SCAN_GRUBWD and B <= 32 and De <= 512
-                    and ops.scan_grubwd_gemm_ok(De, Hd + De))
-        if fuse_gru:
-            # ... and the GRU cell's backward: every transcendental factor for all steps in one launch
-            xhg, afg = g("obs.xhg", (T, B, 3 * De)), g("obs.afg", (T, B, 3 * De))
-            p1g, p2g, ahg = g("obs.p1g", (T, B, De)), g("obs.p2g", (T, B, De)), g("obs.ahg", (T, B, De))
-            ops.scan_gru_factors(v2(gpre, 3 * De), P.gru.g, P.gru.b, v2(din, De), mg.view(TB), rg.view(TB), xhg, afg, p1g,
-                                 p2g, ahg)
-        if fuse_row:
-            # what the two LayerNorm + SiLU backward prologues need from the forward pass, for all steps at once
-            xh3, jc3 = g("obs.xh3", (T, B, Hd)), g("obs.jc3", (T, B, Hd))
-            xh1, jc1 = g("obs.xh1", (T, B, Hd)), g("obs.jc1", (T, B, Hd))
-            ops.scan_ln_factors(v2(x3pre, Hd), P.obs_out.g, P.obs_out.b, m3.view(TB), r3.view(TB), xh3, jc3)
-            ops.scan_ln_factors(v2(x1pre, Hd), P.img_in.g, P.img_in.b, m1.view(TB), r1.view(TB), xh1, jc1)
-        for t in reversed(range(T)):
-            gs_t, gd_t = gs[t], gd[t]  # already hold the carry from step t+1 (folded in by obs_blend_bwd)
-            dx1, ddin = dxd[t][:, :Hd], dxd[t][:, Hd:]
-            if fuse_cs:
-                # the carry out of step t+1, this step's straight-through gradient and dx3 += dlogit W_obs
-                carry = None if t == T - 1 else (dsin[t + 1], dxd[t + 1][:, Hd:], first[t + 1], gd_t, dstoch0, ddeter0)
-                ops.scan_carry_st_gemm(gs_t.view(B, SD), post_logit[t], dpost_logit[t], dpl_out[t], P.obs.W, dx3[t],
-                                       unimix=self.unimix, carry=carry)
-            else:
-                if t == T - 1 or not fuse_carry:  # (otherwise done by step t+1's fused carry + straight-through launch)
-                    ops.onehot_st_bwd(post_logit[t], gs_t.view(B, S, D), dpost_logit[t], unimix=self.unimix,
-                                      accumulate=True)
-                ops.gemm(dpost_logit[t].view(B, SD), P.obs.W, dx3[t], transB=False, accumulate="atomic")
-            if fuse_row:
-                ops.scan_lnbwd_gemm(dx3[t], xh3[t], jc3[t], P.obs_out.g, r3[t], dx3pre[t], P.obs_out.W[:, :De], gd_t,
-                                    _g(P.obs_out.g), _g(P.obs_out.b))
-            else:
-                dense_ln_bwd_pre(P.obs_out, dx3[t], x3pre[t], m3[t], r3[t], dx3pre[t], wgrad=True)
-                ops.gemm(dx3pre[t], P.obs_out.W[:, :De], gd_t, transB=False, accumulate="atomic")
+        with side.chain():  # (lanes: on the scan lane, beside the deferred launches on the side lane)
+            # ---- reverse scan
+            # Every GEMM of the reverse scan ACCUMULATES into buffers zeroed here in bulk: a few-row GEMM with
+            # accumulate="atomic" may split K over workgroups (atomics onto C), which is what fills the chip at B rows.  The two
+            # data gradients of the GRU matmul share one GEMM: dxd[t] = [dx1 | ddin], whose right half gru_bwd
+            # pre-loads with the direct dh path.
+            dx3, dxd, dsin, dstoch0, ddeter0 = ws.zeros_many(
+                "obs.zeroed", [(T, B, Hd), (T, B, Hd + De), (T, B, SD), (SD,), (De,)])
+            dx3pre = g("obs.dx3pre", (T, B, Hd))
+            dgpre = g("obs.dgpre", (T, B, 3 * De))
+            dx1pre = g("obs.dx1pre", (T, B, Hd))
+            fuse_carry = _FUSE_CARRY
+            # row operations in the prologue of the few-row GEMM that consumes them (csrc/scanops.hip): 5 launches per step
+            fuse_row = (_FUSE_SCAN_ROW and _FUSE_SCAN_LNBWD and B <= 64 and ops.scan_lnbwd_gemm_ok(Hd, De)
+                        and ops.scan_lnbwd_gemm_ok(Hd, SD))
+            fuse_cs = (_FUSE_SCAN_ROW and _FUSE_SCAN_CS and B <= 64 and fuse_carry and ops.scan_carry_st_gemm_ok(S, D, Hd))
+            # (the fused first launch re-reads its inputs from every column tile: the finished logit gradient goes to its
+            # own buffer instead of in place)
+            dpl_out = g("obs.dpl_out", (T, B, S, D)) if fuse_cs else dpost_logit
+            # (measured, world-model update: cfg 2 (De 512, 16 rows) 10.30 -> 10.15 ms; cfg 3 (De 1024, 32 rows) 17.19 -> 17.48:
+            # 288 workgroups x 2 row blocks each re-reading 192 KB of factors -- the wide cell keeps its own launch)
+            fuse_gru = (_FUSE_SCAN_ROW and _FUSE_SCAN_GRUBWD and B <= 32 and De <= 512
+                        and ops.scan_grubwd_gemm_ok(De, Hd + De))
             if fuse_gru:
-                ops.scan_grubwd_gemm(gd_t, xhg[t], afg[t], p1g[t], p2g[t], ahg[t], P.gru.g, rg[t], dgpre[t], ddin, P.gru.W,
-                                     dxd[t], _g(P.gru.g), _g(P.gru.b))
-            else:
-                ops.gru_bwd(gd_t, gpre[t], P.gru.g, P.gru.b, din[t], mg[t], rg[t], dgpre[t], ddin, _g(P.gru.g),
-                            _g(P.gru.b))
-                ops.gemm(dgpre[t], P.gru.W, dxd[t], transB=False, accumulate="atomic")
+                # ... and the GRU cell's backward: every transcendental factor for all steps in one launch
+                xhg, afg = g("obs.xhg", (T, B, 3 * De)), g("obs.afg", (T, B, 3 * De))
+                p1g, p2g, ahg = g("obs.p1g", (T, B, De)), g("obs.p2g", (T, B, De)), g("obs.ahg", (T, B, De))
+                ops.scan_gru_factors(v2(gpre, 3 * De), P.gru.g, P.gru.b, v2(din, De), mg.view(TB), rg.view(TB), xhg, afg, p1g,
+                                     p2g, ahg)
             if fuse_row:
-                ops.scan_lnbwd_gemm(dx1, xh1[t], jc1[t], P.img_in.g, r1[t], dx1pre[t], P.img_in.W[:, :SD], dsin[t],
-                                    _g(P.img_in.g), _g(P.img_in.b))
-            else:
-                dense_ln_bwd_pre(P.img_in, dx1, x1pre[t], m1[t], r1[t], dx1pre[t], wgrad=True)
-                ops.gemm(dx1pre[t], P.img_in.W[:, :SD], dsin[t], transB=False, accumulate="atomic")
-            if fuse_cs:
-                if t == 0:
-                    ops.obs_blend_bwd(dsin[0], ddin, first[0], None, None, dstoch0, ddeter0)
-            elif fuse_carry and t > 0:
-                ops.obs_carry_st_bwd(dsin[t], ddin, first[t], gs[t - 1], gd[t - 1], dstoch0, ddeter0, post_logit[t - 1],
-                                     dpost_logit[t - 1], unimix=self.unimix)
-            else:
-                ops.obs_blend_bwd(dsin[t], ddin, first[t], gs[t - 1] if t > 0 else None,
-                                  gd[t - 1] if t > 0 else None, dstoch0, ddeter0)
-        # ---- the encoder-output gradient (critical path) and, beside it, the batched weight gradients
+                # what the two LayerNorm + SiLU backward prologues need from the forward pass, for all steps at once
+                xh3, jc3 = g("obs.xh3", (T, B, Hd)), g("obs.jc3", (T, B, Hd))
+                xh1, jc1 = g("obs.xh1", (T, B, Hd)), g("obs.jc1", (T, B, Hd))
+                ops.scan_ln_factors(v2(x3pre, Hd), P.obs_out.g, P.obs_out.b, m3.view(TB), r3.view(TB), xh3, jc3)
+                ops.scan_ln_factors(v2(x1pre, Hd), P.img_in.g, P.img_in.b, m1.view(TB), r1.view(TB), xh1, jc1)
+            for t in reversed(range(T)):
+                gs_t, gd_t = gs[t], gd[t]  # already hold the carry from step t+1 (folded in by obs_blend_bwd)
+                dx1, ddin = dxd[t][:, :Hd], dxd[t][:, Hd:]
+                if fuse_cs:
+                    # the carry out of step t+1, this step's straight-through gradient and dx3 += dlogit W_obs
+                    carry = None if t == T - 1 else (dsin[t + 1], dxd[t + 1][:, Hd:], first[t + 1], gd_t, dstoch0, ddeter0)
+                    ops.scan_carry_st_gemm(gs_t.view(B, SD), post_logit[t], dpost_logit[t], dpl_out[t], P.obs.W, dx3[t],
+                                           unimix=self.unimix, carry=carry)
+                else:
+                    if t == T - 1 or not fuse_carry:  # (otherwise done by step t+1's fused carry + straight-through launch)
+                        ops.onehot_st_bwd(post_logit[t], gs_t.view(B, S, D), dpost_logit[t], unimix=self.unimix,
+                                          accumulate=True)
+                    ops.gemm(dpost_logit[t].view(B, SD), P.obs.W, dx3[t], transB=False, accumulate="atomic")
+                if fuse_row:
+                    ops.scan_lnbwd_gemm(dx3[t], xh3[t], jc3[t], P.obs_out.g, r3[t], dx3pre[t], P.obs_out.W[:, :De], gd_t,
+                                        _g(P.obs_out.g), _g(P.obs_out.b))
+                else:
+                    dense_ln_bwd_pre(P.obs_out, dx3[t], x3pre[t], m3[t], r3[t], dx3pre[t], wgrad=True)
+                    ops.gemm(dx3pre[t], P.obs_out.W[:, :De], gd_t, transB=False, accumulate="atomic")
+                if fuse_gru:
+                    ops.scan_grubwd_gemm(gd_t, xhg[t], afg[t], p1g[t], p2g[t], ahg[t], P.gru.g, rg[t], dgpre[t], ddin, P.gru.W,
+                                         dxd[t], _g(P.gru.g), _g(P.gru.b))
+                else:
+                    ops.gru_bwd(gd_t, gpre[t], P.gru.g, P.gru.b, din[t], mg[t], rg[t], dgpre[t], ddin, _g(P.gru.g),
+                                _g(P.gru.b))
+                    ops.gemm(dgpre[t], P.gru.W, dxd[t], transB=False, accumulate="atomic")
+                if fuse_row:
+                    ops.scan_lnbwd_gemm(dx1, xh1[t], jc1[t], P.img_in.g, r1[t], dx1pre[t], P.img_in.W[:, :SD], dsin[t],
+                                        _g(P.img_in.g), _g(P.img_in.b))
+                else:
+                    dense_ln_bwd_pre(P.img_in, dx1, x1pre[t], m1[t], r1[t], dx1pre[t], wgrad=True)
+                    ops.gemm(dx1pre[t], P.img_in.W[:, :SD], dsin[t], transB=False, accumulate="atomic")
+                if fuse_cs:
+                    if t == 0:
+                        ops.obs_blend_bwd(dsin[0], ddin, first[0], None, None, dstoch0, ddeter0)
+                elif fuse_carry and t > 0:
+                    ops.obs_carry_st_bwd(dsin[t], ddin, first[t], gs[t - 1], gd[t - 1], dstoch0, ddeter0, post_logit[t - 1],
+                                         dpost_logit[t - 1], unimix=self.unimix)
+                else:
+                    ops.obs_blend_bwd(dsin[t], ddin, first[t], gs[t - 1] if t > 0 else None,
+                                      gd[t - 1] if t > 0 else None, dstoch0, ddeter0)
+            # ---- the encoder-output gradient (critical path) and, beside it, the batched weight gradients
         side.join()  # the init-state backward below adds into the same prior-head gradients
         ops.gemm(v2(dx3pre, Hd), P.obs_out.W[:, De:], v2(dembed, E), transB=False)
         dpl = v2(dpl_out, SD)
@@ -613,7 +754,7 @@ class RSSMEngine:
             lin_wgrad(P.img_in.W, v2(dx1pre, Hd), v2(sin, SD), v2(ain, A))
             self.init_state_bwd(dstoch0, ddeter0)
 
-        side.run([_scan_wgrads])  # beside the encoder backward the caller launches next
+        side.run([_scan_wgrads], chain=False)  # (plain second stream: beside the encoder backward the caller launches next)
         return side
 
     # -- one img_step on a row block (networks.py:208-233), used by the policy path and imagine ---------

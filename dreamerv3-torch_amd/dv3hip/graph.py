@@ -15,7 +15,7 @@ from typing import Dict
 
 import torch
 
-from . import _lib, ops
+from . import _dev, _lib, ops
 
 
 class CaptureRefused(RuntimeError):
@@ -38,6 +38,117 @@ def _capture(graph, fn, **kw):
         raise
 
 
+class SegmentRecorder:
+    """Capture of one phase as a SEQUENCE of graphs, one per lane (engine.Lanes): [main] -> fork -> [side] | [scan] ->
+    join -> [main] ...  The code being captured calls cut(lane) where the lane changes (engine.SideStream does); each
+    segment is an ordinary single-stream capture, on the lane's own CU-masked stream for "side" / "scan", so that its
+    kernels are dispatched by that stream's hardware queue when the graph is launched there."""
+
+    def __init__(self, pool, device):
+        from . import engine
+
+        self.pool, self.device = pool, device
+        self.lanes = engine.Lanes.get(device)
+        self.segments = []  # (lane, graph)
+        self._cur = None
+        self._flat = _dev.flag("DV3_LANES_FLAT", False)  # dev: the same cuts, every segment on the caller's stream
+        self._late_fork = _dev.flag("DV3_LANES_LATE_FORK", True)
+        self._mark = torch.cuda.Event()
+
+    def _begin(self, lane):
+        if self._flat:
+            lane = "main"
+        g = torch.cuda.CUDAGraph()
+        kw = dict(pool=self.pool, capture_error_mode="thread_local")
+        if lane != "main":
+            kw["stream"] = self.lanes.streams[lane]
+        ctx = torch.cuda.graph(g, **kw)
+        ctx.__enter__()
+        self._cur = (lane, g, ctx)
+
+    def _end(self, *exc):
+        lane, g, ctx = self._cur
+        self._cur = None
+        ctx.__exit__(*(exc or (None, None, None)))
+        if not exc or exc[0] is None:
+            self.segments.append((lane, g))
+
+    def cut(self, lane):
+        self._end()
+        self._begin(lane)
+
+    def sync_point(self):
+        """The host holds back the lane segments that follow until the GPU has got here (see replay)."""
+        if any(lane == "sync" for lane, _ in self.segments):
+            return
+        self._end()
+        self.segments.append(("sync", None))
+        self._begin("main")
+
+    def record(self, fn):
+        from . import engine
+
+        prev = engine.SideStream.recorder
+        engine.SideStream.recorder = self
+        try:
+            self._begin("main")
+            try:
+                fn()
+            except BaseException as e:
+                if self._cur is not None:
+                    try:
+                        self._end(type(e), e, e.__traceback__)
+                    except Exception:  # the capture is already broken: the first error is the one to report
+                        pass
+                raise
+            self._end()
+        except _lib.DV3Error:
+            raise
+        except RuntimeError as e:
+            msg = str(e).lower()
+            if "captur" in msg or "graph" in msg:
+                raise CaptureRefused(f"{type(e).__name__}: {e}") from e
+            raise
+        finally:
+            engine.SideStream.recorder = prev
+        return self
+
+    def replay(self):
+        """Launch the segments: consecutive lane segments run side by side, a "main" segment waits for them.
+
+        A lane segment is NOT put on its queue while the main stream is still far from the fork: a queue whose head is a
+        blocked barrier packet costs the other queue ~1.3 us per dependent launch (MI355X, r03: the segment in front of
+        the fork 5.87 ms with the lanes already waiting, 5.35 without -- more than the overlap returns).  So the host
+        waits at the "sync" mark (after the forward scan; the chip-filling decoder / head launches that follow give it
+        ~2 ms to put the lanes in place) before it launches them.  This is the one place where the update call blocks
+        the host; the reference's update reads its metrics back on every call (models.py:158-168)."""
+        cur = torch.cuda.current_stream(self.device)
+        forked = []
+        mark = None
+        for lane, g in self.segments:
+            if lane == "sync":
+                if self._late_fork:
+                    mark = self._mark
+                    mark.record(cur)
+                continue
+            if lane != "main" and mark is not None:
+                mark.synchronize()
+                mark = None
+            if lane == "main":
+                for s in forked:
+                    cur.wait_stream(s)
+                forked = []
+                g.replay()
+            else:
+                s = self.lanes.streams[lane]
+                s.wait_stream(cur)  # nothing has been put on `cur` since the fork point
+                with torch.cuda.stream(s):
+                    g.replay()
+                forked.append(s)
+        for s in forked:
+            cur.wait_stream(s)
+
+
 class UpdateRunner:
     def __init__(self, wm, beh, use_graph: bool = True, warm: int = 2):
         self.wm, self.beh = wm, beh
@@ -47,6 +158,7 @@ class UpdateRunner:
         self._calls = 0
         self._static: Dict[str, torch.Tensor] = {}
         self._graphs = None
+        self._stream = None
         self.last_metrics = {}
         self.last_post = self.last_context = self.last_data = None  # what a further behaviour (Plan2Explore) trains on
 
@@ -67,12 +179,15 @@ class UpdateRunner:
 
     def _capture(self):
         wm, beh = self.wm, self.beh
-        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         pool = torch.cuda.graph_pool_handle()
         # (capture_error_mode thread_local: with a process group alive, RCCL's watchdog thread polls events while we
         # capture; the default global mode would treat that as a capture violation)
         res = {}
-        _capture(g1, lambda: wm.train_fwd_bwd(self._static), pool=pool)
+        # the world model's segment is a sequence of graphs: its reverse scan and the weight gradients that nothing reads
+        # before the optimizer run on two CU-masked lanes (engine.Lanes), everything else on the whole chip
+        dev = next(iter(self._static.values())).device
+        g1 = SegmentRecorder(pool, dev).record(lambda: wm.train_fwd_bwd(self._static))
         wm._model_opt.bucket.allreduce()
 
         def seg2():
@@ -89,7 +204,27 @@ class UpdateRunner:
         self.last_post, self.last_context, self.last_data = res["post"], res["ctx"], self._static
 
     def step(self, data, eager: bool = False):
-        """data: dict of device tensors (image uint8 [B,T,64,64,3], action, reward, is_first, is_terminal ...)."""
+        """data: dict of device tensors (image uint8 [B,T,64,64,3], action, reward, is_first, is_terminal ...).
+
+        Stream-ordered with the caller's current stream.  When that is the NULL stream the update itself runs on a stream
+        of the runner's own: the CU-masked lanes are blocking streams, and beside work on the NULL stream (which
+        synchronises with every blocking stream at every launch) the update took 18.4 ms instead of 16.3."""
+        from . import engine
+
+        cur = torch.cuda.current_stream()
+        own = (engine.SideStream.lanes and not engine.SideStream.plain and cur == torch.cuda.default_stream(cur.device)
+               and _dev.flag("DV3_RUNNER_OWN_STREAM", True))
+        if not own:
+            return self._step(data, eager)
+        if self._stream is None:
+            self._stream = engine.Lanes.get(cur.device).whole_chip_stream()
+        # a BLOCKING stream: HIP orders it with the NULL stream by itself (its launches wait for earlier NULL-stream work,
+        # later NULL-stream launches wait for it), and only when such work exists -- an explicit wait_stream pair would
+        # leave a blocked barrier packet at the head of the NULL queue for the whole update (measured: 17.3 ms vs 16.4)
+        with torch.cuda.stream(self._stream):
+            self._step(data, eager)
+
+    def _step(self, data, eager):
         self._calls += 1
         if eager or not self.use_graph or self._calls <= self.warm:
             self._eager(data)

@@ -215,6 +215,7 @@ class WorldModel(nn.Module):
         kl = ws.get("wm.kl", (T, B))
         ent_p, ent_q = ws.get("wm.ent_post", (T, B)), ws.get("wm.ent_prior", (T, B))
         ops.kl_fwd(out["post_logit"], out["prior_logit"], kl, ent_p, ent_q, unimix=dyn._unimix_ratio)
+        E.SideStream.host_sync_point()  # (captured update: the lanes of the reverse scan are launched once the GPU is here)
 
         # ---- heads, losses and their upstream gradients (loss = mean over B*T of the per-row sum)
         up = 1.0 / TB
@@ -734,7 +735,7 @@ class ImagBehavior(nn.Module):
             veng.backward(fs[:R], fd[:R], slice(0, R), dout=dvl, wgrad=True)
 
         side = E.SideStream(fs.device)
-        side.run([_critic])
+        side.run([_critic], chain=False)  # (what follows fills the chip: in line unless the plain second stream is on)
         # ---- dynamics backprop: target -> reward / cont heads -> imagined states -> actions
         daction = g("bh.daction", (H, N, A))
         if not reinforce:

@@ -434,6 +434,16 @@ int dv3_transpose2d(const float* src, long lds, int R, int C, float* dst, long l
 int dv3_transpose2d_many(int njobs, const unsigned long long* jobs_host, void* stream);
 int dv3_onehot_to_idx(const float* onehot, int* idx, long R, int D, void* stream);
 
+/* ---- compute-unit partitioned streams (csrc/streams.hip) --------------------------------------------------------
+ * The MI355X-native counterpart of nothing in the reference (its update is one stream of ATen launches,
+ * models.py:105-169): the reverse observe scan and the weight gradients that nothing reads before the optimizer run
+ * on two HIP streams whose hardware queues own complementary halves of the compute units.
+ * mask_words: HOST array, bit b of word w = compute unit 32*w + b may be used; stream_out: HOST 64-bit slot that
+ * receives the hipStream_t.  The stream is a blocking stream (it synchronises implicitly with the NULL stream). */
+int dv3_device_cu_count(int* count_out);
+int dv3_stream_create_cu_masked(int n_words, const unsigned int* mask_words, unsigned long long* stream_out);
+int dv3_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -445,6 +445,103 @@ def test_graph_replay_matches_eager_and_trains(name):
     close(w1, w0, 1e-4, "learned initial state after 4 updates")
 
 
+def _wm_gradients(name, mode, seed=11):
+    """Gradient bucket of one world-model forward/backward at `name`, launched `mode`: "inline" (no lanes), "lanes"
+    (eager, the reverse scan and the deferred weight gradients on the two CU-masked streams) or "segments" (the same cut
+    into one hipGraph per lane and replayed twice -- the second replay must overwrite, not accumulate)."""
+    import tools
+    from dv3hip import engine as E
+    from dv3hip.graph import SegmentRecorder
+
+    cfg, wm, beh = Hh.build_models(name)
+    data = {k: torch.from_numpy(v).cuda() for k, v in common.make_batch(name).items()}
+    s = common.SHAPES[name]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    shape = (s["T"], s["B"], s["stoch"], s["discrete"])
+    noise = dict(q_prior=torch.empty(shape).exponential_(1.0, generator=g).clamp_min(1e-20).cuda(),
+                 q_post=torch.empty(shape).exponential_(1.0, generator=g).clamp_min(1e-20).cuda())
+    tools.default_rng("cuda:0", seed=seed)
+    saved = E.SideStream.lanes
+    E.SideStream.lanes = mode != "inline"
+    try:
+        run = lambda: wm.train_fwd_bwd(data, noise=noise)
+        run()  # (also the warm call of the captured variant: workspaces exist before capture)
+        if mode == "segments":
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                torch.cuda.synchronize()
+                rec = SegmentRecorder(torch.cuda.graph_pool_handle(), torch.device("cuda:0")).record(run)
+                lanes = [lane for lane, _ in rec.segments]
+                assert lanes == ["main", "sync", "main", "side", "scan", "main"], lanes
+                rec.replay()
+                rec.replay()
+        torch.cuda.synchronize()
+    finally:
+        E.SideStream.lanes = saved
+    post = wm._pending[0]
+    return wm._model_opt.bucket.grad.clone(), post["stoch"].clone(), float(wm._pending[3])
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg1"])
+def test_cu_lanes_compute_what_the_inline_sequence_computes(name):
+    """The reverse observe scan beside the deferred weight gradients on two CU-masked streams (engine.Lanes), eagerly and
+    as one hipGraph per lane (graph.SegmentRecorder), against the same launches in line on one stream: same samples,
+    same loss, gradients equal up to the summation order of the scan's atomic accumulations (which differs between two
+    inline runs as well)."""
+    g0, s0, l0 = _wm_gradients(name, "inline")
+    scale = float(g0.abs().max())
+    for mode in ("lanes", "segments"):
+        g1, s1, l1 = _wm_gradients(name, mode)
+        assert torch.equal(s0, s1), f"{mode}: sampled states differ"
+        assert abs(l0 - l1) <= 1e-6 * abs(l0), (mode, l0, l1)
+        err = float((g0 - g1).abs().max())
+        assert err <= 2e-6 * scale, f"{mode}: gradient differs by {err:.3e} (max |g| {scale:.3e})"
+
+
+def test_cu_masked_stream_restricts_a_launch_to_its_compute_units():
+    """dv3_stream_create_cu_masked: a chip-filling product on a stream that owns half of the CUs takes about twice as
+    long as on the whole chip, launched eagerly and from a hipGraph replayed on that stream (the mask belongs to the
+    queue the graph is launched on)."""
+    from dv3hip import engine as E
+    from dv3hip import ops
+
+    ln = E.Lanes.get("cuda:0")
+    assert ln.cus["scan"] + ln.cus["side"] == ln.cus["whole"] == torch.cuda.get_device_properties(0).multi_processor_count
+    A = torch.randn(4096, 2048, device="cuda")
+    B = torch.randn(4096, 2048, device="cuda")
+    C = torch.empty(4096, 4096, device="cuda")
+
+    def work():
+        for _ in range(4):
+            ops.gemm(A, B, C, transB=True)
+
+    def timed(fn, stream):
+        best = 1e9
+        with torch.cuda.stream(stream):
+            for _ in range(4):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                a.record()
+                fn()
+                b.record()
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b))
+        return best
+
+    whole = timed(work, ln.streams["whole"])
+    half = timed(work, ln.streams["side"])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=ln.streams["side"]):
+        work()
+    half_graph = timed(g.replay, ln.streams["side"])
+    whole_graph = timed(g.replay, ln.streams["whole"])
+    ratio = ln.cus["whole"] / ln.cus["side"]
+    for label, t, ref in (("eager", half, whole), ("graph", half_graph, whole_graph)):
+        assert 0.75 * ratio <= t / ref <= 1.35 * ratio, f"{label}: {t:.3f} ms on {ln.cus['side']} CUs vs {ref:.3f} ms on all"
+    ref = A @ B.T
+    assert float((C - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
+
+
 # ------------------------------------------------------------------------------------------------------
 # BASELINE cfg 4 (dmc_vision, crafter-size model: deter 4096, hidden / units 1024, cnn_depth 96, batch 64 x 64) and
 # cfg 5 (crafter: deter 2048, five-layer heads, 17-way one-hot actor, reinforce, sequence length 256; the per-GPU shard

@@ -18,23 +18,103 @@ from tests.golden import common  # noqa: E402
 
 
 def replay_ms(fn, reps=10):
-    """Median device time of fn's launch sequence replayed from a hipGraph."""
+    """Median device time of fn's launch sequence replayed from hipGraphs (one per lane segment, as UpdateRunner does)."""
+    from dv3hip.graph import SegmentRecorder
+
     st = torch.cuda.Stream()
-    g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(st):
-        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
-            fn()
-    g.replay()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        g.replay()
-        b.record()
+        rec = SegmentRecorder(torch.cuda.graph_pool_handle(), torch.device("cuda", torch.cuda.current_device())).record(fn)
+        rec.replay()
         torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b))
-    ts.sort()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rec.replay()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        ts.sort()
+        # each segment alone, on its own lane
+        parts = []
+        for lane, g in rec.segments:
+            if lane == "sync":
+                continue
+            s_ = st if lane == "main" else rec.lanes.streams[lane]
+            tt = []
+            for _ in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                with torch.cuda.stream(s_):
+                    a.record()
+                    g.replay()
+                    b.record()
+                torch.cuda.synchronize()
+                tt.append(a.elapsed_time(b))
+            parts.append(f"{lane} {sorted(tt)[2]:.3f}")
+        # timeline of one full replay: start / end of every segment relative to the first launch
+        tl = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            marks, forked = [], []
+            mark = None
+            for lane, g in rec.segments:
+                if lane == "sync":
+                    if rec._late_fork:
+                        mark = torch.cuda.Event()
+                        mark.record()
+                    continue
+                if lane != "main" and mark is not None:
+                    mark.synchronize()
+                    mark = None
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if lane == "main":
+                    for s_ in forked:
+                        st.wait_stream(s_)
+                    forked = []
+                    a.record()
+                    g.replay()
+                    b.record()
+                else:
+                    s_ = rec.lanes.streams[lane]
+                    s_.wait_stream(st)
+                    with torch.cuda.stream(s_):
+                        a.record()
+                        g.replay()
+                        b.record()
+                    forked.append(s_)
+                marks.append((lane, a, b))
+            torch.cuda.synchronize()
+            tl.append([(lane, e0.elapsed_time(a), e0.elapsed_time(b)) for lane, a, b in marks])
+        tl.sort(key=lambda m: m[-1][2])
+        print("timeline (ms):", ", ".join(f"{lane} {a:.3f}-{b:.3f}" for lane, a, b in tl[2]))
+        lanes_ = [(lane, g) for lane, g in rec.segments if lane not in ("main", "sync")]
+        if len(lanes_) == 2:
+            # the two lane segments side by side: each one's own duration and the pair's
+            res = []
+            for _ in range(5):
+                ev = {k: torch.cuda.Event(enable_timing=True) for k in ("f", "j", "a0", "b0", "a1", "b1")}
+                torch.cuda.synchronize()
+                ev["f"].record()
+                for i, (lane, g) in enumerate(lanes_):
+                    s_ = rec.lanes.streams[lane]
+                    s_.wait_stream(st)
+                    with torch.cuda.stream(s_):
+                        ev[f"a{i}"].record()
+                        g.replay()
+                        ev[f"b{i}"].record()
+                for lane, g in lanes_:
+                    st.wait_stream(rec.lanes.streams[lane])
+                ev["j"].record()
+                torch.cuda.synchronize()
+                res.append((ev["f"].elapsed_time(ev["j"]), ev["a0"].elapsed_time(ev["b0"]), ev["a1"].elapsed_time(ev["b1"]),
+                            ev["f"].elapsed_time(ev["a1"])))
+            res.sort()
+            r = res[2]
+            parts.append(f"| pair {r[0]:.3f} ({lanes_[0][0]} {r[1]:.3f}, {lanes_[1][0]} {r[2]:.3f}, second starts at +{r[3]:.3f})")
+    print("segments alone (ms):", ", ".join(parts), f"| lanes: {rec.lanes.cus}")
     return ts[len(ts) // 2]
 
 
