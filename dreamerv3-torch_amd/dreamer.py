@@ -132,8 +132,10 @@ class Dreamer(nn.Module):
                                         use_graph=bool(getattr(self._config, "hip_graph", True)))
             self._stager = BatchStager(self._config.device)
         host = all(not isinstance(v, torch.Tensor) for v in data.values())
-        self._runner.step(self._stager.stage(data) if host else
-                          {k: (v if k == "image" else v.to(torch.float32)) for k, v in data.items()})
+        # (the uploads go onto the stream the update is issued on; see UpdateRunner.launch_stream)
+        with torch.cuda.stream(self._runner.launch_stream() or torch.cuda.current_stream()):
+            self._runner.step(self._stager.stage(data) if host else
+                              {k: (v if k == "image" else v.to(torch.float32)) for k, v in data.items()})
         mets = dict(self._runner.last_metrics)
         if self._expl_behavior is not self._task_behavior:
             # dreamer.py:201-203: the explorer trains on the same posterior states (eagerly: its objective runs torch

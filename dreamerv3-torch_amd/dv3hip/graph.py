@@ -209,20 +209,27 @@ class UpdateRunner:
         Stream-ordered with the caller's current stream.  When that is the NULL stream the update itself runs on a stream
         of the runner's own: the CU-masked lanes are blocking streams, and beside work on the NULL stream (which
         synchronises with every blocking stream at every launch) the update took 18.4 ms instead of 16.3."""
-        from . import engine
-
-        cur = torch.cuda.current_stream()
-        own = (engine.SideStream.lanes and not engine.SideStream.plain and cur == torch.cuda.default_stream(cur.device)
-               and _dev.flag("DV3_RUNNER_OWN_STREAM", True))
-        if not own:
+        s = self.launch_stream()
+        if s is None:
             return self._step(data, eager)
-        if self._stream is None:
-            self._stream = engine.Lanes.get(cur.device).whole_chip_stream()
+        self._stream = s
         # a BLOCKING stream: HIP orders it with the NULL stream by itself (its launches wait for earlier NULL-stream work,
         # later NULL-stream launches wait for it), and only when such work exists -- an explicit wait_stream pair would
         # leave a blocked barrier packet at the head of the NULL queue for the whole update (measured: 17.3 ms vs 16.4)
         with torch.cuda.stream(self._stream):
             self._step(data, eager)
+
+    def launch_stream(self):
+        """The stream step() will issue the update on when the caller's current stream is the NULL stream (None
+        otherwise: the current stream itself).  Work that feeds the update (BatchStager uploads) belongs on the same
+        stream -- `with torch.cuda.stream(runner.launch_stream() or torch.cuda.current_stream()): ...` -- so that no
+        second queue sits blocked beside the update's dependent launches."""
+        from . import engine
+
+        cur = torch.cuda.current_stream()
+        own = (engine.SideStream.lanes and not engine.SideStream.plain and cur == torch.cuda.default_stream(cur.device)
+               and _dev.flag("DV3_RUNNER_OWN_STREAM", True))
+        return engine.Lanes.get(cur.device).whole_chip_stream() if own else None
 
     def _step(self, data, eager):
         self._calls += 1
