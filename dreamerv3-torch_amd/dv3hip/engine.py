@@ -82,6 +82,12 @@ class Lanes:
             # mask's bits run XCD-major or XCD-interleaved
             groups, want = n_cu // 8, scan_cus // 8
             scan_bits = [((g + 1) * want) // groups != (g * want) // groups for g in range(groups)]
+            pattern = _dev.value("DV3_LANES_PATTERN", "group8", str)
+            if pattern == "low":  # dev: the scan lane owns the lowest mask bits (whole XCDs if the bits run XCD-major)
+                scan_bits = [g < want for g in range(groups)]
+            per_bit = None
+            if pattern == "mod8":  # dev: ... the bits with the lowest (bit % 8) (whole XCDs if the bits run XCD-interleaved)
+                per_bit = [(i % 8) < (8 * want) // groups for i in range(n_cu)]
             words = (n_cu + 31) // 32
             self.cus = {"scan": 8 * sum(scan_bits), "side": n_cu - 8 * sum(scan_bits), "whole": n_cu}
             self._handles, self.streams = {}, {}
@@ -89,7 +95,8 @@ class Lanes:
                 mask = (ctypes.c_uint32 * words)()
                 for i in range(n_cu):
                     g = i // 8
-                    mine = lane == "whole" or (scan_bits[g] if g < groups else False) == (lane == "scan")
+                    in_scan = per_bit[i] if per_bit is not None else (scan_bits[g] if g < groups else False)
+                    mine = lane == "whole" or in_scan == (lane == "scan")
                     if mine:
                         mask[i // 32] |= 1 << (i % 32)
                 out = ctypes.c_ulonglong()

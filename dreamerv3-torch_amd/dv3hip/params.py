@@ -13,7 +13,10 @@ from typing import Iterable, List
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _dev, ops
+
+# dev: issue the collective on a one-rank process group too (rehearses the stream topology of N > 1 on one GPU)
+_FORCE_ALLREDUCE = _dev.flag("DV3_FORCE_ALLREDUCE", False)
 
 _ALIGN = 4  # floats: keep every tensor 16-byte aligned inside the bucket
 
@@ -75,7 +78,7 @@ class ParamBucket:
     def allreduce(self) -> float:
         """Sum gradients over ranks (RCCL when the process group is NCCL); returns the scale (1/world)
         the optimizer must apply.  No-op on a single rank."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_ALLREDUCE):
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
             return 1.0 / dist.get_world_size()
         return 1.0

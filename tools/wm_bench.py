@@ -21,7 +21,11 @@ def replay_ms(fn, reps=10):
     """Median device time of fn's launch sequence replayed from hipGraphs (one per lane segment, as UpdateRunner does)."""
     from dv3hip.graph import SegmentRecorder
 
-    st = torch.cuda.Stream()
+    from dv3hip import engine
+
+    # main stream of the replays: the runner's blocking whole-chip stream (WM_MAIN=torch: a plain torch stream)
+    st = (torch.cuda.Stream() if os.environ.get("WM_MAIN") == "torch"
+          else engine.Lanes.get(torch.device("cuda", torch.cuda.current_device())).whole_chip_stream())
     with torch.cuda.stream(st):
         rec = SegmentRecorder(torch.cuda.graph_pool_handle(), torch.device("cuda", torch.cuda.current_device())).record(fn)
         rec.replay()
