@@ -103,6 +103,25 @@ class Lanes:
                 _lib.check(lib.dv3_stream_create_cu_masked(words, mask, ctypes.byref(out)), "dv3_stream_create_cu_masked")
                 self._handles[lane] = out.value
                 self.streams[lane] = torch.cuda.ExternalStream(out.value, device=device)
+        # the runtime's own teardown of these queues at process exit (static destructors) crashes under rocprofv3: hand them
+        # back while the interpreter is still alive
+        import atexit
+
+        atexit.register(self._destroy)
+
+    def _destroy(self):
+        from . import _lib
+
+        handles, self._handles = self._handles, {}
+        if not handles:
+            return
+        try:
+            torch.cuda.synchronize()
+            lib = _lib.load()
+            for h in handles.values():
+                lib.dv3_stream_destroy(h)
+        except Exception:  # interpreter shutdown: nothing left to report to
+            pass
 
 
     # (Lanes) --------------------------------------------------------------------------------------------------------
