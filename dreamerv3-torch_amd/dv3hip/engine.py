@@ -43,6 +43,7 @@ _FUSE_SCAN_ROW = _dev.flag("DV3_FUSE_SCAN_ROW", True)
 _FUSE_SCAN_LN = _dev.flag("DV3_FUSE_SCAN_LN", True)  # ... forward: obs_out LayerNorm + posterior-logit GEMM
 _FUSE_SCAN_LNBWD = _dev.flag("DV3_FUSE_SCAN_LNBWD", True)  # ... reverse: the two LayerNorm backward + data-gradient GEMMs
 _FUSE_SCAN_CS = _dev.flag("DV3_FUSE_SCAN_CS", True)  # ... reverse: carry + straight-through + logit data-gradient GEMM
+_DEFER_CONV_WGRAD = _dev.flag("DV3_DEFER_CONV_WGRAD", True)  # decoder conv weight gradients beside the reverse scan
 _FUSE_SCAN_GRUBWD = _dev.flag("DV3_FUSE_SCAN_GRUBWD", True)  # ... reverse: GRU cell backward + the data-gradient GEMM of its Linear
 
 
@@ -169,6 +170,13 @@ class SideStream:
         """Marks where a captured update lets the host wait before it launches the lane segments (graph.SegmentRecorder)."""
         if SideStream.recorder is not None and SideStream.lanes and not SideStream.plain:
             SideStream.recorder.sync_point()
+
+    @staticmethod
+    def late_join_point():
+        """Inside chain(): marks where a captured update lets the host wait before it queues the join and what follows it
+        (graph.SegmentRecorder.lane_sync_point)."""
+        if SideStream.recorder is not None and SideStream.lanes and not SideStream.plain:
+            SideStream.recorder.lane_sync_point()
 
     def run(self, fns, chain: bool = True):
         """Run the deferred callables beside what follows.  chain=False: what follows fills the chip itself (the encoder
@@ -727,6 +735,10 @@ class RSSMEngine:
                 ops.scan_ln_factors(v2(x3pre, Hd), P.obs_out.g, P.obs_out.b, m3.view(TB), r3.view(TB), xh3, jc3)
                 ops.scan_ln_factors(v2(x1pre, Hd), P.img_in.g, P.img_in.b, m1.view(TB), r1.view(TB), xh1, jc1)
             for t in reversed(range(T)):
+                if T >= 16 and t == T // 4 - 1:
+                    # (captured update: the join behind the scan is queued once the GPU is here -- a main queue blocked at
+                    # the join costs every launch of the chain ~1.3 us, see graph.SegmentRecorder.replay)
+                    SideStream.late_join_point()
                 gs_t, gd_t = gs[t], gd[t]  # already hold the carry from step t+1 (folded in by obs_blend_bwd)
                 dx1, ddin = dxd[t][:, :Hd], dxd[t][:, Hd:]
                 if fuse_cs:
@@ -1039,7 +1051,7 @@ class ConvDecoderEngine:
                     run(lambda dpre=dpre, L=L, rows=rows, Co=Co: ops.colsum(dpre.view(rows, Co), _g(L.bias),
                                                                          accumulate=True))
             # coarse = layer input, fine = output gradient
-            run(lambda x=x, dpre=dpre, L=L: ops.conv_s2_wgrad(x, dpre, _g(L.W)))
+            (run if _DEFER_CONV_WGRAD else (lambda f: f()))(lambda x=x, dpre=dpre, L=L: ops.conv_s2_wgrad(x, dpre, _g(L.W)))
             dx = ws.get(f"dec.dx{i}", x.shape)
             if Co == 3 and Ci in ops.C3_WIDTHS:
                 ops.conv_s2_c3_fwd(dpre, L.W, dx, CW=Ci)  # ConvTranspose2d weight [Ci,3,4,4] read as its adjoint

@@ -53,6 +53,8 @@ class SegmentRecorder:
         self._cur = None
         self._flat = _dev.flag("DV3_LANES_FLAT", False)  # dev: the same cuts, every segment on the caller's stream
         self._late_fork = _dev.flag("DV3_LANES_LATE_FORK", True)
+        self._late_join = _dev.flag("DV3_LANES_LATE_JOIN", True)
+        self._mark2 = torch.cuda.Event()
         self._mark = torch.cuda.Event()
 
     def _begin(self, lane):
@@ -75,6 +77,16 @@ class SegmentRecorder:
 
     def cut(self, lane):
         self._end()
+        self._begin(lane)
+
+    def lane_sync_point(self):
+        """Inside a lane segment: the host holds back the JOIN (and the main segment behind it) until the lane has got
+        here -- the main queue then sits blocked beside the lane's dependent launches only for the rest of the segment."""
+        if self._cur is None or self._cur[0] == "main" or not self._late_join:
+            return
+        lane = self._cur[0]
+        self._end()
+        self.segments.append(("sync_lane", None))
         self._begin(lane)
 
     def sync_point(self):
@@ -113,40 +125,65 @@ class SegmentRecorder:
             engine.SideStream.recorder = prev
         return self
 
-    def replay(self):
+    def replay(self, trace=None):
         """Launch the segments: consecutive lane segments run side by side, a "main" segment waits for them.
+        trace (tools/wm_bench.py): a list that receives (lane, start event, end event) per segment.
 
         A lane segment is NOT put on its queue while the main stream is still far from the fork: a queue whose head is a
         blocked barrier packet costs the other queue ~1.3 us per dependent launch (MI355X, r03: the segment in front of
         the fork 5.87 ms with the lanes already waiting, 5.35 without -- more than the overlap returns).  So the host
         waits at the "sync" mark (after the forward scan; the chip-filling decoder / head launches that follow give it
         ~2 ms to put the lanes in place) before it launches them.  This is the one place where the update call blocks
-        the host; the reference's update reads its metrics back on every call (models.py:158-168)."""
+        the host; the reference's update reads its metrics back on every call (models.py:158-168).  The same holds the
+        other way round: with the join queued behind the lanes at once, the main queue sits blocked beside the reverse
+        scan's ~260 dependent launches (scan segment 2.16-2.22 ms against 1.81 alone, whatever runs on the side lane),
+        so the scan is cut at three quarters ("sync_lane") and the host queues the join when the GPU is there."""
         cur = torch.cuda.current_stream(self.device)
         forked = []
-        mark = None
+        mark = mark2 = None
+        last = None
         for lane, g in self.segments:
             if lane == "sync":
                 if self._late_fork:
                     mark = self._mark
                     mark.record(cur)
                 continue
+            if lane == "sync_lane":
+                mark2 = self._mark2
+                mark2.record(last)
+                continue
             if lane != "main" and mark is not None:
                 mark.synchronize()
                 mark = None
             if lane == "main":
+                if mark2 is not None:
+                    mark2.synchronize()
+                    mark2 = None
                 for s in forked:
                     cur.wait_stream(s)
                 forked = []
-                g.replay()
+                self._launch(g, cur, lane, trace)
             else:
                 s = self.lanes.streams[lane]
-                s.wait_stream(cur)  # nothing has been put on `cur` since the fork point
+                if s not in forked:
+                    s.wait_stream(cur)  # nothing has been put on `cur` since the fork point
+                    forked.append(s)
                 with torch.cuda.stream(s):
-                    g.replay()
-                forked.append(s)
+                    self._launch(g, s, lane, trace)
+                last = s
         for s in forked:
             cur.wait_stream(s)
+
+    @staticmethod
+    def _launch(g, stream, lane, trace):
+        if trace is None:
+            g.replay()
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        g.replay()
+        b.record(stream)
+        trace.append((lane, a, b))
 
 
 class UpdateRunner:
@@ -251,6 +288,8 @@ class UpdateRunner:
                 return
         g1, g2, g3 = self._graphs
         g1.replay()
+        # (queueing the collectives only once the segment in front is over -- so that RCCL's stream does not sit blocked
+        # beside it -- measured slower under a one-rank RCCL group: 16.43 vs 16.34 ms)
         self.wm._model_opt.bucket.allreduce()
         g2.replay()
         self.beh._actor_opt.bucket.allreduce()

@@ -472,7 +472,7 @@ def _wm_gradients(name, mode, seed=11):
                 torch.cuda.synchronize()
                 rec = SegmentRecorder(torch.cuda.graph_pool_handle(), torch.device("cuda:0")).record(run)
                 lanes = [lane for lane, _ in rec.segments]
-                assert lanes == ["main", "sync", "main", "side", "scan", "main"], lanes
+                assert lanes == ["main", "sync", "main", "side", "scan", "sync_lane", "scan", "main"], lanes
                 rec.replay()
                 rec.replay()
         torch.cuda.synchronize()

@@ -42,7 +42,7 @@ def replay_ms(fn, reps=10):
         # each segment alone, on its own lane
         parts = []
         for lane, g in rec.segments:
-            if lane == "sync":
+            if g is None:
                 continue
             s_ = st if lane == "main" else rec.lanes.streams[lane]
             tt = []
@@ -62,39 +62,13 @@ def replay_ms(fn, reps=10):
             torch.cuda.synchronize()
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            marks, forked = [], []
-            mark = None
-            for lane, g in rec.segments:
-                if lane == "sync":
-                    if rec._late_fork:
-                        mark = torch.cuda.Event()
-                        mark.record()
-                    continue
-                if lane != "main" and mark is not None:
-                    mark.synchronize()
-                    mark = None
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                if lane == "main":
-                    for s_ in forked:
-                        st.wait_stream(s_)
-                    forked = []
-                    a.record()
-                    g.replay()
-                    b.record()
-                else:
-                    s_ = rec.lanes.streams[lane]
-                    s_.wait_stream(st)
-                    with torch.cuda.stream(s_):
-                        a.record()
-                        g.replay()
-                        b.record()
-                    forked.append(s_)
-                marks.append((lane, a, b))
+            marks = []
+            rec.replay(trace=marks)
             torch.cuda.synchronize()
             tl.append([(lane, e0.elapsed_time(a), e0.elapsed_time(b)) for lane, a, b in marks])
         tl.sort(key=lambda m: m[-1][2])
         print("timeline (ms):", ", ".join(f"{lane} {a:.3f}-{b:.3f}" for lane, a, b in tl[2]))
-        lanes_ = [(lane, g) for lane, g in rec.segments if lane not in ("main", "sync")]
+        lanes_ = [(lane, g) for lane, g in rec.segments if lane != "main" and g is not None]
         if len(lanes_) == 2:
             # the two lane segments side by side: each one's own duration and the pair's
             res = []
