@@ -62,10 +62,19 @@ class Lanes:
     _by_dev: Dict[str, "Lanes"] = {}
 
     @classmethod
-    def get(cls, device) -> "Lanes":
+    def get(cls, device):
+        """The lanes of `device`, or None when the runtime refuses CU-masked streams there (the callers then launch in
+        line on one stream: the lanes are a scheduling optimisation, not part of the arithmetic)."""
         key = str(torch.device(device))
         if key not in cls._by_dev:
-            cls._by_dev[key] = Lanes(device, _dev.value("DV3_LANES_SCAN_CUS", 128))
+            try:
+                cls._by_dev[key] = Lanes(device, _dev.value("DV3_LANES_SCAN_CUS", 0))
+            except (RuntimeError, ValueError) as e:  # DV3Error (a HIP error code) included
+                import sys
+
+                print(f"[dv3hip] no CU-masked streams on {key} ({e}); the reverse scan and the deferred weight gradients "
+                      "run in line", file=sys.stderr)
+                cls._by_dev[key] = None
         return cls._by_dev[key]
 
     def __init__(self, device, scan_cus: int):
@@ -77,6 +86,8 @@ class Lanes:
             n = ctypes.c_int()
             _lib.check(lib.dv3_device_cu_count(ctypes.byref(n)), "dv3_device_cu_count")
             n_cu = n.value
+            if scan_cus <= 0:
+                scan_cus = (n_cu // 2) // 8 * 8  # half of the chip: the 16-row chain runs at full speed on it (MI355X: 128)
             if not 8 <= scan_cus <= n_cu - 8:
                 raise ValueError(f"scan lane of {scan_cus} CUs on a {n_cu}-CU device")
             # groups of 8 mask bits dealt out evenly: every XCD gives the same share of its CUs to each lane whether the
@@ -157,6 +168,8 @@ class SideStream:
         self._mode = "plain" if SideStream.plain else ("lanes" if SideStream.lanes else "off")
         if self._mode != "off" and SideStream.recorder is None and torch.cuda.is_current_stream_capturing():
             self._mode = "plain" if self._mode == "plain" else "off"
+        if self._mode == "lanes" and Lanes.get(device) is None:
+            self._mode = "off"
         if self._mode == "plain":
             key = str(device)
             if key not in SideStream._streams:
@@ -168,15 +181,17 @@ class SideStream:
     @staticmethod
     def host_sync_point():
         """Marks where a captured update lets the host wait before it launches the lane segments (graph.SegmentRecorder)."""
-        if SideStream.recorder is not None and SideStream.lanes and not SideStream.plain:
-            SideStream.recorder.sync_point()
+        rec = SideStream.recorder
+        if rec is not None and rec.lanes is not None and SideStream.lanes and not SideStream.plain:
+            rec.sync_point()
 
     @staticmethod
     def late_join_point():
         """Inside chain(): marks where a captured update lets the host wait before it queues the join and what follows it
         (graph.SegmentRecorder.lane_sync_point)."""
-        if SideStream.recorder is not None and SideStream.lanes and not SideStream.plain:
-            SideStream.recorder.lane_sync_point()
+        rec = SideStream.recorder
+        if rec is not None and rec.lanes is not None and SideStream.lanes and not SideStream.plain:
+            rec.lane_sync_point()
 
     def run(self, fns, chain: bool = True):
         """Run the deferred callables beside what follows.  chain=False: what follows fills the chip itself (the encoder

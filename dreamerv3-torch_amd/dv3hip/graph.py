@@ -266,7 +266,8 @@ class UpdateRunner:
         cur = torch.cuda.current_stream()
         own = (engine.SideStream.lanes and not engine.SideStream.plain and cur == torch.cuda.default_stream(cur.device)
                and _dev.flag("DV3_RUNNER_OWN_STREAM", True))
-        return engine.Lanes.get(cur.device).whole_chip_stream() if own else None
+        lanes = engine.Lanes.get(cur.device) if own else None
+        return lanes.whole_chip_stream() if lanes is not None else None
 
     def _step(self, data, eager):
         self._calls += 1

@@ -188,6 +188,34 @@ def test_three_consecutive_updates_match_the_oracle(name):
     assert checked >= 20
 
 
+def test_update_runs_in_line_when_masked_streams_are_unavailable(monkeypatch):
+    """The CU-masked lanes are a scheduling optimisation: where the runtime refuses such streams (engine.Lanes.get ->
+    None) the update is captured as one graph on the caller's stream and computes the same thing."""
+    import tools
+    from dv3hip import engine as E
+    from dv3hip.graph import UpdateRunner
+
+    def run(no_lanes):
+        if no_lanes:
+            monkeypatch.setitem(E.Lanes._by_dev, "cuda:0", None)
+        cfg, wm, beh = Hh.build_models("tiny")
+        tools.default_rng("cuda:0", seed=3)
+        data = {k: torch.from_numpy(v).cuda() for k, v in common.make_batch("tiny").items()}
+        r = UpdateRunner(wm, beh, warm=1)
+        for _ in range(3):
+            r.step(data)
+        torch.cuda.synchronize()
+        lanes = [lane for lane, _ in r._graphs[0].segments]
+        return lanes, float(r.last_metrics["model_loss"]), wm.dynamics.W.detach().clone(), r.launch_stream()
+
+    lanes1, loss1, w1, s1 = run(False)
+    lanes0, loss0, w0, s0 = run(True)
+    assert "side" in lanes1 and "scan" in lanes1 and s1 is not None
+    assert lanes0 == ["main"] and s0 is None
+    assert abs(loss0 - loss1) <= 1e-5 * abs(loss1), (loss0, loss1)
+    close(w0, w1, 1e-5, "learned initial state, lanes vs in line")
+
+
 def test_dev_switch_variants():
     """The A/B switches of the launchers and of the host code (DV3_*; live only in a `build.py --dev` library, see
     dv3hip/_dev.py) select older / unfused launch sequences that must compute the same update: one child process with
