@@ -465,9 +465,23 @@ def _wm_gradients(name, mode, seed=11):
     E.SideStream.lanes = mode != "inline"
     try:
         run = lambda: wm.train_fwd_bwd(data, noise=noise)
-        run()  # (also the warm call of the captured variant: workspaces exist before capture)
+        used = []
+        real_get = E.Lanes.get.__func__
+
+        def spy(cls, device):
+            used.append(device)
+            return real_get(cls, device)
+
+        st = torch.cuda.Stream()  # (eager launches take the lanes only off the NULL stream)
+        st.wait_stream(torch.cuda.current_stream())
+        E.Lanes.get = classmethod(spy)
+        try:
+            with torch.cuda.stream(st):
+                run()  # (also the warm call of the captured variant: workspaces exist before capture)
+        finally:
+            E.Lanes.get = classmethod(real_get)
+        assert bool(used) == (mode != "inline"), (mode, used)
         if mode == "segments":
-            st = torch.cuda.Stream()
             with torch.cuda.stream(st):
                 torch.cuda.synchronize()
                 rec = SegmentRecorder(torch.cuda.graph_pool_handle(), torch.device("cuda:0")).record(run)
