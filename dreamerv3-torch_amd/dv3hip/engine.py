@@ -163,10 +163,11 @@ class SideStream:
     recorder = None  # graph.SegmentRecorder while UpdateRunner captures
     _streams: Dict[str, "torch.cuda.Stream"] = {}
 
-    def __init__(self, device):
+    def __init__(self, device, lanes_pay: bool = True):
+        """lanes_pay=False: the caller knows that the lanes do not pay here (RSSMEngine.lanes_pay) -- in line."""
         self.device = device
         self._forked = []
-        self._mode = "plain" if SideStream.plain else ("lanes" if SideStream.lanes else "off")
+        self._mode = "plain" if SideStream.plain else ("lanes" if (SideStream.lanes and lanes_pay) else "off")
         if self._mode != "off" and SideStream.recorder is None and torch.cuda.is_current_stream_capturing():
             self._mode = "plain" if self._mode == "plain" else "off"
         if self._mode == "lanes" and SideStream.recorder is None:
@@ -186,8 +187,10 @@ class SideStream:
         self._cut = False
 
     @staticmethod
-    def host_sync_point():
+    def host_sync_point(lanes_pay: bool = True):
         """Marks where a captured update lets the host wait before it launches the lane segments (graph.SegmentRecorder)."""
+        if not lanes_pay:
+            return
         rec = SideStream.recorder
         if rec is not None and rec.lanes is not None and SideStream.lanes and not SideStream.plain:
             rec.sync_point()
@@ -682,15 +685,26 @@ class RSSMEngine:
         return dict(post_stoch=post_stoch, post_logit=post_logit, deter=deter, prior_stoch=prior_stoch,
                     prior_logit=prior_logit, action=ain, post_idx=post_idx)
 
-    def observe_bwd(self, dpost_logit, dprior_logit, gs, gd, dembed, extra_side=None):
+    def lanes_pay(self, heavy_side: bool) -> bool:
+        """Whether the reverse scan should run beside the deferred weight gradients on the two CU-masked lanes.
+        Measured on MI355X (ms per update, lanes / in line): cfg 2 16.22 / 16.65, cfg 3 26.50 / 27.24 -- but cfg 1 (vector
+        decoder: ~0.2 ms of deferred work against two host waits and three more graph launches) 12.95 / 12.79, cfg 5
+        (deter 2048: 100 MB of weights per scan step) 267.9 / 255.6, cfg 4 (deter 4096) 391.6 / 383.9: once a step of the
+        scan streams more weights than half of the chip's L2 / Infinity-Cache paths deliver in its fixed launch cost,
+        the chain is bandwidth-bound and wants every CU.  heavy_side: the deferred launches include the conv decoder's."""
+        gru_weight_bytes = 4 * 3 * self.De * (self.Hd + self.De)
+        return bool(heavy_side) and gru_weight_bytes <= (32 << 20) and self.B <= 64
+
+    def observe_bwd(self, dpost_logit, dprior_logit, gs, gd, dembed, extra_side=None, lanes_pay=False):
         """Backward of observe_fwd.
 
         dpost_logit/dprior_logit [T,B,S,D]: gradient on the logits (from the KL; dpost_logit is updated in
         place with the straight-through term).  gs [T,B,SD], gd [T,B,De]: gradient on post stoch / deter
         from the heads (both are used as scratch).  dembed [T,B,E] receives the encoder-output gradient.
         All RSSM parameter gradients are accumulated into their .grad views.  extra_side: callables (weight
-        gradients of the heads / decoder) to run on the side stream beside the reverse scan.  Returns the
-        SideStream so that the caller can put more work beside the encoder backward and join()."""
+        gradients of the heads / decoder) to run on the side stream beside the reverse scan; lanes_pay: what
+        self.lanes_pay() said about them.  Returns the SideStream so that the caller can put more work beside the encoder
+        backward and join()."""
         P, ws = self.P, self.ws
         T, B, S, D, SD, De, Hd, A, E = self.T, self.B, self.S, self.D, self.SD, self.De, self.Hd, self.A, self.E
         TB = T * B
@@ -709,7 +723,7 @@ class RSSMEngine:
         # ---- prior head, batched: prior_logit -> ims -> LN/SiLU -> img_out -> deter
         dx2 = g("obs.dx2", (TB, Hd))
         dpl2 = v2(dprior_logit, SD)
-        side = SideStream(dprior_logit.device)
+        side = SideStream(dprior_logit.device, lanes_pay=lanes_pay)
         ops.gemm(dpl2, P.ims.W, dx2, transB=False)
         dx2pre = g("obs.dx2pre", (TB, Hd))
         dense_ln_bwd_pre(P.img_out, dx2, v2(x2pre, Hd), m2.view(TB), r2.view(TB), dx2pre, wgrad=True)

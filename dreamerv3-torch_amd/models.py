@@ -215,7 +215,9 @@ class WorldModel(nn.Module):
         kl = ws.get("wm.kl", (T, B))
         ent_p, ent_q = ws.get("wm.ent_post", (T, B)), ws.get("wm.ent_prior", (T, B))
         ops.kl_fwd(out["post_logit"], out["prior_logit"], kl, ent_p, ent_q, unimix=dyn._unimix_ratio)
-        E.SideStream.host_sync_point()  # (captured update: the lanes of the reverse scan are launched once the GPU is here)
+        # the reverse scan beside the deferred weight gradients on two CU-masked streams, where that pays
+        lanes_pay = rssm.lanes_pay(heavy_side=bool(self.heads["decoder"].cnn_shapes))
+        E.SideStream.host_sync_point(lanes_pay)  # (captured update: the lanes are launched once the GPU is here)
 
         # ---- heads, losses and their upstream gradients (loss = mean over B*T of the per-row sum)
         up = 1.0 / TB
@@ -297,7 +299,7 @@ class WorldModel(nn.Module):
         ops.dot_accumulate(kl.view(TB), acc[4:5], clip_min=cfg.kl_free, scale=up)  # mean of the clipped KL
         # ---- backward through the scan and the encoder
         dembed = ws.get("wm.dembed", (T, B, E_))
-        side = rssm.observe_bwd(dpl, dql, gs, gd, dembed, extra_side=deferred)
+        side = rssm.observe_bwd(dpl, dql, gs, gd, dembed, extra_side=deferred, lanes_pay=lanes_pay)
         if enc.cnn_shapes:
             enc_eng.backward(dembed.view(TB, E_))
         else:

@@ -496,7 +496,23 @@ def _wm_gradients(name, mode, seed=11):
     return wm._model_opt.bucket.grad.clone(), post["stoch"].clone(), float(wm._pending[3])
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg1"])
+def test_lanes_are_taken_where_they_were_measured_to_pay():
+    """engine.RSSMEngine.lanes_pay: the image configs with a latency-bound scan (cfg 2, cfg 3) -- not the vector decoder of
+    cfg 1 (too little deferred work), not the wide cells of cfg 4 / cfg 5 (the scan is bandwidth-bound there)."""
+    from types import SimpleNamespace
+
+    from dv3hip import engine as E
+
+    def pays(name, heavy):
+        s = common.SHAPES[name]
+        eng = SimpleNamespace(De=s["deter"], Hd=s["hidden"], B=s["B"])
+        return E.RSSMEngine.lanes_pay(eng, heavy)
+
+    assert pays("cfg2", True) and pays("cfg3", True)
+    assert not pays("cfg1", False) and not pays("cfg4", True) and not pays("cfg5", True)
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3"])
 def test_cu_lanes_compute_what_the_inline_sequence_computes(name):
     """The reverse observe scan beside the deferred weight gradients on two CU-masked streams (engine.Lanes), eagerly and
     as one hipGraph per lane (graph.SegmentRecorder), against the same launches in line on one stream: same samples,
