@@ -405,7 +405,7 @@ def main():
         from dv3hip.staging import BatchStager
 
         host = {k: v.cpu().numpy() for k, v in data.items()}
-        stager = BatchStager(device)
+        stager = BatchStager(device, overlap=os.environ.get("DV3_STAGE_OVERLAP", "1") != "0")  # ("0": upload in front)
         # (uploads on the stream the update is issued on: no second queue beside its dependent launches)
         with torch.cuda.stream(runner.launch_stream() or torch.cuda.current_stream()):
             for _ in range(3):

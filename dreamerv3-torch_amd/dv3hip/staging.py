@@ -6,10 +6,14 @@ uint8 images (12.6 MB), bool flags as one byte -- from PINNED buffers, double-bu
 while the update on batch i runs); /255, -0.5 and the float conversion happen inside the first kernels that read
 the data (dv3_image_to_f32 / dv3_mse_image).
 
-The uploads go onto the update's OWN stream by default (overlap=False): measured at cfg 2 (tools/stage_probe.py, r02)
-an update with its batch resident takes 18.13 ms, 18.45 ms with the upload in front of it on the same stream, and
-19.49 ms with the upload on a second stream "overlapping" the previous update -- a second active queue slows the
-update's ~3000 dependent launches by more than the 0.3 ms the upload costs.
+The uploads run on a copy stream of their own beside the previous update (overlap=True, r03).  r02 measured exactly that
+SLOWER than uploading in front of the update on its own stream (19.49 against 18.45 ms per update; 18.13 with the batch
+resident) and kept the uploads on the update's stream; r03 found the cause -- not the second queue as such but a BLOCKED
+one: the copy stream waited on the event that frees its buffer pair, and a queue whose head is a blocked barrier packet
+costs every dependent launch of the other queue ~1.3 us ("Compute-unit lanes").  With the host
+waiting for that event instead (it has normally fired long before), the copy queue is never blocked and the upload is
+free: 16.33 ms per update with a fresh host batch every step against 16.31 with the batch resident (16.57-16.62 with the
+upload in front of the update).
 """
 from __future__ import annotations
 
@@ -26,7 +30,7 @@ class BatchStager:
     passed the point where the previous occupant was handed out (recorded with an event), so a captured graph
     may still be reading batch i while batch i+1 is in flight."""
 
-    def __init__(self, device, depth: int = 2, overlap: bool = False):
+    def __init__(self, device, depth: int = 2, overlap: bool = True):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("BatchStager stages into HBM: it needs a GPU device")
@@ -36,7 +40,7 @@ class BatchStager:
         self._h2d = [None] * depth   # event on the copy stream: the slot's previous upload has finished
         self._last = None
         self._i = 0
-        # overlap=False: uploads go onto the consumer's own stream (serialised with the update, no second queue)
+        # overlap=False: uploads go onto the consumer's own stream (serialised in front of the update)
         self._copy = torch.cuda.Stream(self.device) if overlap else None
 
     @staticmethod
@@ -58,7 +62,10 @@ class BatchStager:
         slot = self._slots[self._i]
         copy = self._copy if self._copy is not None else cur
         if self._free[self._i] is not None and copy is not cur:
-            copy.wait_event(self._free[self._i])
+            # the slot's previous batch (two stage() calls back) must have been consumed.  The HOST waits for that, not
+            # the copy stream: a copy queue blocked on the event sits beside the running update's dependent launches and
+            # costs each of them ~1.3 us (r02: 19.49 ms per update against 18.45) -- an unblocked one costs nothing.
+            self._free[self._i].synchronize()
         if self._h2d[self._i] is not None:
             self._h2d[self._i].synchronize()  # the pinned side is rewritten below: its last upload must be over
         out = {}
