@@ -54,8 +54,9 @@ class SegmentRecorder:
         self._flat = _dev.flag("DV3_LANES_FLAT", False)  # dev: the same cuts, every segment on the caller's stream
         self._late_fork = _dev.flag("DV3_LANES_LATE_FORK", True)
         self._late_join = _dev.flag("DV3_LANES_LATE_JOIN", True)
-        self._mark2 = torch.cuda.Event()
-        self._mark = torch.cuda.Event()
+        self._mark2 = torch.cuda.Event(blocking=_dev.flag("DV3_LANES_BLOCKING_WAIT", True))
+        blocking = _dev.flag("DV3_LANES_BLOCKING_WAIT", True)  # the host sleeps in its two waits instead of spinning
+        self._mark = torch.cuda.Event(blocking=blocking)
 
     def _begin(self, lane):
         if self._flat:
