@@ -528,6 +528,51 @@ def test_cu_lanes_compute_what_the_inline_sequence_computes(name):
         assert err <= 2e-6 * scale, f"{mode}: gradient differs by {err:.3e} (max |g| {scale:.3e})"
 
 
+def test_segment_recorder_leaves_no_capture_behind_when_the_recorded_code_raises():
+    """An error inside a lane segment ends that capture, restores SideStream.recorder and reaches the caller unchanged
+    (only a refusal of the capture itself becomes CaptureRefused)."""
+    from dv3hip import engine as E
+    from dv3hip.graph import SegmentRecorder
+
+    x = torch.zeros(1024, device="cuda")
+
+    def body():
+        x.add_(1.0)
+        side = E.SideStream("cuda:0")
+        side.run([lambda: x.add_(1.0)])
+        with side.chain():
+            x.add_(1.0)
+            raise ValueError("shape bug in the recorded code")
+
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        rec = SegmentRecorder(torch.cuda.graph_pool_handle(), torch.device("cuda:0"))
+        with pytest.raises(ValueError, match="shape bug"):
+            rec.record(body)
+        assert E.SideStream.recorder is None
+        assert not torch.cuda.is_current_stream_capturing()
+        for s in rec.lanes.streams.values():
+            with torch.cuda.stream(s):
+                assert not torch.cuda.is_current_stream_capturing()
+        # ... and the streams are usable afterwards: the same body without the error records and replays
+        def good():
+            x.add_(1.0)
+            side = E.SideStream("cuda:0")
+            side.run([lambda: x.add_(2.0)])
+            with side.chain():
+                x.add_(4.0)
+            side.join()
+            x.mul_(2.0)
+
+        x.zero_()
+        torch.cuda.synchronize()
+        rec2 = SegmentRecorder(torch.cuda.graph_pool_handle(), torch.device("cuda:0")).record(good)
+        assert [lane for lane, _ in rec2.segments] == ["main", "side", "scan", "main"]
+        rec2.replay()
+        torch.cuda.synchronize()
+    assert float(x[0]) == 14.0 and float(x.sum()) == 14.0 * 1024
+
+
 def test_cu_masked_stream_restricts_a_launch_to_its_compute_units():
     """dv3_stream_create_cu_masked: a chip-filling product on a stream that owns half of the CUs takes about twice as
     long as on the whole chip, launched eagerly and from a hipGraph replayed on that stream (the mask belongs to the
