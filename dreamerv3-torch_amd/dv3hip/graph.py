@@ -195,18 +195,19 @@ class UpdateRunner:
         self.warm = warm
         self._calls = 0
         self._static: Dict[str, torch.Tensor] = {}
-        self._graphs = None
+        self._g_wm = self._g_beh = None  # (per-lane graphs of the forward/backward, optimizer graph); (behaviour, optimizers)
+        self._cap = {}  # what the captured halves returned (static tensors the replays rewrite)
+        self._pool = torch.cuda.graph_pool_handle() if torch.cuda.is_available() else None
+        self._m1, self._m2, self._beh_out = {}, {}, None
+        self._stager = None
         self._stream = None
         self.last_metrics = {}
         self.last_post = self.last_context = self.last_data = None  # what a further behaviour (Plan2Explore) trains on
 
-    # -- eager reference sequence ----------------------------------------------------------------
-    def _eager(self, data):
-        post, ctx, m1 = self.wm._train(data)
-        m2 = self.beh._train(post, None)[-1]
-        self.last_metrics = {**m1, **m2}
-        self.last_post, self.last_context, self.last_data = post, ctx, data
-
+    # -- the two halves of one update -----------------------------------------------------------------
+    # World-model half: [fwd+bwd as per-lane graphs] -> all-reduce -> [clip+Adam].  Behaviour half: [imagine, returns,
+    # losses, backward] -> all-reduce x2 -> [clip+Adam x2].  step() runs both; WorldModel._train / ImagBehavior._train
+    # reach them one at a time through train_wm() / train_behavior() (a driver written against the reference's classes).
     def _load(self, data):
         if not self._static:
             for k, v in data.items():
@@ -215,47 +216,152 @@ class UpdateRunner:
         for k, v in data.items():
             self._static[k].copy_(v, non_blocking=True)
 
-    def _capture(self):
-        wm, beh = self.wm, self.beh
-        g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        pool = torch.cuda.graph_pool_handle()
+    def _replaying(self, eager):
+        return not (eager or not self.use_graph or self._calls <= self.warm)
+
+    def _wm_half(self, data, eager=False):
+        self._calls += 1
+        if self._replaying(eager):
+            self._load(data)
+            if self._g_wm is None:
+                torch.cuda.synchronize()
+                try:
+                    self._capture_wm()  # records only: nothing has executed yet, so fall through and replay
+                except CaptureRefused as e:  # a runtime that refuses capture: keep training, launch eagerly
+                    self._refused(e)
+        if not self._replaying(eager):
+            post, ctx, m1 = self.wm._train_eager(data)
+            self._m1, self.last_post, self.last_context, self.last_data = m1, post, ctx, data
+            return
+        g1, ga = self._g_wm
+        g1.replay()
+        # (queueing the collectives only once the segment in front is over -- so that RCCL's stream does not sit blocked
+        # beside it -- measured slower under a one-rank RCCL group: 16.43 vs 16.34 ms)
+        self.wm._model_opt.bucket.allreduce()
+        ga.replay()
+        self._m1, self.last_post, self.last_context, self.last_data = self._cap["m1"], self._cap["post"], self._cap["ctx"], self._static
+
+    def _beh_half(self, eager=False):
+        if self._replaying(eager) and self._g_beh is None:
+            torch.cuda.synchronize()
+            try:
+                self._capture_beh()
+            except CaptureRefused as e:
+                self._refused(e)
+        if not self._replaying(eager):
+            self._beh_out = self.beh._train_eager(self.last_post, None)
+            self._m2 = self._beh_out[-1]
+            return
+        gb, g3 = self._g_beh
+        gb.replay()
+        self.beh._actor_opt.bucket.allreduce()
+        self.beh._value_opt.bucket.allreduce()
+        self.beh.sync_ema()
+        g3.replay()
+        self._beh_out, self._m2 = self._cap["beh_out"], self._cap["beh_out"][-1]
+
+    def _refused(self, e):
+        import sys
+
+        print(f"[dv3hip] hipGraph capture refused ({e}); falling back to eager launches", file=sys.stderr)
+        self.use_graph, self._g_wm, self._g_beh = False, None, None
+        torch.cuda.synchronize()  # an asynchronous HIP error surfaces here instead of being trained over
+
+    def _capture_wm(self):
+        wm = self.wm
         # (capture_error_mode thread_local: with a process group alive, RCCL's watchdog thread polls events while we
         # capture; the default global mode would treat that as a capture violation)
-        res = {}
-        # the world model's segment is a sequence of graphs: its reverse scan and the weight gradients that nothing reads
+        # the forward/backward is a sequence of graphs: its reverse scan and the weight gradients that nothing reads
         # before the optimizer run on two CU-masked lanes (engine.Lanes), everything else on the whole chip
         dev = next(iter(self._static.values())).device
-        g1 = SegmentRecorder(pool, dev).record(lambda: wm.train_fwd_bwd(self._static))
+        g1 = SegmentRecorder(self._pool, dev).record(lambda: wm.train_fwd_bwd(self._static))
         wm._model_opt.bucket.allreduce()
+        ga = torch.cuda.CUDAGraph()
+        cap = self._cap
 
-        def seg2():
-            res["post"], res["ctx"], res["m1"] = wm.train_opt(allreduce=False)
-            beh.train_fwd_bwd(res["post"])
+        def opt():
+            cap["post"], cap["ctx"], cap["m1"] = wm.train_opt(allreduce=False)
 
-        _capture(g2, seg2, pool=pool)
+        _capture(ga, opt, pool=self._pool)
+        self._g_wm = (g1, ga)
+
+    def _capture_beh(self):
+        beh = self.beh
+        gb, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        _capture(gb, lambda: beh.train_fwd_bwd(self.last_post), pool=self._pool)
         beh._actor_opt.bucket.allreduce()
         beh._value_opt.bucket.allreduce()
         beh.sync_ema()
-        _capture(g3, lambda: res.update(m2=beh.train_opt(allreduce=False)[-1]), pool=pool)
-        self._graphs = (g1, g2, g3)
-        self.last_metrics = {**res["m1"], **res["m2"]}
-        self.last_post, self.last_context, self.last_data = res["post"], res["ctx"], self._static
+        _capture(g3, lambda: self._cap.update(beh_out=beh.train_opt(allreduce=False)), pool=self._pool)
+        self._g_beh = (gb, g3)
 
-    def step(self, data, eager: bool = False):
-        """data: dict of device tensors (image uint8 [B,T,64,64,3], action, reward, is_first, is_terminal ...).
-
-        Stream-ordered with the caller's current stream.  When that is the NULL stream the update itself runs on a stream
+    def _on_launch_stream(self, fn):
+        """Stream-ordered with the caller's current stream.  When that is the NULL stream the update itself runs on a stream
         of the runner's own: the CU-masked lanes are blocking streams, and beside work on the NULL stream (which
         synchronises with every blocking stream at every launch) the update took 18.4 ms instead of 16.3."""
         s = self.launch_stream()
         if s is None:
-            return self._step(data, eager)
+            return fn()
         self._stream = s
         # a BLOCKING stream: HIP orders it with the NULL stream by itself (its launches wait for earlier NULL-stream work,
         # later NULL-stream launches wait for it), and only when such work exists -- an explicit wait_stream pair would
         # leave a blocked barrier packet at the head of the NULL queue for the whole update (measured: 17.3 ms vs 16.4)
-        with torch.cuda.stream(self._stream):
-            self._step(data, eager)
+        with torch.cuda.stream(s):
+            return fn()
+
+    def step(self, data, eager: bool = False):
+        """One full update.  data: dict of device tensors (image uint8 [B,T,64,64,3], action, reward, is_first,
+        is_terminal ...)."""
+        def both():
+            self._wm_half(data, eager)
+            self._beh_half(eager)
+            self.last_metrics = {**self._m1, **self._m2}
+
+        self._on_launch_stream(both)
+
+    # -- the reference's two calls ------------------------------------------------------------------------
+    def train_wm(self, data):
+        """WorldModel._train(data) (models.py:108-171) through the runner -> (post, context, metrics).  data: what the
+        reference hands its world model (a dict of host arrays from the replay sampler), or device tensors."""
+        from models import _wrap, DeviceScalar
+
+        def run():
+            host = all(not isinstance(v, torch.Tensor) for v in data.values())
+            if not (self.use_graph and self._calls + 1 > self.warm):
+                staged = data  # (an eager call stages for itself)
+            elif host:
+                if self._stager is None:
+                    from .staging import BatchStager
+
+                    self._stager = BatchStager(self.wm._config.device)
+                staged = self._stager.stage(data)
+            else:
+                staged = {k: (v if k == "image" else v.to(torch.float32)) for k, v in data.items()}
+            self._wm_half(staged)
+            # the captured metrics live in buffers the next replay overwrites: the caller gets a snapshot (one launch)
+            fresh = _wrap({k: (v._t if isinstance(v, DeviceScalar) else v) for k, v in self._m1.items()})
+            return self.last_post, self.last_context, fresh
+
+        return self._on_launch_stream(run)
+
+    def owns(self, start) -> bool:
+        """Is `start` the posterior the last train_wm() handed out (what the reference passes on, dreamer.py:195)?"""
+        lp = self.last_post
+        return lp is not None and (start is lp or (isinstance(start, dict) and set(start) == set(lp) and all(
+            isinstance(start[k], torch.Tensor) and start[k].data_ptr() == lp[k].data_ptr()
+            and start[k].shape == lp[k].shape for k in lp)))
+
+    def train_behavior(self):
+        """ImagBehavior._train(post, reward head) (models.py:327-446) on the posterior of the last train_wm()."""
+        from models import _wrap, DeviceScalar
+
+        def run():
+            self._beh_half()
+            out = self._beh_out
+            fresh = _wrap({k: (v._t if isinstance(v, DeviceScalar) else v) for k, v in out[-1].items()})
+            return tuple(out[:-1]) + (fresh,)
+
+        return self._on_launch_stream(run)
 
     def launch_stream(self):
         """The stream step() will issue the update on when the caller's current stream is the NULL stream (None
@@ -269,35 +375,6 @@ class UpdateRunner:
                and _dev.flag("DV3_RUNNER_OWN_STREAM", True))
         lanes = engine.Lanes.get(cur.device) if own else None
         return lanes.whole_chip_stream() if lanes is not None else None
-
-    def _step(self, data, eager):
-        self._calls += 1
-        if eager or not self.use_graph or self._calls <= self.warm:
-            self._eager(data)
-            return
-        self._load(data)
-        if self._graphs is None:
-            torch.cuda.synchronize()
-            try:
-                self._capture()  # records only: nothing has executed yet, so fall through and replay
-            except CaptureRefused as e:  # a runtime that refuses capture: keep training, launch eagerly
-                import sys
-
-                print(f"[dv3hip] hipGraph capture refused ({e}); falling back to eager launches", file=sys.stderr)
-                self.use_graph, self._graphs = False, None
-                torch.cuda.synchronize()  # an asynchronous HIP error surfaces here instead of being trained over
-                self._eager(data)
-                return
-        g1, g2, g3 = self._graphs
-        g1.replay()
-        # (queueing the collectives only once the segment in front is over -- so that RCCL's stream does not sit blocked
-        # beside it -- measured slower under a one-rank RCCL group: 16.43 vs 16.34 ms)
-        self.wm._model_opt.bucket.allreduce()
-        g2.replay()
-        self.beh._actor_opt.bucket.allreduce()
-        self.beh._value_opt.bucket.allreduce()
-        self.beh.sync_ema()
-        g3.replay()
 
 
 class PolicyRunner:

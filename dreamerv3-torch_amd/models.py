@@ -147,10 +147,33 @@ class WorldModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _train(self, data, noise=None):
-        """One world-model update (models.py:108-171).  `noise` (tests): dict(q_prior, q_post) of
-        [T,B,S,D] Exp(1) draws.  = train_fwd_bwd (forward, losses, explicit backward into the flat gradient
-        bucket) + train_opt (all-reduce, clip, Adam); split so that a hipGraph can hold each half with the
-        collective between them."""
+        """One world-model update (models.py:108-171) -> (post, context, metrics).  `noise` (tests): dict(q_prior,
+        q_post) of [T,B,S,D] Exp(1) draws.  A driver written against the reference's classes (its dreamer.py:192-199)
+        calls this and then ImagBehavior._train(post, reward): once a behaviour exists both go through one
+        dv3hip.graph.UpdateRunner, which replays the update from hipGraphs after two eager warm-up calls (config key
+        `hip_graph`, default on) -- the eager launch sequence is host-bound (19.5 ms per cfg-2 update against 16.2)."""
+        r = self._auto_runner() if noise is None else None
+        if r is None:
+            return self._train_eager(data, noise)
+        return r.train_wm(data)
+
+    def _auto_runner(self):
+        r = self.__dict__.get("_runner")
+        if r is None:
+            cfg = self._config
+            beh = next((b() for b in self.__dict__.get("_behaviors", []) if b() is not None), None)
+            if (beh is None or not bool(getattr(cfg, "hip_graph", True)) or not torch.cuda.is_available()
+                    or torch.device(cfg.device).type != "cuda"):
+                return None
+            from dv3hip.graph import UpdateRunner
+
+            r = UpdateRunner(self, beh, use_graph=True)
+            self.__dict__["_runner"] = r
+        return r
+
+    def _train_eager(self, data, noise=None):
+        """= train_fwd_bwd (forward, losses, explicit backward into the flat gradient bucket) + train_opt (all-reduce,
+        clip, Adam); split so that a hipGraph can hold each half with the collective between them."""
         self.train_fwd_bwd(data, noise)
         return self.train_opt()
 
@@ -386,6 +409,10 @@ class ImagBehavior(nn.Module):
             feat_size, (255,) if config.critic["dist"] == "symlog_disc" else (), config.critic["layers"], config.units,
             config.act, config.norm, config.critic["dist"], outscale=config.critic["outscale"], device=config.device,
             name="Value")
+        # (WorldModel._train finds the behaviour that follows it in an update through this list: see _auto_runner)
+        import weakref
+
+        world_model.__dict__.setdefault("_behaviors", []).append(weakref.ref(self))
         if config.critic["dist"] != "symlog_disc" or config.actor["dist"] not in ("normal", "onehot"):
             raise NotImplementedError("critic symlog_disc; actor normal|onehot")
         if config.imag_gradient not in ("dynamics", "reinforce", "both"):
@@ -559,6 +586,18 @@ class ImagBehavior(nn.Module):
         * anything else (exploration.Plan2Explore._intrinsic_reward, exploration.py:108-121): the objective is
           evaluated under torch autograd on leaf views of the imagined states / actions and its input gradients are
           injected into the hand-written reverse rollout where the reward head's would enter (see train_fwd_bwd)."""
+        r = self._world_model.__dict__.get("_runner") if noise is None else None
+        if r is not None and r.beh is self and r.owns(start) and self._is_known_reward_head(objective):
+            return r.train_behavior()
+        return self._train_eager(start, objective, noise)
+
+    def _is_known_reward_head(self, objective):
+        """None, or an objective an earlier (eager) call has recognised as the world model's reward head."""
+        if objective is None:
+            return True
+        return self.__dict__.get("_objective_kinds", {}).get(self._objective_key(objective)) is True
+
+    def _train_eager(self, start, objective=None, noise=None):
         self.train_fwd_bwd(start, noise, objective)
         return self.train_opt()
 

@@ -119,3 +119,41 @@ def test_objective_and_policy_arguments():
     N = s["B"] * s["T"]
     assert feats.shape[:2] == (3, N) and actions.shape == (3, N, s["A"]) and states["stoch"].shape[:2] == (3, N)
 
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg2"])
+def test_a_driver_written_against_the_reference_classes_replays_graphs(name):
+    """The reference's Dreamer._train (dreamer.py:192-199) calls WorldModel._train(data) and then
+    ImagBehavior._train(post, reward-head lambda).  Against these modules the two calls meet in one UpdateRunner: after
+    two eager warm-up updates they replay hipGraphs (per-lane graphs of the world model, the behaviour, the optimizers)
+    and compute what the eager calls compute; the metrics handed back are snapshots (a later update does not rewrite
+    them); `hip_graph: False` keeps every call eager."""
+    import tools
+
+    def drive(hip_graph, n=5):
+        cfg, wm, beh = Hh.build_models(name)
+        cfg.hip_graph = hip_graph
+        tools.default_rng("cuda:0", seed=21)
+        reward = lambda f, s_, a: wm.heads["reward"](wm.dynamics.get_feat(s_)).mode()  # dreamer.py:196-198
+        seen = []
+        for i in range(n):
+            data = common.make_batch(name)  # host arrays, as the replay sampler hands them over
+            post, context, mets = wm._train(data)
+            out = beh._train(post, reward)
+            assert set(post) == {"stoch", "deter", "logit"} and len(out) == 5
+            seen.append((mets["model_loss"], out[-1]["actor_loss"], out[-1]["value_loss"]))
+        torch.cuda.synchronize()
+        r = wm.__dict__.get("_runner")
+        vals = [tuple(float(v) for v in t) for t in seen]
+        return r, vals, wm.dynamics.W.detach().clone()
+
+    r1, v1, w1 = drive(True)
+    r0, v0, w0 = drive(False)
+    assert r0 is None and r1 is not None and r1._g_wm is not None and r1._g_beh is not None  # graphs were captured
+    assert all(np.isfinite(v1).ravel())
+    assert len({v[0] for v in v1}) == len(v1), "the metrics of earlier updates were rewritten by later replays"
+    for a, b in zip(v1, v0):
+        assert abs(a[0] - b[0]) <= 2e-3 * abs(b[0]), (v1, v0)
+        assert abs(a[2] - b[2]) <= 2e-2 * max(1.0, abs(b[2])), (v1, v0)
+    err = float((w1 - w0).abs().max())
+    assert err <= 1e-4 * max(1.0, float(w0.abs().max())), err

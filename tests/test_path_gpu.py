@@ -205,7 +205,7 @@ def test_update_runs_in_line_when_masked_streams_are_unavailable(monkeypatch):
         for _ in range(3):
             r.step(data)
         torch.cuda.synchronize()
-        lanes = [lane for lane, _ in r._graphs[0].segments]
+        lanes = [lane for lane, _ in r._g_wm[0].segments]
         return lanes, float(r.last_metrics["model_loss"]), wm.dynamics.W.detach().clone(), r.launch_stream()
 
     lanes1, loss1, w1, s1 = run(False)
