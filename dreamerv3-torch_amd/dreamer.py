@@ -131,7 +131,7 @@ class Dreamer(nn.Module):
             self._runner = UpdateRunner(self._wm, self._task_behavior,
                                         use_graph=bool(getattr(self._config, "hip_graph", True)))
             self._stager = BatchStager(self._config.device)
-            self._wm.__dict__["_runner"] = self._runner  # (WorldModel._train / ImagBehavior._train share it)
+            models.share_runner(self._wm, self._runner)  # (WorldModel._train / ImagBehavior._train share it)
         host = all(not isinstance(v, torch.Tensor) for v in data.values())
         # (the uploads go onto the stream the update is issued on; see UpdateRunner.launch_stream)
         with torch.cuda.stream(self._runner.launch_stream() or torch.cuda.current_stream()):

@@ -135,8 +135,6 @@ class Lanes:
         except Exception:  # interpreter shutdown: nothing left to report to
             pass
 
-
-    # (Lanes) --------------------------------------------------------------------------------------------------------
     def whole_chip_stream(self):
         """A blocking stream over every CU (what UpdateRunner runs an update on when its caller sits on the NULL stream)."""
         return self.streams["whole"]

@@ -30,6 +30,23 @@ _FUSED_IMAG = _dev.flag("DV3_FUSED_IMAG", True)  # fused launches + one-hot gath
 _STACK_DETER = _dev.flag("DV3_STACK_DETER", True)  # img_out + actor layer-0 dense half as one GEMM
 
 
+# World model -> the behaviours built on it / the UpdateRunner its _train shares with them.  Kept out of the modules'
+# __dict__ (weak references and hipGraphs do not pickle or deep-copy; a module must).
+import weakref  # noqa: E402
+
+_BEHAVIORS = weakref.WeakKeyDictionary()
+_RUNNERS = weakref.WeakKeyDictionary()
+
+
+def runner_of(world_model):
+    """The dv3hip.graph.UpdateRunner that WorldModel._train / ImagBehavior._train of this world model go through."""
+    return _RUNNERS.get(world_model)
+
+
+def share_runner(world_model, runner):
+    _RUNNERS[world_model] = runner
+
+
 class DeviceScalar:
     """A metric that stays on the GPU until somebody looks at it (one D2H copy at log time instead of a
     sync per update)."""
@@ -158,17 +175,17 @@ class WorldModel(nn.Module):
         return r.train_wm(data)
 
     def _auto_runner(self):
-        r = self.__dict__.get("_runner")
+        r = _RUNNERS.get(self)
         if r is None:
             cfg = self._config
-            beh = next((b() for b in self.__dict__.get("_behaviors", []) if b() is not None), None)
+            beh = next((b() for b in _BEHAVIORS.get(self, []) if b() is not None), None)
             if (beh is None or not bool(getattr(cfg, "hip_graph", True)) or not torch.cuda.is_available()
                     or torch.device(cfg.device).type != "cuda"):
                 return None
             from dv3hip.graph import UpdateRunner
 
             r = UpdateRunner(self, beh, use_graph=True)
-            self.__dict__["_runner"] = r
+            _RUNNERS[self] = r
         return r
 
     def _train_eager(self, data, noise=None):
@@ -410,9 +427,7 @@ class ImagBehavior(nn.Module):
             config.act, config.norm, config.critic["dist"], outscale=config.critic["outscale"], device=config.device,
             name="Value")
         # (WorldModel._train finds the behaviour that follows it in an update through this list: see _auto_runner)
-        import weakref
-
-        world_model.__dict__.setdefault("_behaviors", []).append(weakref.ref(self))
+        _BEHAVIORS.setdefault(world_model, []).append(weakref.ref(self))
         if config.critic["dist"] != "symlog_disc" or config.actor["dist"] not in ("normal", "onehot"):
             raise NotImplementedError("critic symlog_disc; actor normal|onehot")
         if config.imag_gradient not in ("dynamics", "reinforce", "both"):
@@ -586,7 +601,7 @@ class ImagBehavior(nn.Module):
         * anything else (exploration.Plan2Explore._intrinsic_reward, exploration.py:108-121): the objective is
           evaluated under torch autograd on leaf views of the imagined states / actions and its input gradients are
           injected into the hand-written reverse rollout where the reward head's would enter (see train_fwd_bwd)."""
-        r = self._world_model.__dict__.get("_runner") if noise is None else None
+        r = _RUNNERS.get(self._world_model) if noise is None else None
         if r is not None and r.beh is self and r.owns(start) and self._is_known_reward_head(objective):
             return r.train_behavior()
         return self._train_eager(start, objective, noise)

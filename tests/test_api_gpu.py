@@ -143,7 +143,9 @@ def test_a_driver_written_against_the_reference_classes_replays_graphs(name):
             assert set(post) == {"stoch", "deter", "logit"} and len(out) == 5
             seen.append((mets["model_loss"], out[-1]["actor_loss"], out[-1]["value_loss"]))
         torch.cuda.synchronize()
-        r = wm.__dict__.get("_runner")
+        import models
+
+        r = models.runner_of(wm)
         vals = [tuple(float(v) for v in t) for t in seen]
         return r, vals, wm.dynamics.W.detach().clone()
 
