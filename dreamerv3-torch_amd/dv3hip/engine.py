@@ -86,6 +86,10 @@ class Lanes:
             n = ctypes.c_int()
             _lib.check(lib.dv3_device_cu_count(ctypes.byref(n)), "dv3_device_cu_count")
             n_cu = n.value
+            if n_cu < 128:
+                # (a partitioned device, e.g. CPX mode: the 16-row chain needs ~128 CUs to run at full speed -- 10.3 us per
+                # launch on 64 against 7.7 -- so there is nothing to give away)
+                raise ValueError(f"{n_cu} compute units: too few to split")
             if scan_cus <= 0:
                 scan_cus = (n_cu // 2) // 8 * 8  # half of the chip: the 16-row chain runs at full speed on it (MI355X: 128)
             if not 8 <= scan_cus <= n_cu - 8:
