@@ -172,14 +172,18 @@ class SideStream:
         self._mode = "plain" if SideStream.plain else ("lanes" if (SideStream.lanes and lanes_pay) else "off")
         if self._mode != "off" and SideStream.recorder is None and torch.cuda.is_current_stream_capturing():
             self._mode = "plain" if self._mode == "plain" else "off"
-        if self._mode == "lanes" and SideStream.recorder is None:
-            # eager launches on the NULL stream (a caller driving WorldModel._train directly): the lanes are blocking
-            # streams, every NULL-stream launch synchronises with them -- 20.4 ms per eager update against 19.5 in line
-            cur = torch.cuda.current_stream()
-            if cur == torch.cuda.default_stream(cur.device):
+        if self._mode == "lanes":
+            # The lanes are taken only beside the Lanes' OWN whole-chip stream (where UpdateRunner puts the update of a
+            # NULL-stream caller).  Eager launches on the NULL stream itself synchronise with the (blocking) lane streams
+            # at every launch (20.4 ms per eager update against 19.5 in line); beside a caller's own torch stream the
+            # cross-queue dependencies can cost ~25 us each instead of ~1.3 (19.2 ms per update against 16.2 when that
+            # stream was made after the masked queues, 16.4 when before -- nothing the caller should have to know).
+            ln = Lanes.get(device)
+            rec = SideStream.recorder
+            on_whole = (rec.on_whole if rec is not None else
+                        (ln is not None and torch.cuda.current_stream() == ln.streams["whole"]))
+            if ln is None or not on_whole:
                 self._mode = "off"
-        if self._mode == "lanes" and Lanes.get(device) is None:
-            self._mode = "off"
         if self._mode == "plain":
             key = str(device)
             if key not in SideStream._streams:
@@ -194,7 +198,7 @@ class SideStream:
         if not lanes_pay:
             return
         rec = SideStream.recorder
-        if rec is not None and rec.lanes is not None and SideStream.lanes and not SideStream.plain:
+        if rec is not None and rec.lanes is not None and rec.on_whole and SideStream.lanes and not SideStream.plain:
             rec.sync_point()
 
     @staticmethod
@@ -202,7 +206,7 @@ class SideStream:
         """Inside chain(): marks where a captured update lets the host wait before it queues the join and what follows it
         (graph.SegmentRecorder.lane_sync_point)."""
         rec = SideStream.recorder
-        if rec is not None and rec.lanes is not None and SideStream.lanes and not SideStream.plain:
+        if rec is not None and rec.lanes is not None and rec.on_whole and SideStream.lanes and not SideStream.plain:
             rec.lane_sync_point()
 
     def run(self, fns, chain: bool = True):

@@ -49,6 +49,8 @@ class SegmentRecorder:
 
         self.pool, self.device = pool, device
         self.lanes = engine.Lanes.get(device)
+        # lanes only when the segments will be launched on the Lanes' own whole-chip stream (engine.SideStream)
+        self.on_whole = self.lanes is not None and torch.cuda.current_stream(device) == self.lanes.streams["whole"]
         self.segments = []  # (lane, graph)
         self._cur = None
         self._flat = _dev.flag("DV3_LANES_FLAT", False)  # dev: the same cuts, every segment on the caller's stream
@@ -201,6 +203,7 @@ class UpdateRunner:
         self._m1, self._m2, self._beh_out = {}, {}, None
         self._stager = None
         self._stream = None
+        self._home = None  # ("whole", stream) or ("caller", None): where the first call put the update
         self.last_metrics = {}
         self.last_post = self.last_context = self.last_data = None  # what a further behaviour (Plan2Explore) trains on
 
@@ -298,16 +301,35 @@ class UpdateRunner:
     def _on_launch_stream(self, fn):
         """Stream-ordered with the caller's current stream.  When that is the NULL stream the update itself runs on a stream
         of the runner's own: the CU-masked lanes are blocking streams, and beside work on the NULL stream (which
-        synchronises with every blocking stream at every launch) the update took 18.4 ms instead of 16.3."""
+        synchronises with every blocking stream at every launch) the update took 18.4 ms instead of 16.3.  A caller on
+        a stream of its own keeps the update there, in line (engine.SideStream).  Whichever it was on the first call is
+        the runner's home for good -- its graphs were cut for it; a caller that changes streams later is ordered with
+        the home stream explicitly."""
         s = self.launch_stream()
-        if s is None:
+        if self._home is None:
+            from . import engine
+
+            cur0 = torch.cuda.current_stream()
+            ln = engine.Lanes._by_dev.get(str(torch.device("cuda", cur0.device.index)))
+            if s is None and ln is not None and cur0 == ln.streams["whole"]:
+                s = cur0  # (the caller already is on launch_stream(), as Dreamer._train and the staged bench leg are)
+            self._home = ("whole", s) if s is not None else ("caller", None)
+        if self._home[0] != "whole":
             return fn()
-        self._stream = s
+        whole = self._home[1]
+        self._stream = whole
+        cur = torch.cuda.current_stream()
+        foreign = cur != torch.cuda.default_stream(cur.device) and cur != whole
         # a BLOCKING stream: HIP orders it with the NULL stream by itself (its launches wait for earlier NULL-stream work,
         # later NULL-stream launches wait for it), and only when such work exists -- an explicit wait_stream pair would
         # leave a blocked barrier packet at the head of the NULL queue for the whole update (measured: 17.3 ms vs 16.4)
-        with torch.cuda.stream(s):
-            return fn()
+        if foreign:
+            whole.wait_stream(cur)
+        with torch.cuda.stream(whole):
+            out = fn()
+        if foreign:
+            cur.wait_stream(whole)
+        return out
 
     def step(self, data, eager: bool = False):
         """One full update.  data: dict of device tensors (image uint8 [B,T,64,64,3], action, reward, is_first,
@@ -371,8 +393,10 @@ class UpdateRunner:
         from . import engine
 
         cur = torch.cuda.current_stream()
-        own = (engine.SideStream.lanes and not engine.SideStream.plain and cur == torch.cuda.default_stream(cur.device)
-               and _dev.flag("DV3_RUNNER_OWN_STREAM", True))
+        if self._home is not None and self._home[0] == "whole":
+            return self._home[1] if cur != self._home[1] else None
+        own = (self._home is None and engine.SideStream.lanes and not engine.SideStream.plain
+               and cur == torch.cuda.default_stream(cur.device) and _dev.flag("DV3_RUNNER_OWN_STREAM", True))
         lanes = engine.Lanes.get(cur.device) if own else None
         return lanes.whole_chip_stream() if lanes is not None else None
 

@@ -472,8 +472,8 @@ def _wm_gradients(name, mode, seed=11):
             used.append(device)
             return real_get(cls, device)
 
-        st = torch.cuda.Stream()  # (eager launches take the lanes only off the NULL stream)
-        st.wait_stream(torch.cuda.current_stream())
+        st = E.Lanes.get("cuda:0").whole_chip_stream()  # (the lanes are taken only beside their own whole-chip stream)
+        torch.cuda.synchronize()
         E.Lanes.get = classmethod(spy)
         try:
             with torch.cuda.stream(st):
@@ -544,7 +544,7 @@ def test_segment_recorder_leaves_no_capture_behind_when_the_recorded_code_raises
             x.add_(1.0)
             raise ValueError("shape bug in the recorded code")
 
-    st = torch.cuda.Stream()
+    st = E.Lanes.get("cuda:0").whole_chip_stream()
     with torch.cuda.stream(st):
         rec = SegmentRecorder(torch.cuda.graph_pool_handle(), torch.device("cuda:0"))
         with pytest.raises(ValueError, match="shape bug"):

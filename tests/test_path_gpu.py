@@ -195,25 +195,33 @@ def test_update_runs_in_line_when_masked_streams_are_unavailable(monkeypatch):
     from dv3hip import engine as E
     from dv3hip.graph import UpdateRunner
 
-    def run(no_lanes):
+    def run(no_lanes, own_stream=False):
         if no_lanes:
             monkeypatch.setitem(E.Lanes._by_dev, "cuda:0", None)
         cfg, wm, beh = Hh.build_models("tiny")
         tools.default_rng("cuda:0", seed=3)
         data = {k: torch.from_numpy(v).cuda() for k, v in common.make_batch("tiny").items()}
         r = UpdateRunner(wm, beh, warm=1)
-        for _ in range(3):
-            r.step(data)
         torch.cuda.synchronize()
+        with torch.cuda.stream(torch.cuda.Stream() if own_stream else torch.cuda.current_stream()):
+            for _ in range(3):
+                r.step(data)
+            torch.cuda.synchronize()
+            ls = r.launch_stream()
         lanes = [lane for lane, _ in r._g_wm[0].segments]
-        return lanes, float(r.last_metrics["model_loss"]), wm.dynamics.W.detach().clone(), r.launch_stream()
+        return lanes, float(r.last_metrics["model_loss"]), wm.dynamics.W.detach().clone(), ls
 
     lanes1, loss1, w1, s1 = run(False)
+    # a caller on a stream of its own: the update stays on that stream, in line (the lanes are taken only beside the
+    # runner's own whole-chip stream, where a NULL-stream caller's update is put)
+    lanes2, loss2, w2, s2 = run(False, own_stream=True)
     lanes0, loss0, w0, s0 = run(True)
     assert "side" in lanes1 and "scan" in lanes1 and s1 is not None
+    assert lanes2 == ["main"] and s2 is None
     assert lanes0 == ["main"] and s0 is None
-    assert abs(loss0 - loss1) <= 1e-5 * abs(loss1), (loss0, loss1)
-    close(w0, w1, 1e-5, "learned initial state, lanes vs in line")
+    for loss, w, what in ((loss0, w0, "no masked streams"), (loss2, w2, "caller's own stream")):
+        assert abs(loss - loss1) <= 1e-5 * abs(loss1), (what, loss, loss1)
+        close(w, w1, 1e-5, f"learned initial state, lanes vs in line ({what})")
 
 
 def test_dev_switch_variants():
