@@ -42,16 +42,19 @@ class Dreamer(nn.Module):
             plan2explore=lambda: expl.Plan2Explore(config, self._wm, reward),
         )[config.expl_behavior]().to(self._config.device)
         self._runner, self._stager, self._policy_runner = None, None, None
-        self._metric_keys, self._metric_sum, self._metric_n = [], None, 0
+        self._metric_keys, self._metric_sum, self._metric_cnt, self._metric_idx = [], None, None, {}
 
     def __call__(self, obs, reset, state=None, training=True):
         step = self._step
         if training:
             steps = self._config.pretrain if self._should_pretrain() else self._should_train(step)
             for _ in range(steps):
-                self._train(next(self._dataset))
+                # back-to-back updates of one call: the behaviour phase of each is issued beside the next one's
+                # world-model phase (dv3hip.graph.UpdateRunner.step_pipelined); the last one by _finish_updates()
+                self._train(next(self._dataset), pipelined=steps > 1)
                 self._update_count += 1
                 self._metrics["update_count"] = self._update_count
+            self._finish_updates()  # (the policy below, a checkpoint, the logger read the actor / critic / metrics)
             if self._should_log(step) and self._logger is not None:
                 self._flush_metrics()
                 for name, values in self._metrics.items():
@@ -119,11 +122,13 @@ class Dreamer(nn.Module):
             raise NotImplementedError("actor dist onehot_gumble")
         return {"action": action, "logprob": logprob}, (latent, action)
 
-    def _train(self, data):
+    def _train(self, data, pipelined=False):
         """dreamer.py:192-208.  One update = WorldModel._train + ImagBehavior._train on the updated world model; the
-        launch sequence is replayed from hipGraphs (dv3hip.graph.UpdateRunner, ~1750 launches per update) once it has
+        launch sequence is replayed from hipGraphs (dv3hip.graph.UpdateRunner, ~1130 launches per update) once it has
         been captured, with the host batch staged through pinned buffers (dv3hip.staging.BatchStager).  Metrics stay
-        on the device: one running sum per key, read back once per log interval (see _flush_metrics)."""
+        on the device: one running sum per key, read back once per log interval (see _flush_metrics).
+        pipelined (the update loop of __call__): the behaviour phase of this update may still be pending when the call
+        returns -- it is issued beside the next update's world-model phase, or by _finish_updates()."""
         if self._runner is None:
             from dv3hip.graph import UpdateRunner
             from dv3hip.staging import BatchStager
@@ -133,38 +138,64 @@ class Dreamer(nn.Module):
             self._stager = BatchStager(self._config.device)
             models.share_runner(self._wm, self._runner)  # (WorldModel._train / ImagBehavior._train share it)
         host = all(not isinstance(v, torch.Tensor) for v in data.values())
+        explorer = self._expl_behavior is not self._task_behavior
+        pipelined = pipelined and not explorer and bool(getattr(self._config, "pipeline_updates", True))
         # (the uploads go onto the stream the update is issued on; see UpdateRunner.launch_stream)
         with torch.cuda.stream(self._runner.launch_stream() or torch.cuda.current_stream()):
-            self._runner.step(self._stager.stage(data) if host else
-                              {k: (v if k == "image" else v.to(torch.float32)) for k, v in data.items()})
+            staged = (self._stager.stage(data) if host else
+                      {k: (v if k == "image" else v.to(torch.float32)) for k, v in data.items()})
+            (self._runner.step_pipelined if pipelined else self._runner.step)(staged)
         mets = dict(self._runner.last_metrics)
-        if self._expl_behavior is not self._task_behavior:
+        if explorer:
             # dreamer.py:201-203: the explorer trains on the same posterior states (eagerly: its objective runs torch
             # autograd, which a hipGraph segment cannot hold)
             staged = self._runner.last_data
             xm = self._expl_behavior.train(self._runner.last_post, self._runner.last_context, staged)[-1]
             mets.update({"expl_" + k: v for k, v in xm.items()})
-        # device-resident metrics: the snapshots of the fused path (DeviceScalar) and the 0-d tensors an autograd-style
-        # caller's Optimizer.__call__ returns (the explorer)
+        self._accumulate(mets)
+
+    def _finish_updates(self):
+        """End of a run of pipelined updates: issue the behaviour phase that is still pending."""
+        r = self._runner
+        if r is not None and r._pipe_pending:
+            with torch.cuda.stream(r.launch_stream() or torch.cuda.current_stream()):
+                r.flush()
+            self._accumulate(dict(r.last_metrics))
+
+    def _accumulate(self, mets):
+        """Device-resident metrics -- the snapshots of the fused path (DeviceScalar) and the 0-d tensors an autograd-style
+        caller's Optimizer.__call__ returns (the explorer) -- go into one running sum and one count per key (a pipelined
+        call reports the world-model keys of one update and the behaviour keys of the previous one)."""
         dev = [(k, v._t if isinstance(v, models.DeviceScalar) else v.detach()) for k, v in mets.items()
                if isinstance(v, (models.DeviceScalar, torch.Tensor))]
-        if self._metric_keys != [k for k, _ in dev]:
-            self._flush_metrics()
-            self._metric_keys = [k for k, _ in dev]
-            self._metric_sum = torch.zeros(len(dev), device=dev[0][1].device, dtype=torch.float32)
-            self._metric_n = 0
-        self._metric_sum.add_(torch.stack([t.reshape(()).to(torch.float32) for _, t in dev]))
-        self._metric_n += 1
         for k, v in mets.items():
             if not isinstance(v, (models.DeviceScalar, torch.Tensor)):
                 self._metrics.setdefault(k, []).append(v)
+        if not dev:
+            return
+        keys = tuple(k for k, _ in dev)
+        idx = self._metric_idx.get(keys)
+        if idx is None:
+            new = [k for k in keys if k not in self._metric_keys]
+            if new:
+                self._metric_keys += new
+                d = dev[0][1].device
+                grow = torch.zeros(len(new), device=d, dtype=torch.float32)
+                self._metric_sum = grow if self._metric_sum is None else torch.cat([self._metric_sum, grow])
+                self._metric_cnt = grow.clone() if self._metric_cnt is None else torch.cat([self._metric_cnt, grow])
+            idx = torch.tensor([self._metric_keys.index(k) for k in keys], device=dev[0][1].device)
+            self._metric_idx[keys] = idx
+        vals = torch.stack([t.reshape(()).to(torch.float32) for _, t in dev])
+        self._metric_sum.index_add_(0, idx, vals)
+        self._metric_cnt.index_add_(0, idx, torch.ones_like(vals))
 
     def _flush_metrics(self):
         """Device-side running sums -> self._metrics[name] = [mean] (what the reference's logging loop, which takes
         np.mean of each list, then reports): a single device-to-host copy per log interval."""
-        if self._metric_n:
-            mean = (self._metric_sum / self._metric_n).cpu().numpy()
-            for k, v in zip(self._metric_keys, mean):
-                self._metrics.setdefault(k, []).append(float(v))
+        if self._metric_sum is not None:
+            both = torch.stack([self._metric_sum, self._metric_cnt]).cpu().numpy()
+            for k, sm, n in zip(self._metric_keys, both[0], both[1]):
+                if n > 0:
+                    self._metrics.setdefault(k, []).append(float(sm / n))
             self._metric_sum.zero_()
-            self._metric_n = 0
+            self._metric_cnt.zero_()

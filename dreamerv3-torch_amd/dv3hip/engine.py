@@ -144,6 +144,26 @@ class Lanes:
         return self.streams["whole"]
 
 
+class Cuts:
+    """Labelled cut points of the update's launch sequence (graph.PhaseRecorder): `Cuts.mark("wm.fscan")` closes the
+    hipGraph segment being captured and opens the next one under that label, so that a replay can place the segments
+    of two different updates side by side -- the behaviour phase of update k beside the world-model phase of update
+    k+1 (graph.UpdateRunner.step_pipelined).  A no-op outside such a capture: eager launches and the serial graphs
+    never see the marks."""
+
+    recorder = None  # graph.PhaseRecorder while UpdateRunner captures the pipelined segments
+
+    @staticmethod
+    def mark(label: str):
+        rec = Cuts.recorder
+        if rec is not None:
+            rec.mark(label)
+
+    @staticmethod
+    def active() -> bool:
+        return Cuts.recorder is not None
+
+
 class SideStream:
     """Work that is off the critical path (weight gradients) beside a latency-bound chain of few-row launches.
 
@@ -170,7 +190,11 @@ class SideStream:
         self.device = device
         self._forked = []
         self._mode = "plain" if SideStream.plain else ("lanes" if (SideStream.lanes and lanes_pay) else "off")
-        if self._mode != "off" and SideStream.recorder is None and torch.cuda.is_current_stream_capturing():
+        if Cuts.active():
+            # pipelined capture (graph.PhaseRecorder): the fork / chain / join points become labelled cuts and the
+            # replay schedule decides which lane a segment runs on
+            self._mode = "cuts"
+        if self._mode not in ("off", "cuts") and SideStream.recorder is None and torch.cuda.is_current_stream_capturing():
             self._mode = "plain" if self._mode == "plain" else "off"
         if self._mode == "lanes":
             # The lanes are taken only beside the Lanes' OWN whole-chip stream (where UpdateRunner puts the update of a
@@ -195,7 +219,7 @@ class SideStream:
     @staticmethod
     def host_sync_point(lanes_pay: bool = True):
         """Marks where a captured update lets the host wait before it launches the lane segments (graph.SegmentRecorder)."""
-        if not lanes_pay:
+        if not lanes_pay or Cuts.active():
             return
         rec = SideStream.recorder
         if rec is not None and rec.lanes is not None and rec.on_whole and SideStream.lanes and not SideStream.plain:
@@ -205,6 +229,9 @@ class SideStream:
     def late_join_point():
         """Inside chain(): marks where a captured update lets the host wait before it queues the join and what follows it
         (graph.SegmentRecorder.lane_sync_point)."""
+        if Cuts.active():
+            Cuts.mark("wm.rscan2")
+            return
         rec = SideStream.recorder
         if rec is not None and rec.lanes is not None and rec.on_whole and SideStream.lanes and not SideStream.plain:
             rec.lane_sync_point()
@@ -213,6 +240,13 @@ class SideStream:
         """Run the deferred callables beside what follows.  chain=False: what follows fills the chip itself (the encoder
         backward), so in lanes mode the callables simply run in line."""
         if not fns:
+            return
+        if self._mode == "cuts":
+            if chain:
+                Cuts.mark("wm.defer")
+                self._cut = True
+            for f in fns:
+                f()
             return
         if self._mode == "off" or (self._mode == "lanes" and not chain):
             for f in fns:
@@ -251,6 +285,10 @@ class SideStream:
 
         def __enter__(self):
             side = self.side
+            if side._mode == "cuts":
+                Cuts.mark("wm.rscan")
+                side._cut = True
+                return self
             if side._mode != "lanes":
                 return self
             rec = SideStream.recorder
@@ -277,6 +315,11 @@ class SideStream:
         return SideStream._Chain(self)
 
     def join(self):
+        if self._mode == "cuts":
+            if self._cut:
+                Cuts.mark("wm.post")
+            self._cut = False
+            return
         rec = SideStream.recorder
         if self._mode == "lanes" and rec is not None:
             if self._cut:
@@ -629,7 +672,9 @@ class RSSMEngine:
         init_idx = g("init.idx", (S,), torch.int32)
         gather = _GATHER_OBS
         if gather:
-            wt_in = self.pack_img_in()
+            # (a copy of its own: the imagination of the PREVIOUS update may be reading "rssm.img_in_wt" while this
+            # scan runs beside it -- graph.UpdateRunner.step_pipelined)
+            wt_in = self.pack_img_in(name="obs.img_in_wt")
         # embed half of obs_out for all steps at once: x3pre = embed @ W_obs[:, De:]^T
         ops.gemm(v2(embed_tm, E), P.obs_out.W[:, De:], v2(x3pre, Hd))
         # Reset blends (networks.py:183-191) off the per-step critical path: the action blend needs no state (one
@@ -639,7 +684,10 @@ class RSSMEngine:
         fuse = ((De % 256 == 0 and De <= 1024) or (De % 1024 == 0 and De <= 4096)) and _FUSE_BLEND
         fuse_in = fuse and gather and _FUSE_SAMPLE_IN and ops.sample_linear_ln_ok(S, D, Hd) and Hd % 4 == 0
         fuse_row = _FUSE_SCAN_ROW and _FUSE_SCAN_LN and B <= 64 and ops.scan_ln_gemm_ok(Hd, SD)
+        Cuts.mark("wm.fscan")  # (pipelined capture: the forward scan is a lane segment of its own)
         for t in range(T):
+            if T >= 16 and t == (3 * T) // 4:
+                Cuts.mark("wm.fscan2")  # (... cut where the host queues the join behind it, as in the reverse scan)
             if t == 0 or not fuse:
                 prev_s = post_stoch[t - 1].view(B, SD) if t > 0 else (None if state0 is None else state0[0])
                 prev_d = deter[t - 1] if t > 0 else (None if state0 is None else state0[1])
@@ -679,6 +727,7 @@ class RSSMEngine:
                                   next_blend=(first[t + 1], s0.view(SD), sin[t + 1].view(B, S, D), init_idx,
                                               idx_in[t + 1].view(-1)) if nxt else None,
                                   forced=None if f_post is None else f_post[t], flips=flips, idx=post_idx[t].view(-1))
+        Cuts.mark("wm.mid")
         # prior head for all steps at once
         x2pre, x2 = g("obs.x2pre", (T, B, Hd)), g("obs.x2", (T, B, Hd))
         m2, r2 = g("obs.m2", (T, B)), g("obs.r2", (T, B))
@@ -838,11 +887,11 @@ class RSSMEngine:
         return side
 
     # -- one img_step on a row block (networks.py:208-233), used by the policy path and imagine ---------
-    def pack_img_in(self, defer=None):
+    def pack_img_in(self, defer=None, name="rssm.img_in_wt"):
         """Transposed copy of the img_in weight, [Hd, SD+A] -> [SD+A, Hd], for the one-hot gather path of img_step
         (once per update: the world model's weights are frozen during imagination, models.py:335)."""
         W = self.P.img_in.W
-        wt = self.ws.get("rssm.img_in_wt", (W.shape[1], W.shape[0]))
+        wt = self.ws.get(name, (W.shape[1], W.shape[0]))
         if defer is not None:
             defer.append((W, wt))
         else:

@@ -1,6 +1,6 @@
 """hipGraph replay of the training update and of the acting step.
 
-One update is ~1750 short kernel launches (two sequential scans of small GEMMs); launched eagerly
+One update is ~1130 short kernel launches (two sequential scans of small GEMMs); launched eagerly
 from Python it is host-bound.  The launch sequence is static (fixed shapes, no host reads, RNG and
 Adam step counters live in device memory), so it is captured once into HIP graphs and replayed:
 MI355X-native replacement for the reference's (inert) torch.compile switch (dreamer.py:75-79).
@@ -24,6 +24,27 @@ class CaptureRefused(RuntimeError):
     asynchronous HIP fault propagate to the caller."""
 
 
+# What the HIP runtime says when it refuses stream capture or graph instantiation (hipErrorStreamCapture*,
+# hipErrorCapturedEvent, hipErrorGraphExecUpdateFailure and the texts hipGetErrorString gives them).  Anything else --
+# an autograd error that happens to mention a "graph", a shape bug -- is NOT a refusal and propagates.
+_CAPTURE_REFUSALS = (
+    "hiperrorstreamcapture", "cudaerrorstreamcapture", "hiperrorcapturedevent", "hiperrorgraphexecupdatefailure",
+    "operation not permitted when stream is capturing", "operation failed due to a previous error during capture",
+    "operation would result in a merge of separate capture sequences",
+    "capture was not ended in the same stream as it began", "capturing stream has unjoined work",
+    "dependency created on uncaptured work in another stream",
+    "operation would make the legacy stream depend on a capturing blocking stream",
+    "operation not permitted on an event last recorded in a capturing stream",
+    "attempt to terminate a thread-local capture sequence from another thread",
+    "hipgraphinstantiate", "cudagraphinstantiate", "graph instantiation",
+)
+
+
+def _is_capture_refusal(e: BaseException) -> bool:
+    msg = str(e).lower()
+    return any(t in msg for t in _CAPTURE_REFUSALS)
+
+
 def _capture(graph, fn, **kw):
     """Run fn under stream capture into `graph`; translate a refusal of the capture itself into CaptureRefused."""
     try:
@@ -32,8 +53,7 @@ def _capture(graph, fn, **kw):
     except _lib.DV3Error:
         raise
     except RuntimeError as e:
-        msg = str(e).lower()
-        if "captur" in msg or "graph" in msg:
+        if _is_capture_refusal(e):
             raise CaptureRefused(f"{type(e).__name__}: {e}") from e
         raise
 
@@ -120,8 +140,7 @@ class SegmentRecorder:
         except _lib.DV3Error:
             raise
         except RuntimeError as e:
-            msg = str(e).lower()
-            if "captur" in msg or "graph" in msg:
+            if _is_capture_refusal(e):
                 raise CaptureRefused(f"{type(e).__name__}: {e}") from e
             raise
         finally:
@@ -189,6 +208,89 @@ class SegmentRecorder:
         trace.append((lane, a, b))
 
 
+# Schedule of the pipelined update (UpdateRunner.step_pipelined).  a_split / c_split: step index at which the rollout /
+# reverse rollout leaves the side lane for the whole chip (None: all of it on the lane); defer: where the world model's
+# deferred weight gradients run ("side": behind the reverse rollout on the side lane; "post" / "mid": in line on the
+# whole chip).  Development switches DV3_PIPE_* (build.py --dev) override for A/B runs.
+_PIPE_PLAN = dict(on=_dev.flag("DV3_PIPE", True), a_split=_dev.value("DV3_PIPE_A_SPLIT", 0) or None,
+                  c_split=_dev.value("DV3_PIPE_C_SPLIT", 0) or None, defer=_dev.value("DV3_PIPE_DEFER", "side", str),
+                  late=_dev.flag("DV3_PIPE_LATE", True))
+
+
+class PhaseRecorder:
+    """Capture of one phase of the update (world model, or behaviour) as LABELLED hipGraph segments.  The code being
+    captured calls engine.Cuts.mark(label) where a segment ends; UpdateRunner.step_pipelined then places the segments of
+    two different updates side by side: the behaviour phase of update k beside the world-model phase of update k+1.
+
+    lane_of(label) -> "main" | "scan" | "side": the stream a segment is CAPTURED on.  A hipGraph takes the CU mask of
+    the stream it is launched on, so the lane is decided at replay; but the per-stream scratch buffers of dv3hip.ops
+    are keyed by the capture stream, so two segments that may run at the same time are captured on different
+    streams.  Labels with an "@" are optional cuts: taken only when listed in `optional`."""
+
+    def __init__(self, pool, device, lanes, lane_of, first_label, optional=()):
+        self.pool, self.device, self.lanes = pool, device, lanes
+        self.lane_of, self.first, self.optional = lane_of, first_label, set(optional)
+        self.segments = []  # (label, graph) in capture order
+        self._cur = None
+
+    def _begin(self, label):
+        g = torch.cuda.CUDAGraph()
+        kw = dict(pool=self.pool, capture_error_mode="thread_local")
+        lane = self.lane_of(label)
+        if lane != "main":
+            kw["stream"] = self.lanes.streams[lane]
+        ctx = torch.cuda.graph(g, **kw)
+        ctx.__enter__()
+        self._cur = (label, g, ctx)
+
+    def _end(self, *exc):
+        label, g, ctx = self._cur
+        self._cur = None
+        ctx.__exit__(*(exc or (None, None, None)))
+        if not exc or exc[0] is None:
+            self.segments.append((label, g))
+
+    def mark(self, label):
+        if "@" in label and label not in self.optional:
+            return
+        self._end()
+        self._begin(label)
+
+    def record(self, fn, at_end=None):
+        """at_end: called inside the last segment (PhasedRng.finish_phase)."""
+        from . import engine
+
+        if engine.Cuts.recorder is not None:
+            raise RuntimeError("nested PhaseRecorder")
+        engine.Cuts.recorder = self
+        try:
+            self._begin(self.first)
+            try:
+                fn()
+                if at_end is not None:
+                    at_end()
+            except BaseException as e:
+                if self._cur is not None:
+                    try:
+                        self._end(type(e), e, e.__traceback__)
+                    except Exception:  # the capture is already broken: the first error is the one to report
+                        pass
+                raise
+            self._end()
+        except _lib.DV3Error:
+            raise
+        except RuntimeError as e:
+            if _is_capture_refusal(e):
+                raise CaptureRefused(f"{type(e).__name__}: {e}") from e
+            raise
+        finally:
+            engine.Cuts.recorder = None
+        return self
+
+    def by_label(self):
+        return dict(self.segments)
+
+
 class UpdateRunner:
     def __init__(self, wm, beh, use_graph: bool = True, warm: int = 2):
         self.wm, self.beh = wm, beh
@@ -206,6 +308,11 @@ class UpdateRunner:
         self._home = None  # ("whole", stream) or ("caller", None): where the first call put the update
         self.last_metrics = {}
         self.last_post = self.last_context = self.last_data = None  # what a further behaviour (Plan2Explore) trains on
+        # two-update software pipeline (step_pipelined / flush): labelled segments of both phases + their schedule
+        self._pipe = None
+        self._pipe_trace = None
+        self._pipe_pending = False  # a world-model phase has been issued whose behaviour phase has not
+        self.pipe_plan = dict(_PIPE_PLAN)
 
     # -- the two halves of one update -----------------------------------------------------------------
     # World-model half: [fwd+bwd as per-lane graphs] -> all-reduce -> [clip+Adam].  Behaviour half: [imagine, returns,
@@ -334,6 +441,8 @@ class UpdateRunner:
     def step(self, data, eager: bool = False):
         """One full update.  data: dict of device tensors (image uint8 [B,T,64,64,3], action, reward, is_first,
         is_terminal ...)."""
+        self.flush()
+
         def both():
             self._wm_half(data, eager)
             self._beh_half(eager)
@@ -341,11 +450,236 @@ class UpdateRunner:
 
         self._on_launch_stream(both)
 
+    # -- two-update software pipeline ----------------------------------------------------------------------
+    # The reference issues its updates back to back inside one agent call -- `for _ in range(steps):
+    # self._train(next(self._dataset))` (dreamer.py:95-97; 2 per call at the dmc configs, 100 at pretrain).  Within such a
+    # run the behaviour phase of update k only READS the world model that update k's Adam step left behind, and the
+    # world-model phase of update k+1 reads the same weights and a fresh batch: the two are independent until update
+    # k+1's own Adam step.  step_pipelined() therefore issues world model k+1 BESIDE behaviour k: the two observe scans
+    # of the world-model phase are chains of dependent 16-row launches that cannot use more than half of the chip
+    # (DESIGN.md section 4), and the behaviour phase's rollout and reverse rollout -- themselves chains of 1024-row
+    # launches -- run on the other half meanwhile (engine.Lanes: complementary CU masks).  Every number is the serial
+    # sequence's: the same weights are read (world-model Adam k+1 is ordered behind behaviour k's last read of them),
+    # the posterior of update k is copied out before scan k+1 overwrites it ("bh.start"), and each phase draws from
+    # the Philox counters the serial order would have given it (ops.PhasedRng).  flush() issues the last behaviour
+    # phase alone; anything that reads the actor or the critic (Dreamer._policy, a checkpoint) comes after a flush.
+    def pipeline_available(self) -> bool:
+        from . import engine
+
+        if not self.use_graph or self._home is None or self._home[0] != "whole":
+            return False
+        return engine.Lanes._by_dev.get(str(torch.device("cuda", self._home[1].device.index))) is not None
+
+    def step_pipelined(self, data):
+        """Like step(), but the behaviour phase of this update is issued only with the NEXT call (beside that update's
+        world-model phase) or by flush().  Falls back to step() where the pipeline is not available (eager warm-up
+        calls, no CU-masked streams, a caller on a stream of its own)."""
+        def run():
+            if not self._pipe_pending:
+                # prologue: nothing to run beside -- the serial world-model half (its own per-lane graphs)
+                self._wm_half(data)
+                if self._replaying(False) and self.pipeline_available() and self.pipe_plan.get("on", True):
+                    self._pipe_pending = True
+                    self.last_metrics = dict(self._m1)
+                else:
+                    self._beh_half()
+                    self.last_metrics = {**self._m1, **self._m2}
+                return
+            if self._pipe is None:
+                torch.cuda.synchronize()
+                try:
+                    self._capture_pipe()
+                except CaptureRefused as e:
+                    self._refused(e)
+                    self._pipe_pending = False
+                    self._beh_half()
+                    return self.step(data)
+            if not self._pipe["entered"]:
+                self._pipe_enter()
+            self._load(data)
+            self._calls += 1
+            self._pipe_iteration()
+            cap = self._pipe["cap"]
+            self._m1, self._m2 = cap["m1"], cap["beh_out"][-1]
+            self._beh_out = cap["beh_out"]
+            self.last_post, self.last_context, self.last_data = cap["post"], cap["ctx"], self._static
+            self.last_metrics = {**self._m1, **self._m2}
+
+        self._on_launch_stream(run)
+
+    def flush(self):
+        """Issue the behaviour phase step_pipelined() has left pending (no-op otherwise)."""
+        if not self._pipe_pending:
+            return
+
+        def run():
+            self._pipe_pending = False
+            if self._pipe is not None and self._pipe["entered"]:
+                self._pipe_leave()
+            self._beh_half()
+            self.last_metrics = dict(self._m2)
+
+        self._on_launch_stream(run)
+
+    def _capture_pipe(self):
+        """Both phases as labelled segments (PhaseRecorder) against Philox states of their own, and their optimizer
+        graphs.  Records only: nothing executes."""
+        import tools
+        from . import engine
+
+        wm, beh = self.wm, self.beh
+        dev = next(iter(self._static.values())).device
+        lanes = engine.Lanes.get(dev)
+        plan = self.pipe_plan
+        rng_wm, rng_beh = ops.PhasedRng(dev), ops.PhasedRng(dev)
+        key_dev = wm.dynamics.W.device
+        lane_wm = lambda lb: {"wm.fscan": "scan", "wm.fscan2": "scan", "wm.rscan": "scan", "wm.rscan2": "scan",
+                              "wm.defer": "side"}.get(lb, "main")
+        lane_beh = lambda lb: "side" if lb.startswith(("bh.A", "bh.C")) else "main"
+        opt_cuts = [f"bh.A@{plan['a_split']}"] if plan.get("a_split") else []
+        opt_cuts += [f"bh.C@{plan['c_split']}"] if plan.get("c_split") else []
+        cap = {}
+        # separate graph pools: the two phases replay in an order other than the capture order
+        pool_w, pool_b = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        with tools.rng_override(key_dev, rng_wm):
+            W = PhaseRecorder(pool_w, dev, lanes, lane_wm, "wm.pre").record(
+                lambda: wm.train_fwd_bwd(self._static), at_end=rng_wm.finish_phase)
+            gw = torch.cuda.CUDAGraph()
+
+            def wopt():
+                cap["post"], cap["ctx"], cap["m1"] = wm.train_opt(allreduce=False)
+
+            _capture(gw, wopt, pool=pool_w)
+        with tools.rng_override(key_dev, rng_beh):
+            B = PhaseRecorder(pool_b, dev, lanes, lane_beh, "bh.start", optional=opt_cuts).record(
+                lambda: beh.train_fwd_bwd(cap["post"]), at_end=rng_beh.finish_phase)
+            gb = torch.cuda.CUDAGraph()
+            _capture(gb, lambda: cap.update(beh_out=beh.train_opt(allreduce=False)), pool=pool_b)
+        stride = rng_wm.taken + rng_beh.taken
+        rng_wm.stride.fill_(stride), rng_beh.stride.fill_(stride)
+        mk = lambda: torch.cuda.Event(blocking=True)
+        self._pipe = dict(W=W.segments, B=B.segments, wopt=gw, bopt=gb, cap=cap, rng_wm=rng_wm, rng_beh=rng_beh,
+                          lanes=lanes, entered=False, shared=tools.default_rng(key_dev),
+                          ev={k: mk() for k in ("tail", "fork1", "q1", "mid", "fork2", "q2")})
+
+    def _pipe_enter(self):
+        """The serial world-model half of update k has run (shared Philox offset S + w): behaviour k draws from there,
+        world model k+1 behind behaviour k's counters."""
+        P = self._pipe
+        sh = P["shared"]
+        sh.commit()
+        P["rng_beh"].state.copy_(sh.state)
+        P["rng_wm"].state.copy_(sh.state)
+        P["rng_wm"].state[1:2].add_(P["rng_beh"].taken)
+        P["entered"] = True
+
+    def _pipe_leave(self):
+        """Back to the shared stream in front of the serial behaviour half: it continues where the pending phase draws."""
+        P = self._pipe
+        P["shared"].state.copy_(P["rng_beh"].state)
+        P["entered"] = False
+
+    def _pipe_iteration(self):
+        """World-model phase of update k+1 beside the behaviour phase of update k.
+
+          main   [bh.start . wm.pre]      [wm.mid . bh.B]                  [wm.post . bh.D] -> all-reduce -> [Adam x3]
+          scan              [forward scan k+1]           [reverse scan k+1]
+          side              [rollout k       ]           [reverse rollout k . deferred weight gradients k+1]
+
+        The host queues a lane segment LATE (once the GPU is within a segment of the fork) and the join LATE (once the
+        scan is three quarters through): a queue whose head is a blocked barrier packet costs every dependent launch
+        of the other queues ~1.3 us ("Compute-unit lanes")."""
+        import torch.distributed as dist
+
+        P = self._pipe
+        W, B, ev, plan = dict(P["W"]), dict(P["B"]), P["ev"], self.pipe_plan
+        L = P["lanes"].streams
+        scan, side = L["scan"], L["side"]
+        cur = torch.cuda.current_stream()
+        late = plan.get("late", True)
+
+        trace = self._pipe_trace  # tools/pipe_bench.py: a list that receives (label, start event, end event)
+
+        def run(segs, labels, stream=None):
+            with torch.cuda.stream(stream if stream is not None else cur):
+                for lb in labels:
+                    g = segs.get(lb)
+                    if g is None:
+                        continue
+                    if trace is None:
+                        g.replay()
+                        continue
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    g.replay()
+                    b.record()
+                    trace.append((lb, a, b))
+
+        a_rest = [lb for lb in B if lb.startswith("bh.A@")]  # (the part of the rollout the plan keeps off the lane)
+        c_rest = [lb for lb in B if lb.startswith("bh.C@")]
+        # ---- stage 1 (whole chip): the posterior of update k leaves the scan's buffers; encoder of update k+1
+        ev["tail"].record(cur)
+        run(B, ["bh.start"])
+        run(W, ["wm.pre"])
+        ev["fork1"].record(cur)
+        if late:
+            ev["tail"].synchronize()  # (the GPU has finished the previous call's tail: the lanes' wait below is short)
+        scan.wait_event(ev["fork1"]), side.wait_event(ev["fork1"])
+        # ---- stage 2 (lanes): forward scan k+1 | rollout k
+        run(W, ["wm.fscan"], scan)
+        ev["q1"].record(scan)
+        run(W, ["wm.fscan2"], scan)
+        run(B, ["bh.A"], side)
+        if late and "wm.fscan2" in W:
+            ev["q1"].synchronize()  # (three quarters through the scan: queue the join and what follows it)
+        cur.wait_stream(scan), cur.wait_stream(side)
+        # ---- stage 3 (whole chip): decoder / heads of update k+1, heads / returns / critic of update k
+        run(W, ["wm.mid"])
+        ev["mid"].record(cur)
+        run(B, a_rest + ["bh.B", "bh.B@critic", "bh.B@dyn"])
+        if plan.get("defer") == "mid":
+            run(W, ["wm.defer"])
+        ev["fork2"].record(cur)
+        if late:
+            ev["mid"].synchronize()
+        scan.wait_event(ev["fork2"]), side.wait_event(ev["fork2"])
+        # ---- stage 4 (lanes): reverse scan k+1 | reverse rollout k (+ the deferred weight gradients of update k+1)
+        run(W, ["wm.rscan"], scan)
+        ev["q2"].record(scan)
+        run(W, ["wm.rscan2"], scan)
+        run(B, ["bh.C"], side)
+        if plan.get("defer", "side") == "side":
+            run(W, ["wm.defer"], side)
+        if late and "wm.rscan2" in W:
+            ev["q2"].synchronize()
+        cur.wait_stream(scan), cur.wait_stream(side)
+        # ---- stage 5 (whole chip): encoder backward + scan weight gradients k+1, actor backward k, optimizers
+        run(W, ["wm.post"])
+        if plan.get("defer") == "post":
+            run(W, ["wm.defer"])
+        mb = self.wm._model_opt.bucket
+        work = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # the model gradient's all-reduce runs on RCCL's stream beside the actor's backward
+            work = dist.all_reduce(mb.grad, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            mb.allreduce()  # (no-op on one rank; the forced one-rank collective of the development build)
+        run(B, c_rest + ["bh.D"])
+        if work is not None:
+            work.wait()
+        P["wopt"].replay()
+        self.beh._actor_opt.bucket.allreduce()
+        self.beh._value_opt.bucket.allreduce()
+        self.beh.sync_ema()
+        P["bopt"].replay()
+
     # -- the reference's two calls ------------------------------------------------------------------------
     def train_wm(self, data):
         """WorldModel._train(data) (models.py:108-171) through the runner -> (post, context, metrics).  data: what the
         reference hands its world model (a dict of host arrays from the replay sampler), or device tensors."""
         from models import _wrap, DeviceScalar
+
+        self.flush()
 
         def run():
             host = all(not isinstance(v, torch.Tensor) for v in data.values())

@@ -656,6 +656,29 @@ class RngStream:
         self.cursor = 0
 
 
+class PhasedRng(RngStream):
+    """The Philox state of ONE phase of the update (world model or behaviour) while the phases of two different updates
+    run side by side (graph.UpdateRunner.step_pipelined).  The serial stream hands out counter ranges in launch order
+    -- world model k takes [S, S + w), behaviour k [S + w, S + w + b), world model k+1 starts at S + w + b -- and the
+    two phases cannot share one device offset once behaviour k runs beside world model k+1.  Each phase therefore
+    carries its own {seed, offset}; a phase's draws use launch-argument offsets from its own state as before, and the
+    phase ends with `offset += stride`, stride = w + b (a device scalar the runner fills once both phases have been
+    captured): the numbers drawn are exactly those of the serial stream."""
+
+    def __init__(self, device):
+        super().__init__(device, 0)
+        self.stride = torch.zeros(1, dtype=torch.int64, device=device)
+        self.taken = 0  # counters one phase takes (known once the phase has been traced)
+
+    def commit(self):
+        pass  # the phase's captured sequence ends with finish_phase() instead
+
+    def finish_phase(self):
+        """Last launch of the phase's captured sequence: advance the state past this update's draws of BOTH phases."""
+        self.taken, self.cursor = self.cursor, 0
+        self.state[1:2].add_(self.stride)
+
+
 def onehot_sample(logit, out, *, noise=None, rng=None, idx=None, unimix=0.01, mode=False, next_blend=None,
                   forced=None, flips=None):
     """next_blend = (next_first [B], init [S*D], next_out [B,S,D]) for logit [B,S,D]: also write the next observe

@@ -544,6 +544,9 @@ class ImagBehavior(nn.Module):
         # that reads it (actor layer 0, img_in) gather weight columns instead of multiplying zeros (engine.py).
         idx = g("im.idx", (H, N, S), torch.int32)
         ops.onehot_to_idx(stoch[0].view(N, S, D), idx[0].view(-1))  # class indices of the start states
+        # (pipelined capture, graph.UpdateRunner.step_pipelined: everything up to here reads the posterior of the world
+        # model's scan and runs BEFORE the next update's scan overwrites it; the rollout below runs beside that scan)
+        E.Cuts.mark("bh.A")
         if _FUSED_IMAG and not packed:
             tr = []
             actor_eng.pack_onehot(SD, defer=tr)
@@ -554,6 +557,8 @@ class ImagBehavior(nn.Module):
             """The H-step rollout of the row range rc (rows are independent: models.py:450-451 flattens [B,T])."""
             n, r0 = rc.stop - rc.start, rc.start
             for t in range(H):
+                if t:
+                    E.Cuts.mark(f"bh.A@{t}")  # (optional cut: the schedule may move the rest of the rollout off the lane)
                 nz_act = None if act_noise is None else act_noise[t][rc]
                 if _FUSED_IMAG:
                     head = dict(action=action[t][rc], ent=ent[t][rc], rng=rng, onehot=not normal, flips=flips,
@@ -710,6 +715,7 @@ class ImagBehavior(nn.Module):
                 rssm.pack_img_in(defer=tr)
             ops.transpose2d_many(tr)
         self._imagine_fwd(start, H, noise, packed=True)
+        E.Cuts.mark("bh.B")
         im = self._im
         N = im["N"]
         HN, H1N = H * N, (H - 1) * N
@@ -790,8 +796,10 @@ class ImagBehavior(nn.Module):
                 ops.disc_logprob_bwd(v_logits[:R], slow.view(R), up_v, dvl, accumulate=True)
             veng.backward(fs[:R], fd[:R], slice(0, R), dout=dvl, wgrad=True)
 
+        E.Cuts.mark("bh.B@critic")
         side = E.SideStream(fs.device)
         side.run([_critic], chain=False)  # (what follows fills the chip: in line unless the plain second stream is on)
+        E.Cuts.mark("bh.B@dyn")
         # ---- dynamics backprop: target -> reward / cont heads -> imagined states -> actions
         daction = g("bh.daction", (H, N, A))
         if not reinforce:
@@ -825,13 +833,17 @@ class ImagBehavior(nn.Module):
             scratch = dict(dlogit=g("bh.s.dlogit", (N, SD)), dx2=g("bh.s.dx2", (N, Hd)), dx2pre=g("bh.s.dx2pre", (N, Hd)),
                            dgpre=g("bh.s.dgpre", (N, 3 * De)), dx1=g("bh.s.dx1", (N, Hd)),
                            dx1pre=g("bh.s.dx1pre", (N, Hd)))
+            E.Cuts.mark("bh.C")  # the reverse rollout: a chain of dependent 1024-row launches
             for t in range(H - 1, 0, -1):
+                if t < H - 1:
+                    E.Cuts.mark(f"bh.C@{t}")
                 b = {k: v[t - 1] for k, v in im["step"].items()}
                 b.update(logit=im["logit"][t].view(N, S, D))
                 # state gradients flow straight into gs/gd[t-1] (which already hold the heads' gradient);
                 # step 0 is the detached start state: its slot is scratch
                 rssm.img_step_bwd(gs[t], gd[t], deter[t - 1], b, scratch, gs[t - 1], gd[t - 1], daction[t - 1],
                                   accumulate_prev=t > 1, wt=wt_bwd)
+            E.Cuts.mark("bh.D")
             if g_act is not None:
                 # an action-conditioned objective: reward_t depends on action_t directly, including the LAST step's
                 # (r_{H-1} enters the return of step H-2), so the actor's backward below covers all H steps

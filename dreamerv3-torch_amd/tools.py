@@ -288,11 +288,34 @@ class Bernoulli:
 
 
 _DEFAULT_RNG = {}
+_RNG_OVERRIDE = {}
+
+
+class rng_override:
+    """`with tools.rng_override(device, stream):` -- samplers that ask for the default stream of `device` get `stream`
+    (dv3hip.graph.UpdateRunner captures each phase of the pipelined update against a Philox state of its own)."""
+
+    def __init__(self, device, stream):
+        self._key, self._stream = str(torch.device(device)), stream
+
+    def __enter__(self):
+        self._prev = _RNG_OVERRIDE.get(self._key)
+        _RNG_OVERRIDE[self._key] = self._stream
+        return self._stream
+
+    def __exit__(self, *exc):
+        if self._prev is None:
+            _RNG_OVERRIDE.pop(self._key, None)
+        else:
+            _RNG_OVERRIDE[self._key] = self._prev
+        return False
 
 
 def default_rng(device, seed=None):
     """Device-resident Philox stream shared by every sampler that gets no injected noise."""
     key = str(torch.device(device))
+    if seed is None and key in _RNG_OVERRIDE:
+        return _RNG_OVERRIDE[key]
     if key not in _DEFAULT_RNG:
         _DEFAULT_RNG[key] = ops.RngStream(torch.device(device), seed or 0)
     elif seed is not None:
