@@ -1718,11 +1718,9 @@ extern "C" int dv3_convT_s2_fwd(const float* x, const float* w_packed, const flo
     const size_t lds = (size_t)(18 * 18 * (Ci + 8) + 32 * (4 * Ci + 8)) * sizeof(float);
 #define DV3_CT(CI_)                                                                                              \
   {                                                                                                              \
-    static bool attr = false;                                                                                    \
-    if (!attr) {                                                                                                 \
+    static unsigned long long seen[4] = {0, 0, 0, 0};                                                            \
+    if (dv3_first_on_device(seen))                                                                               \
       (void)hipFuncSetAttribute((const void*)convT_s2_tile_kernel<CI_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr = true;                                                                                               \
-    }                                                                                                            \
     hipLaunchKernelGGL((convT_s2_tile_kernel<CI_>), grid, dim3(512), lds, s, p);                                  \
   }
     if (Ci == 16) DV3_CT(16) else if (Ci == 32) DV3_CT(32) else if (Ci == 48) DV3_CT(48) else DV3_CT(64)
@@ -1781,11 +1779,9 @@ extern "C" int dv3_conv_s2_wgrad(const float* coarse, const float* fine, float* 
     if (Ccoarse == 32) {
       hipLaunchKernelGGL((conv_wgrad_c3_kernel<32>), dim3(grid), dim3(256), lds, (hipStream_t)stream, coarse, fine, dw, Nimg, H, W);
     } else {
-      static bool attr = false;
-      if (!attr) {
+      static unsigned long long seen[4] = {0, 0, 0, 0};
+      if (dv3_first_on_device(seen))
         (void)hipFuncSetAttribute((const void*)conv_wgrad_c3_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-      }
       hipLaunchKernelGGL((conv_wgrad_c3_kernel<96>), dim3(grid), dim3(256), lds, (hipStream_t)stream, coarse, fine, dw, Nimg, H, W);
     }
     return (int)hipGetLastError();
@@ -1852,11 +1848,9 @@ extern "C" int dv3_conv_s2_wgrad_tile(const float* coarse, const float* fine, fl
   const long tiles = (long)Nimg * (H / 16) * (W / 16);
   const int G = (int)(tiles < 256 ? tiles : 256);
   const size_t lds = (size_t)(64 * (64 + 16) + 18 * 18 * (32 + 8)) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long seen[4] = {0, 0, 0, 0};
+  if (dv3_first_on_device(seen))
     (void)hipFuncSetAttribute((const void*)conv_wgrad_tile_kernel<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL((conv_wgrad_tile_kernel<32, 64>), dim3(G), dim3(512), lds, s, coarse, fine, partial, Nimg, H, W);
   hipLaunchKernelGGL(conv_wgrad_tile_reduce_kernel, dim3((64 * 16 * 32 + 255) / 256), dim3(256), 0, s, partial, dw, G, 64, 32);

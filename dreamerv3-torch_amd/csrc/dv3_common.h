@@ -15,6 +15,18 @@
 #define DV3_ENV_INT(name, dflt) (dflt)
 #endif
 
+// hipFuncSetAttribute (dynamic LDS above 64 KB) is a PER-DEVICE setting: a launcher remembers per device, not per
+// process, that it has made the call -- a process that drives a second GPU gets the attribute there too.
+// `seen`: a zero-initialised static of the call site (256 device bits).
+static inline bool dv3_first_on_device(unsigned long long (&seen)[4]) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 256) return true;
+  const unsigned long long bit = 1ull << (d & 63);
+  if (seen[d >> 6] & bit) return false;
+  seen[d >> 6] |= bit;
+  return true;
+}
+
 namespace dv3 {
 
 constexpr float kLnEps = 1e-3f;  // every LayerNorm on the path: networks.py:55,66,75,631,754,802

@@ -147,9 +147,11 @@ class SegmentRecorder:
             engine.SideStream.recorder = prev
         return self
 
-    def replay(self, trace=None):
+    def replay(self, trace=None, on_join=None):
         """Launch the segments: consecutive lane segments run side by side, a "main" segment waits for them.
-        trace (tools/wm_bench.py): a list that receives (lane, start event, end event) per segment.
+        trace (tools/wm_bench.py): a list that receives (lane, start event, end event) per segment.  on_join: called once
+        the main stream has been ordered behind the lanes, before the segment that follows them is launched (the
+        deferred weight gradients are complete there: UpdateRunner starts their all-reduce).
 
         A lane segment is NOT put on its queue while the main stream is still far from the fork: a queue whose head is a
         blocked barrier packet costs the other queue ~1.3 us per dependent launch (MI355X, r03: the segment in front of
@@ -183,6 +185,8 @@ class SegmentRecorder:
                     mark2 = None
                 for s in forked:
                     cur.wait_stream(s)
+                if forked and on_join is not None:
+                    on_join()
                 forked = []
                 self._launch(g, cur, lane, trace)
             else:
@@ -344,10 +348,22 @@ class UpdateRunner:
             self._m1, self.last_post, self.last_context, self.last_data = m1, post, ctx, data
             return
         g1, ga = self._g_wm
-        g1.replay()
         # (queueing the collectives only once the segment in front is over -- so that RCCL's stream does not sit blocked
         # beside it -- measured slower under a one-rank RCCL group: 16.43 vs 16.34 ms)
-        self.wm._model_opt.bucket.allreduce()
+        mb = self.wm._model_opt.bucket
+        cut = self._model_cut()
+        if cut is None:
+            g1.replay()
+            mb.allreduce()
+        else:
+            # data parallel: the decoder / head half of the gradient is complete where the lanes join (its weight
+            # gradients ran beside the reverse scan) -- it crosses xGMI while the encoder's backward still runs
+            works = []
+            g1.replay(on_join=lambda: works.append(mb.allreduce_range(cut, None, async_op=True)))
+            works.append(mb.allreduce_range(0, cut if works else None, async_op=True))
+            for w in works:
+                if w is not None:
+                    w.wait()
         ga.replay()
         self._m1, self.last_post, self.last_context, self.last_data = self._cap["m1"], self._cap["post"], self._cap["ctx"], self._static
 
@@ -365,10 +381,24 @@ class UpdateRunner:
         gb, g3 = self._g_beh
         gb.replay()
         self.beh._actor_opt.bucket.allreduce()
-        self.beh._value_opt.bucket.allreduce()
-        self.beh.sync_ema()
+        self.beh._value_opt.bucket.allreduce()  # (the return-normalisation EMA values ride in its tail)
         g3.replay()
         self._beh_out, self._m2 = self._cap["beh_out"], self._cap["beh_out"][-1]
+
+    def _model_cut(self):
+        """Where the world-model gradient bucket is cut into two all-reduces (floats): the first decoder / head
+        parameter -- `heads.*` follows encoder and dynamics in WorldModel.parameters().  None on a single rank."""
+        mb = self.wm._model_opt.bucket
+        if not mb.distributed():
+            return None
+        if "cut" not in self.__dict__:
+            first = next((p for n, p in self.wm.named_parameters() if n.startswith("heads.")), None)
+            off = mb.ensure().offset_of(first) if first is not None else None
+            names = [n for n, _ in self.wm.named_parameters()]
+            i0 = next((i for i, n in enumerate(names) if n.startswith("heads.")), len(names))
+            # (only a contiguous tail can be cut off: every parameter behind the first head parameter is a head's)
+            self.cut = off if off and all(n.startswith("heads.") for n in names[i0:]) else None
+        return self.cut
 
     def _refused(self, e):
         import sys
@@ -385,7 +415,6 @@ class UpdateRunner:
         # before the optimizer run on two CU-masked lanes (engine.Lanes), everything else on the whole chip
         dev = next(iter(self._static.values())).device
         g1 = SegmentRecorder(self._pool, dev).record(lambda: wm.train_fwd_bwd(self._static))
-        wm._model_opt.bucket.allreduce()
         ga = torch.cuda.CUDAGraph()
         cap = self._cap
 
@@ -399,9 +428,6 @@ class UpdateRunner:
         beh = self.beh
         gb, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         _capture(gb, lambda: beh.train_fwd_bwd(self.last_post), pool=self._pool)
-        beh._actor_opt.bucket.allreduce()
-        beh._value_opt.bucket.allreduce()
-        beh.sync_ema()
         _capture(g3, lambda: self._cap.update(beh_out=beh.train_opt(allreduce=False)), pool=self._pool)
         self._g_beh = (gb, g3)
 
@@ -589,8 +615,6 @@ class UpdateRunner:
         The host queues a lane segment LATE (once the GPU is within a segment of the fork) and the join LATE (once the
         scan is three quarters through): a queue whose head is a blocked barrier packet costs every dependent launch
         of the other queues ~1.3 us ("Compute-unit lanes")."""
-        import torch.distributed as dist
-
         P = self._pipe
         W, B, ev, plan = dict(P["W"]), dict(P["B"]), P["ev"], self.pipe_plan
         L = P["lanes"].streams
@@ -653,24 +677,23 @@ class UpdateRunner:
         if late and "wm.rscan2" in W:
             ev["q2"].synchronize()
         cur.wait_stream(scan), cur.wait_stream(side)
-        # ---- stage 5 (whole chip): encoder backward + scan weight gradients k+1, actor backward k, optimizers
+        # ---- stage 5 (whole chip): encoder backward + scan weight gradients k+1, actor backward k, optimizers.  Data
+        # parallel: the model gradient crosses xGMI on RCCL's stream beside them, in two halves -- the decoder / head
+        # half as soon as the lanes have joined (where the deferred weight gradients ran on the side lane)
+        mb = self.wm._model_opt.bucket
+        cut = self._model_cut() if plan.get("defer", "side") == "side" else None
+        works = [mb.allreduce_range(cut, None, async_op=True)] if cut is not None else []
         run(W, ["wm.post"])
         if plan.get("defer") == "post":
             run(W, ["wm.defer"])
-        mb = self.wm._model_opt.bucket
-        work = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # the model gradient's all-reduce runs on RCCL's stream beside the actor's backward
-            work = dist.all_reduce(mb.grad, op=dist.ReduceOp.SUM, async_op=True)
-        else:
-            mb.allreduce()  # (no-op on one rank; the forced one-rank collective of the development build)
+        works.append(mb.allreduce_range(0, cut, async_op=True))
         run(B, c_rest + ["bh.D"])
-        if work is not None:
-            work.wait()
+        for w in works:
+            if w is not None:
+                w.wait()
         P["wopt"].replay()
         self.beh._actor_opt.bucket.allreduce()
         self.beh._value_opt.bucket.allreduce()
-        self.beh.sync_ema()
         P["bopt"].replay()
 
     # -- the reference's two calls ------------------------------------------------------------------------

@@ -95,6 +95,14 @@ _TILE_TEMPLATES = {0: "2, 2, 2, 2, 16, 1", 1: "2, 2, 1, 1, 32, 1", 2: "1, 4, 1, 
                    5: "2, 2, 1, 1, 64, 1", 6: "1, 2, 1, 1, 64, 2", 8: "1, 1, 1, 1, 64, 4"}
 
 
+def _l16_auto_name(M: int, N: int) -> str:
+    """Which k-contiguous LDS tile the library picks for tile 11 and for the split-output entry (csrc/gemm.hip
+    launch_l16): profile keys name the kernel that RUNS, so that bench.py's dominant key is a row of the rocprofv3
+    kernel trace."""
+    wgs = lambda bm, bn: -(-M // bm) * -(-N // bn)
+    return "l16_128x128" if wgs(128, 128) >= 448 else ("l16_64x64" if wgs(64, 64) >= 512 else "l16_32x64")
+
+
 def kernel_symbol(key: str) -> str:
     """Profile key -> the C++ kernel name rocprofv3 prints (to match bench.py's roofline with profiles/)."""
     import re
@@ -274,8 +282,8 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
             tile = 7
     _call("dv3_gemm_f32", int(transA), int(transB), M, N, K, _ptr(A), lda, _ptr(A2), lda2, K1, _ptr(B), ldb,
           _ptr(C), ldc, _ptr(bias), acc_flag, tile, s,
-          key=(f"gemm_kernel<{_TILE_NAMES[tile]},tA={int(transA)},tB={int(transB)}>"
-               + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else "")), flops=2.0 * M * N * K,
+          key=(f"gemm_kernel<{_l16_auto_name(M, N) if tile == 11 else _TILE_NAMES[tile]},tA={int(transA)},"
+               f"tB={int(transB)}>" + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else "")), flops=2.0 * M * N * K,
           nbytes=4.0 * (M * K + N * K + M * N))
     return C
 
@@ -350,8 +358,8 @@ def gemm_split(A, B, C, C2, *, accumulate=False, accumulate2=False):
         raise ValueError("gemm_split shapes mismatch")
     _call("dv3_gemm_split_f32", M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(C), ldc, int(bool(accumulate)), _ptr(C2),
           ldc2, n1, int(bool(accumulate2)), _stream(),
-          key="gemm_kernel<l16,tA=0,tB=1>" + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else ""), flops=2.0 * M * N * K,
-          nbytes=4.0 * (M * K + N * K + M * N))
+          key=f"gemm_kernel<{_l16_auto_name(M, N)},tA=0,tB=1>" + (f"[{M}x{N}x{K}]" if PROFILE.by_shape else ""),
+          flops=2.0 * M * N * K, nbytes=4.0 * (M * K + N * K + M * N))
 
 
 def ln_act_fwd(x, gamma, beta, y, mean=None, rstd=None, *, act=True, chw_group=0):

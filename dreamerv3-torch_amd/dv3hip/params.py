@@ -22,14 +22,18 @@ _ALIGN = 4  # floats: keep every tensor 16-byte aligned inside the bucket
 
 
 class ParamBucket:
-    def __init__(self, name: str, params: Iterable[torch.nn.Parameter], allow_cpu: bool = False):
+    def __init__(self, name: str, params: Iterable[torch.nn.Parameter], allow_cpu: bool = False, extra: int = 0):
         """allow_cpu: layout + all-reduce logic on CPU tensors (multi-process gloo tests); step() still
-        needs the GPU kernels."""
+        needs the GPU kernels.  extra: floats that ride behind the gradients through the same all-reduce (`tail`: the
+        two return-normalisation EMA values travel with the critic's gradient instead of in a collective of their own);
+        they are not parameters -- clipping and Adam never see them."""
         self.name = name
         self.params: List[torch.nn.Parameter] = [p for p in params]
         self.flat = None
         self._layout = None
         self._allow_cpu = allow_cpu
+        self._extra = int(extra)
+        self.tail = None
 
     # ------------------------------------------------------------------------------------------
     def _needs_build(self) -> bool:
@@ -55,7 +59,10 @@ class ParamBucket:
             layout.append((total, n))
             total += (n + _ALIGN - 1) // _ALIGN * _ALIGN
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        extra = (self._extra + _ALIGN - 1) // _ALIGN * _ALIGN
+        wire = torch.zeros(total + extra, dtype=torch.float32, device=dev)  # what crosses xGMI: gradients | tail
+        grad = wire[:total]
+        self._wire, self.tail = wire, (wire[total:total + self._extra] if self._extra else None)
         old_m = getattr(self, "exp_avg", None)
         for p, (off, n) in zip(self.params, layout):
             flat[off:off + n].copy_(p.data.reshape(-1).to(torch.float32))
@@ -75,13 +82,36 @@ class ParamBucket:
         self.grad.zero_()
 
     # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def distributed() -> bool:
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_ALLREDUCE)
+
     def allreduce(self) -> float:
-        """Sum gradients over ranks (RCCL when the process group is NCCL); returns the scale (1/world)
+        """Sum gradients (and the tail) over ranks (RCCL when the process group is NCCL); returns the scale (1/world)
         the optimizer must apply.  No-op on a single rank."""
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE_ALLREDUCE):
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+        if self.distributed():
+            dist.all_reduce(self._wire, op=dist.ReduceOp.SUM)
             return 1.0 / dist.get_world_size()
         return 1.0
+
+    def offset_of(self, param) -> int:
+        """Start of `param` in the flat buffers (floats): where a caller may cut the bucket into two collectives."""
+        for p, (off, _) in zip(self.params, self._layout):
+            if p is param:
+                return off
+        raise ValueError(f"{self.name}: not a parameter of this bucket")
+
+    def allreduce_range(self, lo: int, hi: int = None, async_op: bool = False):
+        """The collective of allreduce() on floats [lo, hi) of the wire buffer only (hi=None: to its end, tail included).
+        A sum over ranks is elementwise: two ranges reduce to exactly what one call over both would.  The world-model
+        bucket is cut where its decoder / head gradients end, so that their half crosses xGMI while the encoder's
+        backward still runs (graph.UpdateRunner).  -> the work handle (async_op) or None."""
+        if not self.distributed():
+            return None
+        hi = self._wire.numel() if hi is None else hi
+        if hi <= lo:
+            return None
+        return dist.all_reduce(self._wire[lo:hi], op=dist.ReduceOp.SUM, async_op=async_op)
 
     def step(self, *, lr, eps, clip, weight_decay=0.0, grad_scale=1.0):
         """clip_grad_norm_ + Adam on the whole bucket; the pre-clip norm lands in state[2]."""

@@ -438,8 +438,10 @@ class ImagBehavior(nn.Module):
         kw = dict(wd=config.weight_decay, opt=config.opt, use_amp=False)
         self._actor_opt = tools.Optimizer("actor", list(self.actor.parameters()), config.actor["lr"],
                                           config.actor["eps"], config.actor["grad_clip"], **kw)
+        # (data parallel: the two return-normalisation EMA values ride behind the critic's gradient through ITS all-reduce)
         self._value_opt = tools.Optimizer("value", list(self.value.parameters()), config.critic["lr"],
-                                          config.critic["eps"], config.critic["grad_clip"], **kw)
+                                          config.critic["eps"], config.critic["grad_clip"],
+                                          extra=2 if config.reward_EMA else 0, **kw)
         if self._config.reward_EMA:
             self.register_buffer("ema_vals", torch.zeros((2,), device=self._config.device))
             self.reward_ema = RewardEMA(device=self._config.device)
@@ -491,13 +493,14 @@ class ImagBehavior(nn.Module):
     def _imagine_generic(self, start, policy, horizon):
         """models.py:448-548 for a foreign `policy` (any callable feat -> distribution with .sample()): the rollout
         step by step through the public RSSM methods, i.e. through dv3hip.autograd when gradients are wanted, so the
-        returned feats / states / actions carry a graph exactly as the reference's do.  Rows are b*T+t as there."""
+        returned states / actions carry a graph as the reference's do; the returned feats are DETACHED, as the
+        reference's are (models.py:513-517: `feat = get_feat(state).detach()`).  Rows are b*T+t as there."""
         dyn = self._world_model.dynamics
         state = {k: v.reshape((-1,) + tuple(v.shape[2:])) for k, v in start.items()}
         feats, states, actions = [], [], []
         for t in range(horizon):
-            feat = dyn.get_feat(state)
-            action = policy(feat.detach()).sample()
+            feat = dyn.get_feat(state).detach()
+            action = policy(feat).sample()
             feats.append(feat), states.append(state), actions.append(action)
             if t < horizon - 1:  # the H-th successor is discarded by the reference (models.py:546)
                 state = dyn.img_step(state, action)
@@ -666,22 +669,32 @@ class ImagBehavior(nn.Module):
         return r, leaves
 
     def sync_ema(self):
-        """Data parallel: the return-normalisation EMA is computed from each rank's own imagined returns; average the
-        two floats over the ranks so that the replicas normalise alike (the reference is single-process).  Eager
-        collective, outside any hipGraph segment; no-op on one rank."""
-        import torch.distributed as dist
+        """Data parallel: the return-normalisation EMA is computed from each rank's own imagined returns and averaged
+        over the ranks so that the replicas normalise alike (the reference is single-process).  The two floats travel
+        in the tail of the critic's gradient bucket (ema_to_wire / ema_from_wire around ITS all-reduce: three
+        collectives per update, not four); kept as a public no-op for callers of the earlier interface."""
 
-        if self._config.reward_EMA and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.ema_vals, op=dist.ReduceOp.SUM)
-            self.ema_vals.mul_(1.0 / dist.get_world_size())
+    def _ema_on_wire(self):
+        return bool(self._config.reward_EMA) and ParamBucket.distributed()
+
+    def ema_to_wire(self):
+        """After the backward, before the critic's all-reduce: this rank's EMA values into the bucket's tail."""
+        if self._ema_on_wire():
+            self._value_opt.bucket.ensure().tail.copy_(self.ema_vals)
+
+    def ema_from_wire(self):
+        """After the critic's all-reduce: the mean over the ranks."""
+        if self._ema_on_wire():
+            import torch.distributed as dist
+
+            torch.mul(self._value_opt.bucket.tail, 1.0 / dist.get_world_size(), out=self.ema_vals)
 
     def train_opt(self, allreduce=True):
         ret, metrics, losses = self._pending
         metrics = dict(metrics)
-        if allreduce:
-            self.sync_ema()
         metrics.update(self._actor_opt.finish(losses[0], allreduce))
         metrics.update(self._value_opt.finish(losses[1], allreduce))
+        self.ema_from_wire()
         return ret + (_wrap(metrics),)
 
     def train_fwd_bwd(self, start, noise=None, objective=None):
@@ -882,6 +895,7 @@ class ImagBehavior(nn.Module):
             metrics["EMA_005"], metrics["EMA_095"] = ema[0], ema[1]
         metrics.update(tools.tensorstats_many(groups))
         metrics["actor_entropy"] = acc[2]
+        self.ema_to_wire()
         self._last = dict(reward=reward, value=value, target=target, weights=weights, disc=disc, slow=slow)
         imag_state = {"stoch": stoch.view(H, N, S, D), "deter": deter, "logit": im["logit"].view(H, N, S, D)}
         self._pending = ((None, imag_state, action, weights.view(H, N, 1)), metrics, (acc[0], acc[1]))

@@ -419,7 +419,7 @@ class Optimizer:
     `__call__(loss, params)` is kept for autograd-built losses."""
 
     def __init__(self, name, parameters, lr, eps=1e-4, clip=None, wd=None, wd_pattern=r".*", opt="adam",
-                 use_amp=False):
+                 use_amp=False, extra=0):
         assert 0 <= (wd or 0) < 1
         assert not clip or 1 <= clip
         if opt != "adam":
@@ -429,7 +429,7 @@ class Optimizer:
         if wd_pattern != r".*":
             raise NotImplementedError
         self._name, self._clip = name, clip
-        self.bucket = ParamBucket(name, parameters)
+        self.bucket = ParamBucket(name, parameters, extra=extra)  # extra: see ParamBucket (floats riding the all-reduce)
         self._opt = _BucketAdam(self.bucket, float(lr), float(eps), wd or 0.0)  # hyper-parameters live in its group
 
     @property

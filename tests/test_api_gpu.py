@@ -118,6 +118,15 @@ def test_objective_and_policy_arguments():
     feats, states, actions = beh._imagine(post, lambda feat: beh.actor(feat), 3)
     N = s["B"] * s["T"]
     assert feats.shape[:2] == (3, N) and actions.shape == (3, N, s["A"]) and states["stoch"].shape[:2] == (3, N)
+    # as in the reference (models.py:513-517) the feats are detached; the states keep their graph
+    import tools
+
+    with tools.RequiresGrad(wm.dynamics):
+        feats, states, actions = beh._imagine(post, lambda feat: beh.actor(feat), 3)
+        assert not feats.requires_grad and states["deter"].requires_grad
+        w = wm.dynamics._cell.layers.GRU_linear.weight
+        (gw,) = torch.autograd.grad(states["deter"][-1].pow(2).sum(), [w])
+    assert float(gw.abs().max()) > 0.0
 
 
 

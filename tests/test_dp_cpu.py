@@ -97,3 +97,46 @@ def test_bucket_rebuilds_after_module_to():
     b.ensure()
     assert b.flat is not flat0
     assert params[1].data_ptr() >= b.flat.data_ptr()
+
+
+def _split_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = {}
+        for mode in ("single", "split"):
+            params = _make_params()
+            b = ParamBucket("model", params, allow_cpu=True, extra=2).ensure()
+            assert b.tail.shape == (2,) and b.tail.data_ptr() == b.grad.data_ptr() + 4 * b.grad.numel()
+            g = torch.Generator().manual_seed(500 + rank)
+            for p in params:
+                p.grad.copy_(torch.randn(p.shape, generator=g) * 1e3)
+            b.tail.copy_(torch.tensor([0.25 + rank, -3.0 * (rank + 1)]))  # (what ImagBehavior.ema_to_wire puts there)
+            if mode == "single":
+                assert b.allreduce() == 1.0 / world
+            else:
+                cut = b.offset_of(params[2])  # two collectives, the second half first (graph.UpdateRunner._wm_half)
+                assert 0 < cut < b.grad.numel()
+                w1 = b.allreduce_range(cut, None, async_op=True)
+                w0 = b.allreduce_range(0, cut, async_op=True)
+                w1.wait(), w0.wait()
+            res[mode] = (b.grad.clone(), b.tail.clone())
+        (g0, t0), (g1, t1) = res["single"], res["split"]
+        # a sum over ranks is elementwise: the two ranges reduce to exactly what the one call does, tail included
+        assert torch.equal(g0, g1) and torch.equal(t0, t1)
+        want = torch.tensor([sum(0.25 + r for r in range(world)), sum(-3.0 * (r + 1) for r in range(world))])
+        assert torch.equal(t0, want)
+        out[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_split_allreduce_equals_single_and_carries_the_tail():
+    """Data-parallel readiness (no hardware needed): the world-model bucket cut into two collectives reduces bit for bit
+    to what the single all-reduce gives, and the two EMA floats ride in the critic bucket's tail through the same
+    call (three collectives per update instead of four)."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_split_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert set(out.keys()) == {0, 1}

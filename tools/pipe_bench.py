@@ -67,7 +67,7 @@ def main():
         for nm, fn in (("serial", serial), ("pipelined", stream), ("pairs", pairs)):
             res.setdefault(nm, []).append(timed(fn, steps))
     print(f"{name}: ms per update  " + "  ".join(f"{k} {min(v):.3f} (median {np.median(v):.3f})" for k, v in res.items()),
-          f"| plan {r.pipe_plan} | model_loss {float(r.last_metrics['model_loss']):.4f}")
+          f"| plan {r.pipe_plan} | model_loss {float(r._m1['model_loss']):.4f}")
     if r._pipe is None:
         print("pipeline not taken")
         return
