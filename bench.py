@@ -145,6 +145,45 @@ def phase_timers(wm, beh, data, H, t_upd_ms, reps=10):
             "imagine_fwd_gflop": gflop, "imagine_fwd_gflop_mfma": gflop_mfma, "imagine_fwd_tflops": gflop / t_img}
 
 
+def launch_name(runner, mode):
+    if not runner.use_graph:
+        return "eager"
+    if mode == "serial" or runner._pipe is None:
+        return "hipGraph replay, one update after the other"
+    return ("hipGraph replay, two-update pipeline: behaviour phase of update k beside the world-model phase of update "
+            f"k+1 ({runner._pipe['mode']}), stream of back-to-back updates as in one agent call (dreamer.py:95-97)")
+
+
+def run_updates(runner, data, n, mode):
+    """n updates on `data`: "pipelined" = the stream of back-to-back updates of one agent call (dreamer.py:95-97), the
+    behaviour phase of each issued beside the next one's world-model phase and the last one by flush(); "pairs" = two
+    updates per call + flush (what the reference's train_ratio gives at the dmc configs); "serial" = one whole update
+    after the other."""
+    if mode == "serial":
+        for _ in range(n):
+            runner.step(data)
+    elif mode == "pairs":
+        for i in range(n):
+            runner.step_pipelined(data)
+            if i % 2 == 1 or i == n - 1:
+                runner.flush()
+    else:
+        for _ in range(n):
+            runner.step_pipelined(data)
+        runner.flush()
+
+
+def warm_up(runner, data, n, mode):
+    """n untimed updates; for the pipelined modes as many more (at most 4) as it takes until every hipGraph the timed
+    region replays has been captured (two eager calls, the serial halves, then the pipelined segments)."""
+    run_updates(runner, data, n, mode)
+    extra = 0
+    while (mode != "serial" and runner.use_graph and runner._pipe is None and runner.pipeline_wanted() and extra < 4):
+        run_updates(runner, data, 2, mode)
+        extra += 2
+    return extra
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N copies of this script, one per GPU, with the
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment torch.distributed.run would give them (the seam is the
@@ -153,10 +192,7 @@ def launch_ranks(n: int) -> int:
     import socket
     import subprocess
 
-    ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU
-    if n > ndev and os.environ.get("DV3_DIST_BACKEND", "nccl") != "gloo":
-        print(f"[bench] --gpus {n} but only {ndev} device(s) visible", file=sys.stderr)
-        return 2
+    # (the device count is checked by the ranks themselves, in main(): the parent touches no GPU API at all)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -176,9 +212,10 @@ def launch_ranks(n: int) -> int:
     return rc
 
 
-def secondary_config(name, device, steps, warmup):
-    """A second BASELINE config measured in the SAME run on rank 0 (cfg 3 = the largest `1xMI355X` config of
-    BASELINE.json): time per update over `steps` hipGraph replays, T_img, and the dominant MFMA kernel's fraction."""
+def secondary_config(name, device, steps, warmup, serial=False):
+    """Another BASELINE config measured in the SAME run on rank 0: time per update over `steps` hipGraph replays (the
+    same timed region as the headline: pipelined where UpdateRunner takes the pipeline at this shape), the serial time,
+    T_img, and the dominant MFMA kernel's fraction."""
     import models
     import tools
     from dv3hip import ops, shapes
@@ -193,15 +230,22 @@ def secondary_config(name, device, steps, warmup):
     wm.requires_grad_(False), beh.requires_grad_(False)
     data = synthetic_batch(name, seed=0, device=device)
     runner = UpdateRunner(wm, beh)
-    for _ in range(warmup):
-        runner.step(data)
+    mode = "serial" if serial else "pipelined"
+    warm_up(runner, data, warmup, mode)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        runner.step(data)
+    run_updates(runner, data, steps, mode)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    loss = float(runner.last_metrics["model_loss"])
+    loss = float(runner.wm_metrics["model_loss"])
+    ms_serial = ms
+    if runner._pipe is not None:
+        warm_up(runner, data, 2, "serial")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_updates(runner, data, steps, "serial")
+        torch.cuda.synchronize()
+        ms_serial = (time.perf_counter() - t0) / steps * 1e3
     ops.PROFILE.by_shape = False
     ops.PROFILE.start()
     runner.step(data, eager=True)
@@ -211,9 +255,12 @@ def secondary_config(name, device, steps, warmup):
     dom = max(eng, key=lambda k: eng[k]["ms"])
     ach = eng[dom]["flops"] / (eng[dom]["ms"] * 1e-3) / 1e12
     tm = phase_timers(wm, beh, data, H, ms, reps=5)
+    tot_fl = sum(v["flops"] for v in prof.values())
     return {"workload": f"{name}: {WORKLOADS.get(name, name)}, batch {B} x seq {T}, horizon {H}", "ms_per_step": ms,
             "value": B * T * H / (ms * 1e-3), "unit": "imagination-steps/s", "steps": steps, "warmup": warmup,
-            "model_loss": loss,
+            "launch": launch_name(runner, mode), "ms_per_step_serial": ms_serial,
+            "model_loss": loss, "update_gflop": tot_fl / 1e9,
+            "update_frac": tot_fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "roofline": {"kernel": dom, "kernel_symbol": ops.kernel_symbol(dom), "achieved": ach,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                          "avg_launch_us": eng[dom]["ms"] * 1e3 / eng[dom]["launches"]},
@@ -230,11 +277,14 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
+    ap.add_argument("--serial", action="store_true",
+                    help="time whole updates one after the other (no two-update pipeline): r01-r03's timed region")
     ap.add_argument("--by-shape", action="store_true", help="roofline leg: key GEMM launches by (M,N,K) too")
     ap.add_argument("--plain", action="store_true",
                     help="only the warm-up and timed updates (no roofline / phase-timer / staging / cpu legs): the "
                          "command tools/run_trace.sh puts under rocprofv3 so that every traced launch belongs to an update")
-    ap.add_argument("--also", default="cfg3", help="second config measured in the same run on one GPU ('none' = skip)")
+    ap.add_argument("--also", default="cfg1,cfg3,cfg4,cfg5",
+                    help="further BASELINE configs measured in the same run on one GPU, comma-separated ('none' = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -289,23 +339,22 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        runner.step(data)
+    mode = "serial" if (args.serial or args.no_graph) else "pipelined"
+    extra_warm = warm_up(runner, data, args.warmup, mode)
     sync()
     if os.environ.get("DV3_BENCH_LATE_STREAM"):  # rehearsal: the caller moves to a torch stream of its own (update in line)
         torch.cuda.set_stream(torch.cuda.Stream(device))
-        for _ in range(3):
-            runner.step(data)
+        run_updates(runner, data, 3, mode)
         sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.step(data)
+    run_updates(runner, data, args.steps, mode)
     sync()
     elapsed = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
-    loss = float(runner.last_metrics["model_loss"])
+    loss = float(runner.wm_metrics["model_loss"])
+    launch = launch_name(runner, mode)
     if not np.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
 
@@ -315,7 +364,7 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": world * B * T * H * args.steps / elapsed, "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                              "config": {"workload": name}, "plain": True}))
+                              "config": {"workload": name, "launch": launch}, "plain": True}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -375,6 +424,11 @@ def main():
                     "launches_per_update": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                     "flops_per_launch": d["flops"] / d["launches"],
                     "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                    "update": {"gflop": tot_fl / 1e9, "ms": elapsed / args.steps * 1e3,
+                               "achieved": tot_fl / (elapsed / args.steps) / 1e12, "unit": "TFLOP/s",
+                               "frac": tot_fl / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                               "note": "algorithmic FLOPs of every launch of one update (gather layers priced as the "
+                                       "Linear they replace) / the timed region's time per update / fp32 MFMA peak"},
                     "all_mfma_kernels": {"achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
                                          "gflop_per_update": tot_fl / 1e9, "ms_per_update": tot_ms},
                     "scan_gemm": {"bound": "hbm", "kernel": "gemm_skinny_kernel (M = batch rows of the observe scan)",
@@ -390,7 +444,21 @@ def main():
     # all-reduces, which stay outside capture)
     timers = None
     if world == 1:
-        timers = phase_timers(wm, beh, data, H, elapsed / args.steps * 1e3)
+        def timed(m, n):
+            warm_up(runner, data, 2, m)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_updates(runner, data, n, m)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+
+        # T_upd_ms: one whole update after the other (r01-r03's timed region); the pipelined figures: see run_updates
+        t_serial = elapsed / args.steps * 1e3 if mode == "serial" else timed("serial", args.steps)
+        t_pipe = elapsed / args.steps * 1e3 if mode == "pipelined" else None
+        t_pairs = timed("pairs", args.steps // 2 * 2) if (mode == "pipelined" and runner._pipe is not None) else None
+        timers = phase_timers(wm, beh, data, H, t_serial)
+        timers["T_upd_pipelined_ms"], timers["T_upd_pairs_ms"] = t_pipe, t_pairs
+        timers["value_uses"] = "T_upd_pipelined_ms" if (mode == "pipelined" and runner._pipe is not None) else "T_upd_ms"
         if roofline is not None:
             g_mfma = timers.pop("imagine_fwd_gflop_mfma")
             roofline["imagine_fwd"] = {
@@ -423,8 +491,22 @@ def main():
         timers["T_upd_host_staged_ms"] = (time.perf_counter() - t0) / args.steps * 1e3
 
     others = None
-    if rank == 0 and world == 1 and args.also not in ("", "none", name):
-        others = {args.also: secondary_config(args.also, device, steps=max(5, args.steps // 2), warmup=3)}
+    also = [c for c in args.also.split(",") if c and c not in ("none", name)]
+    if rank == 0 and world == 1 and also:
+        # free this config's graphs and workspaces first: cfg 4 / cfg 5 need tens of GB
+        del runner, wm, beh
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        others = {}
+        for c in also:
+            big = shapes.SHAPES[c]["deter"] >= 2048
+            print(f"[bench] {c} ...", file=sys.stderr, flush=True)
+            others[c] = secondary_config(c, device, steps=5 if big else max(6, args.steps // 2), warmup=3 if big else 5,
+                                         serial=args.serial)
+            gc.collect()
+            torch.cuda.empty_cache()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -445,8 +527,8 @@ def main():
                                    "one step = full Dreamer._train update (world model + actor + critic fwd/bwd, "
                                    "gradient all-reduce, 3x clip+Adam)",
                        "global_batch": B * world, "seq_len": T, "horizon": H, "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay" if (runner.use_graph and not args.no_graph) else "eager"},
-            "model_loss": loss, "timers": timers,
+                       "launch": launch},
+            "warmup_extra_for_capture": extra_warm, "model_loss": loss, "timers": timers,
             "roofline": roofline, "cpu_baseline": cpu, "configs": others,
         }
         print(json.dumps(out))

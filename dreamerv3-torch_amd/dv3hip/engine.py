@@ -245,7 +245,9 @@ class SideStream:
             if chain:
                 Cuts.mark("wm.defer")
                 self._cut = True
-            for f in fns:
+            for i, f in enumerate(fns):
+                if chain and i:
+                    Cuts.mark(f"wm.defer@{i}")  # (optional cut: the schedule may share the deferred launches between lanes)
                 f()
             return
         if self._mode == "off" or (self._mode == "lanes" and not chain):
@@ -750,6 +752,20 @@ class RSSMEngine:
         gru_weight_bytes = 4 * 3 * self.De * (self.Hd + self.De)
         return bool(heavy_side) and gru_weight_bytes <= (32 << 20) and self.B <= 64
 
+    def pipeline_mode(self, conv: bool):
+        """How graph.UpdateRunner.step_pipelined runs the behaviour phase of update k beside the world-model phase of
+        update k+1 at this shape -- "lanes": each phase on one half of the chip from end to end; "staged": only the two
+        scans beside the rollout / reverse rollout, everything else on the whole chip; None: one update after the other.
+        Measured on MI355X (tools/pipe_bench.py, ms per update serial / staged / lanes): cfg 2 16.2 / 15.3 / 13.75,
+        cfg 3 26.6 / 25.5 / 24.2 -- a segment of the update's chip-filling launches takes only 1.5-1.8x as long on 128
+        compute units as on 256, so two half-chip streams of independent work beat one whole-chip stream; cfg 1 (MLP
+        encoder / decoder: the world-model phase is 7 ms of the 12.8, the behaviour lane would be the long pole)
+        12.8 / 11.4 / 12.7.  conv: the world model has the convolutional encoder / decoder."""
+        gru_weight_bytes = 4 * 3 * self.De * (self.Hd + self.De)
+        if gru_weight_bytes > (32 << 20) or getattr(self, "B", 0) > 64:
+            return None  # (wide cells: the scans are bandwidth-bound and want every compute unit, see lanes_pay)
+        return "lanes" if conv else "staged"
+
     def observe_bwd(self, dpost_logit, dprior_logit, gs, gd, dembed, extra_side=None, lanes_pay=False):
         """Backward of observe_fwd.
 
@@ -789,7 +805,10 @@ class RSSMEngine:
             ops.colsum(dpl2, _g(P.ims.b), accumulate=True)
             lin_wgrad(P.img_out.W, dx2pre, v2(deter, De))
 
-        side.run((extra_side or []) + [_prior_wgrads])  # beside the reverse scan below
+        # (pipelined capture: the prior head's weight gradients stay in line -- the deferred launches may then run beside
+        # the segment behind the join, where the init-state backward adds into the same gradients)
+        prior_inline = side._mode == "cuts"
+        side.run((extra_side or []) + ([] if prior_inline else [_prior_wgrads]))  # beside the reverse scan below
         with side.chain():  # (lanes: on the scan lane, beside the deferred launches on the side lane)
             # ---- reverse scan
             # Every GEMM of the reverse scan ACCUMULATES into buffers zeroed here in bulk: a few-row GEMM with
@@ -872,6 +891,8 @@ class RSSMEngine:
                                       gd[t - 1] if t > 0 else None, dstoch0, ddeter0)
             # ---- the encoder-output gradient (critical path) and, beside it, the batched weight gradients
         side.join()  # the init-state backward below adds into the same prior-head gradients
+        if prior_inline:
+            _prior_wgrads()
         ops.gemm(v2(dx3pre, Hd), P.obs_out.W[:, De:], v2(dembed, E), transB=False)
         dpl = v2(dpl_out, SD)
 

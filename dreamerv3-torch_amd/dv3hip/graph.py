@@ -217,8 +217,9 @@ class SegmentRecorder:
 # deferred weight gradients run ("side": behind the reverse rollout on the side lane; "post" / "mid": in line on the
 # whole chip).  Development switches DV3_PIPE_* (build.py --dev) override for A/B runs.
 _PIPE_PLAN = dict(on=_dev.flag("DV3_PIPE", True), a_split=_dev.value("DV3_PIPE_A_SPLIT", 0) or None,
-                  c_split=_dev.value("DV3_PIPE_C_SPLIT", 0) or None, defer=_dev.value("DV3_PIPE_DEFER", "side", str),
-                  late=_dev.flag("DV3_PIPE_LATE", True))
+                  c_split=_dev.value("DV3_PIPE_C_SPLIT", 0) or None, defer=_dev.value("DV3_PIPE_DEFER", "auto", str),
+                  late=_dev.flag("DV3_PIPE_LATE", True), mode=_dev.value("DV3_PIPE_MODE", "auto", str),
+                  defer_split=_dev.value("DV3_PIPE_DEFER_SPLIT", 0) or None)
 
 
 class PhaseRecorder:
@@ -496,6 +497,27 @@ class UpdateRunner:
             return False
         return engine.Lanes._by_dev.get(str(torch.device("cuda", self._home[1].device.index))) is not None
 
+    @property
+    def wm_metrics(self):
+        """Metrics of the last world-model phase issued (a pipelined call's last_metrics pairs them with the behaviour
+        metrics of the update before)."""
+        return self._m1
+
+    @property
+    def beh_metrics(self):
+        return self._m2
+
+    def pipeline_wanted(self) -> bool:
+        """Plan switch on and a schedule exists for this shape (engine.RSSMEngine.pipeline_mode)."""
+        return bool(self.pipe_plan.get("on", True)) and self._pipe_mode() is not None
+
+    def _pipe_mode(self):
+        mode = self.pipe_plan.get("mode", "auto")
+        if mode == "auto":
+            wm = self.wm
+            mode = wm.dynamics.engine.pipeline_mode(bool(wm.encoder.cnn_shapes) and bool(wm.heads["decoder"].cnn_shapes))
+        return mode
+
     def step_pipelined(self, data):
         """Like step(), but the behaviour phase of this update is issued only with the NEXT call (beside that update's
         world-model phase) or by flush().  Falls back to step() where the pipeline is not available (eager warm-up
@@ -504,7 +526,7 @@ class UpdateRunner:
             if not self._pipe_pending:
                 # prologue: nothing to run beside -- the serial world-model half (its own per-lane graphs)
                 self._wm_half(data)
-                if self._replaying(False) and self.pipeline_available() and self.pipe_plan.get("on", True):
+                if self._replaying(False) and self.pipeline_available() and self.pipeline_wanted():
                     self._pipe_pending = True
                     self.last_metrics = dict(self._m1)
                 else:
@@ -522,9 +544,12 @@ class UpdateRunner:
                     return self.step(data)
             if not self._pipe["entered"]:
                 self._pipe_enter()
-            self._load(data)
             self._calls += 1
-            self._pipe_iteration()
+            if self._pipe["mode"] == "lanes":
+                self._pipe_iteration_lanes(data)
+            else:
+                self._load(data)
+                self._pipe_iteration()
             cap = self._pipe["cap"]
             self._m1, self._m2 = cap["m1"], cap["beh_out"][-1]
             self._beh_out = cap["beh_out"]
@@ -562,13 +587,19 @@ class UpdateRunner:
         lane_wm = lambda lb: {"wm.fscan": "scan", "wm.fscan2": "scan", "wm.rscan": "scan", "wm.rscan2": "scan",
                               "wm.defer": "side"}.get(lb, "main")
         lane_beh = lambda lb: "side" if lb.startswith(("bh.A", "bh.C")) else "main"
+        mode = self._pipe_mode()
+        if mode == "lanes":
+            # each phase on a lane of its own from end to end: its segments are captured on that lane's stream
+            lane_wm = lambda lb: "side" if lb == "wm.defer" else "scan"  # ("wm.defer@i", the rest of them: on the scan lane)
+            lane_beh = lambda lb: "side"
         opt_cuts = [f"bh.A@{plan['a_split']}"] if plan.get("a_split") else []
         opt_cuts += [f"bh.C@{plan['c_split']}"] if plan.get("c_split") else []
         cap = {}
         # separate graph pools: the two phases replay in an order other than the capture order
         pool_w, pool_b = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        w_cuts = [f"wm.defer@{plan['defer_split']}"] if (plan.get("defer_split") and mode == "lanes") else []
         with tools.rng_override(key_dev, rng_wm):
-            W = PhaseRecorder(pool_w, dev, lanes, lane_wm, "wm.pre").record(
+            W = PhaseRecorder(pool_w, dev, lanes, lane_wm, "wm.pre", optional=w_cuts).record(
                 lambda: wm.train_fwd_bwd(self._static), at_end=rng_wm.finish_phase)
             gw = torch.cuda.CUDAGraph()
 
@@ -581,12 +612,19 @@ class UpdateRunner:
                 lambda: beh.train_fwd_bwd(cap["post"]), at_end=rng_beh.finish_phase)
             gb = torch.cuda.CUDAGraph()
             _capture(gb, lambda: cap.update(beh_out=beh.train_opt(allreduce=False)), pool=pool_b)
+        if plan.get("defer", "auto") == "auto":
+            # staged: the side lane beside the reverse scan takes the reverse rollout where there is one (imag_gradient
+            # dynamics / both) and the deferred weight gradients run in line on the whole chip (cfg 2: 15.3 against
+            # 16.1 ms with them behind the reverse rollout on the lane); else the lane is theirs (reinforce)
+            plan["defer"] = "post" if any(lb == "bh.C" for lb, _ in B.segments) else "side"
         stride = rng_wm.taken + rng_beh.taken
         rng_wm.stride.fill_(stride), rng_beh.stride.fill_(stride)
         mk = lambda: torch.cuda.Event(blocking=True)
         self._pipe = dict(W=W.segments, B=B.segments, wopt=gw, bopt=gb, cap=cap, rng_wm=rng_wm, rng_beh=rng_beh,
-                          lanes=lanes, entered=False, shared=tools.default_rng(key_dev),
-                          ev={k: mk() for k in ("tail", "fork1", "q1", "mid", "fork2", "q2")})
+                          lanes=lanes, entered=False, shared=tools.default_rng(key_dev), mode=mode,
+                          ev={k: mk() for k in ("tail", "fork1", "q1", "mid", "fork2", "q2")},
+                          ev2={k: torch.cuda.Event() for k in ("load", "start", "mid", "defer", "wopt")},
+                          ring=[mk(), mk()])
 
     def _pipe_enter(self):
         """The serial world-model half of update k has run (shared Philox offset S + w): behaviour k draws from there,
@@ -602,8 +640,86 @@ class UpdateRunner:
     def _pipe_leave(self):
         """Back to the shared stream in front of the serial behaviour half: it continues where the pending phase draws."""
         P = self._pipe
+        if P.get("lanes_running"):
+            cur = torch.cuda.current_stream()
+            for s in (P["lanes"].streams["scan"], P["lanes"].streams["side"]):
+                cur.wait_stream(s)
+            P["lanes_running"] = False
         P["shared"].state.copy_(P["rng_beh"].state)
         P["entered"] = False
+
+    def _pipe_iteration_lanes(self, data):
+        """World-model phase of update k+1 on one half of the chip, behaviour phase of update k on the other, each from
+        end to end -- no stage joins.  Measured on MI355X (tools/pipe_bench.py --segments): a segment of chip-filling
+        launches takes only 1.5-1.8x as long on 128 compute units as on 256 (every launch pays ~4-5 us that do not scale
+        with its work), so two half-chip streams of independent work deliver ~1.25x the whole chip's serial rate.
+
+          X (scan lane)  [load . wm.pre] -e_start-> [fwd scan . wm.mid] [rev scan . wm.post] -e_defer-> [all-reduce . Adam] -e_wopt->
+          Y (side lane)  -e_wopt(k)-> [bh.start] [rollout . heads . reverse rollout . actor] [all-reduce x2 . Adam x2] -e_mid-> [wm.defer]
+
+        Cross-lane events: the posterior of update k is copied out (bh.start) before scan k+1 overwrites it; the
+        deferred weight gradients of update k+1 follow its decoder / heads (e_mid); world-model Adam k+1 follows the last
+        read of the weights by behaviour k and the deferred gradients (e_defer); behaviour k+1 follows Adam k+1 (e_wopt)."""
+        P = self._pipe
+        W, B, ev = dict(P["W"]), dict(P["B"]), P["ev2"]
+        L = P["lanes"].streams
+        X, Y = L["scan"], L["side"]
+        cur = torch.cuda.current_stream()
+        first = not P.get("lanes_running")
+        it = P["iter"] = P.get("iter", 0) + 1
+        ring = P["ring"]
+        ring[it % 2].synchronize()  # (the host stays at most two iterations ahead of the GPU)
+
+        def run(segs, labels, stream):
+            with torch.cuda.stream(stream):
+                for lb in labels:
+                    g = segs.get(lb)
+                    if g is not None:
+                        self._traced(lb, g)
+
+        # the batch: its last reader in update k was the decoder loss (wm.mid)
+        if not first:
+            cur.wait_event(ev["mid"])
+        self._load(data)
+        ev["load"].record(cur)
+        X.wait_event(ev["load"])
+        if first:
+            Y.wait_event(ev["load"])  # (behind the serial world-model half the prologue has queued on this stream)
+        else:
+            Y.wait_event(ev["wopt"])
+        run(B, ["bh.start"], Y)
+        ev["start"].record(Y)
+        run(W, ["wm.pre"], X)
+        X.wait_event(ev["start"])
+        run(W, ["wm.fscan", "wm.fscan2", "wm.mid"], X)
+        ev["mid"].record(X)
+        run(W, ["wm.rscan", "wm.rscan2", "wm.post"] + [lb for lb in W if lb.startswith("wm.defer@")], X)
+        run(B, [lb for lb in B if lb != "bh.start"], Y)  # (capture order: rollout, heads, reverse rollout, actor)
+        with torch.cuda.stream(Y):
+            self.beh._actor_opt.bucket.allreduce()
+            self.beh._value_opt.bucket.allreduce()
+            self._traced("bh.opt", P["bopt"])
+        Y.wait_event(ev["mid"])
+        run(W, ["wm.defer"], Y)
+        ev["defer"].record(Y)
+        X.wait_event(ev["defer"])
+        with torch.cuda.stream(X):
+            self.wm._model_opt.bucket.allreduce()
+            self._traced("wm.opt", P["wopt"])
+        ev["wopt"].record(X)
+        ring[it % 2].record(X)
+        P["lanes_running"] = True
+
+    def _traced(self, label, g):
+        trace = self._pipe_trace
+        if trace is None:
+            g.replay()
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        g.replay()
+        b.record()
+        trace.append((label, a, b))
 
     def _pipe_iteration(self):
         """World-model phase of update k+1 beside the behaviour phase of update k.

@@ -22,6 +22,11 @@ SHAPES = {
     "tiny_proprio": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
                          actor_dist="normal", imag_gradient="dynamics", encoder="mlp",
                          enc_mlp_units=32, enc_mlp_layers=2),
+    # image AND vector observations together (networks.MultiEncoder / MultiDecoder, networks.py:293-445; the shipped
+    # `minecraft` block, configs.yaml:206-207): embed = [cnn | mlp], the decoder predicts the image and every vector key
+    "tiny_mixed": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
+                       actor_dist="normal", imag_gradient="dynamics", encoder="both",
+                       enc_mlp_units=24, enc_mlp_layers=2),
     # Plan2Explore (exploration.py:40-135) on the tiny model: defaults (stoch target, log disagreement, no action
     # conditioning, no extrinsic term) and the action-conditioned variant with an extrinsic term
     "tiny_p2e": dict(stoch=4, discrete=4, deter=16, hidden=16, units=16, A=3, cnn_depth=2, B=3, T=6, H=4,
@@ -83,6 +88,10 @@ def make_config(name, device="cuda:0"):
     s = SHAPES[name]
     blocks = ["dmc_proprio"] if s["encoder"] == "mlp" else ["dmc_vision"]
     cfg = tools.load_config(os.path.join(PKG, "configs.yaml"), blocks)
+    if s["encoder"] == "both":  # the vision block with the vector keys routed to the MLP as well (as `minecraft` does)
+        keys = "|".join(k for k, _ in PROPRIO_KEYS)
+        cfg["encoder"].update(mlp_keys=keys, cnn_keys="image")
+        cfg["decoder"].update(mlp_keys=keys, cnn_keys="image")
     cfg.update(device=device, num_actions=s["A"], dyn_stoch=s["stoch"], dyn_discrete=s["discrete"],
                dyn_deter=s["deter"], dyn_hidden=s["hidden"], units=s["units"], batch_size=s["B"],
                batch_length=s["T"], imag_horizon=s["H"], imag_gradient=s["imag_gradient"],
@@ -95,7 +104,7 @@ def make_config(name, device="cuda:0"):
     cfg["critic"]["layers"] = s.get("critic_layers", 2)
     cfg["reward_head"]["layers"] = s.get("reward_layers", 2)
     cfg["cont_head"]["layers"] = s.get("cont_layers", 2)
-    if s["encoder"] == "mlp":
+    if s["encoder"] in ("mlp", "both"):
         for d in (cfg["encoder"], cfg["decoder"]):
             d.update(mlp_units=s["enc_mlp_units"], mlp_layers=s["enc_mlp_layers"])
     if "p2e" in s:
@@ -106,7 +115,7 @@ def make_config(name, device="cuda:0"):
 def obs_space(name):
     s = SHAPES[name]
     spaces = {}
-    if s["encoder"] == "mlp":
+    if s["encoder"] in ("mlp", "both"):
         for k, w in PROPRIO_KEYS:
             spaces[k] = _Space((w,))
     spaces["image"] = _Space((64, 64, 3))
@@ -136,7 +145,7 @@ def synthetic_batch(name, seed=0):
         first[b, rs.randint(1, T)] = 1.0
     data["is_first"] = first
     data["is_terminal"] = np.zeros((B, T), np.float32)
-    if s["encoder"] == "mlp":
+    if s["encoder"] in ("mlp", "both"):
         for k, w in PROPRIO_KEYS:
             data[k] = rs.randn(B, T, w).astype(np.float32)
     return data

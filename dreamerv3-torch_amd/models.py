@@ -222,14 +222,15 @@ class WorldModel(nn.Module):
         ops.transpose01(st["is_terminal"], cont_tm)
         ops.axpby(ws.get("wm.ones", (T, B)).fill_(1.0), cont_tm, 1.0, -1.0)  # cont = 1 - is_terminal
 
-        # ---- encoder
+        # ---- encoder (networks.MultiEncoder.forward, networks.py:348-356: the CNN on the image, the MLP on the symlog of
+        # the vector keys, their outputs side by side)
         enc = self.encoder
-        if enc.cnn_shapes and enc.mlp_shapes:
-            raise NotImplementedError("mixed image + vector encoders")
+        cnn_eng = mlp_eng = None
+        parts = []
         if enc.cnn_shapes:
-            enc_eng = enc._cnn.engine
-            embed = enc_eng.forward(st["image"], (B, T))
-        else:
+            cnn_eng = enc._cnn.engine
+            parts.append(cnn_eng.forward(st["image"], (B, T)))
+        if enc.mlp_shapes:
             keys = list(enc.mlp_shapes)
             widths = [int(np.prod(enc.mlp_shapes[k])) for k in keys]
             xin = ws.get("wm.mlp_in", (TB, sum(widths)))
@@ -240,9 +241,17 @@ class WorldModel(nn.Module):
                 raw[:, off:off + w] = tmp.view(TB, w)
                 off += w
             ops.symlog(raw, xin)
-            enc_eng = enc._mlp.engine_for(".wm")
-            embed, _, _ = enc_eng.forward(xin)
+            mlp_eng = enc._mlp.engine_for(".wm")
+            parts.append(mlp_eng.forward(xin)[0])
             self._enc_in = xin
+        if len(parts) == 2:
+            # image + vector keys together (the `minecraft` block, configs.yaml:206-207): embed = [cnn | mlp]
+            Ec, Em = parts[0].shape[1], parts[1].shape[1]
+            embed = ws.get("wm.embed", (TB, Ec + Em))
+            embed[:, :Ec].copy_(parts[0])
+            embed[:, Ec:].copy_(parts[1])
+        else:
+            embed = parts[0]
         E_ = embed.shape[1]
 
         # ---- RSSM scan
@@ -340,10 +349,18 @@ class WorldModel(nn.Module):
         # ---- backward through the scan and the encoder
         dembed = ws.get("wm.dembed", (T, B, E_))
         side = rssm.observe_bwd(dpl, dql, gs, gd, dembed, extra_side=deferred, lanes_pay=lanes_pay)
-        if enc.cnn_shapes:
-            enc_eng.backward(dembed.view(TB, E_))
+        de = dembed.view(TB, E_)
+        if cnn_eng is not None and mlp_eng is not None:
+            Ec = parts[0].shape[1]
+            d_cnn, d_mlp = ws.get("wm.dembed_cnn", (TB, Ec)), ws.get("wm.dembed_mlp", (TB, E_ - Ec))
+            d_cnn.copy_(de[:, :Ec])
+            d_mlp.copy_(de[:, Ec:])
         else:
-            enc_eng.backward(self._enc_in, None, slice(0, TB), wgrad=True, dh=dembed.view(TB, E_))
+            d_cnn = d_mlp = de
+        if cnn_eng is not None:
+            cnn_eng.backward(d_cnn)
+        if mlp_eng is not None:
+            mlp_eng.backward(self._enc_in, None, slice(0, TB), wgrad=True, dh=d_mlp)
         side.join()
 
         # ---- scalar loss + optimizer

@@ -47,7 +47,7 @@ class PathConfig:
     num_actions: int = 6
     unimix: float = 0.01  # configs.yaml:92
     cnn_depth: int = 32  # encoder/decoder cnn_depth
-    encoder: str = "cnn"  # "cnn" (dmc_vision) or "mlp" (dmc_proprio)
+    encoder: str = "cnn"  # "cnn" (dmc_vision), "mlp" (dmc_proprio) or "both" (image + vector keys: minecraft)
     mlp_keys: Tuple[Tuple[str, int], ...] = ()  # proprio keys and their widths, in obs_space order
     enc_mlp_layers: int = 5
     enc_mlp_units: int = 1024
@@ -80,9 +80,8 @@ class PathConfig:
 
     @property
     def embed(self) -> int:
-        if self.encoder == "cnn":
-            return self.cnn_depth * 8 * 16
-        return self.enc_mlp_units
+        e = self.cnn_depth * 8 * 16 if self.encoder in ("cnn", "both") else 0
+        return e + (self.enc_mlp_units if self.encoder in ("mlp", "both") else 0)
 
 
 # --------------------------------------------------------------------------------------
@@ -499,22 +498,27 @@ def wm_forward(cfg: PathConfig, p, data: Dict, q_prior: Tensor, q_post: Tensor) 
     """WorldModel._train up to the scalar loss (models.py:113-147).  Returns every tensor
     the parity tests look at."""
     obs = preprocess(cfg, data)
-    if cfg.encoder == "cnn":
-        embed = conv_encoder(cfg, p, obs["image"])
-    else:
-        embed = mlp_encoder(cfg, p, obs)
+    # MultiEncoder.forward (networks.py:348-356): the CNN's and the MLP's outputs side by side
+    parts = []
+    if cfg.encoder in ("cnn", "both"):
+        parts.append(conv_encoder(cfg, p, obs["image"]))
+    if cfg.encoder in ("mlp", "both"):
+        parts.append(mlp_encoder(cfg, p, obs))
+    embed = parts[0] if len(parts) == 1 else torch.cat(parts, -1)
     action = obs["action"].clone()  # obs_step zeroes prev_action at is_first rows in place
     post, prior = observe(cfg, p, embed, action, obs["is_first"], q_prior, q_post)
     kl, kl_value, dyn, rep = kl_loss(cfg, post["logit"], prior["logit"])
     feat = get_feat(cfg, post)
     losses = {}
     out = {}
-    if cfg.encoder == "cnn":
+    # MultiDecoder.forward (networks.py:424-438): image head and every vector key on the same feat
+    if cfg.encoder in ("cnn", "both"):
         recon = conv_decoder(cfg, p, feat)
         out["recon"] = recon
         losses["image"] = ((recon - obs["image"]) ** 2).sum([2, 3, 4])  # -MSEDist.log_prob, tools.py:531-540
-    else:
+    if cfg.encoder in ("mlp", "both"):
         modes = mlp_decoder_modes(cfg, p, feat)
+        out["recon_modes"] = modes
         for k, _ in cfg.mlp_keys:
             losses[k] = -symlog_mse_logprob(modes[k], obs[k])
     r_logits = head_logits(p, "heads.reward.", "Reward", cfg.reward_layers, feat)

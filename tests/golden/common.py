@@ -36,7 +36,7 @@ def path_config(name: str):
         cont_layers=s.get("cont_layers", 2), critic_layers=s.get("critic_layers", 2),
         imag_gradient_mix=s.get("imag_gradient_mix", 0.0),
     )
-    if s["encoder"] == "mlp":
+    if s["encoder"] in ("mlp", "both"):
         kw.update(mlp_keys=PROPRIO_KEYS, enc_mlp_units=s["enc_mlp_units"], enc_mlp_layers=s["enc_mlp_layers"])
     return PathConfig(**kw)
 
@@ -59,17 +59,19 @@ def param_shapes(name: str) -> Dict[str, Tuple[int, ...]]:
             sh[f"{prefix}layers.{nm}_linear{i}.weight"] = (units, inp if i == 0 else units)
             ln(f"{prefix}layers.{nm}_norm{i}", units)
 
-    if s["encoder"] == "cnn":
-        E = d * 8 * 16
+    E = 0
+    if s["encoder"] in ("cnn", "both"):
+        E += d * 8 * 16
         cin = 3
         for i in range(4):
             cout = d * 2**i
             sh[f"encoder._cnn.layers.{3 * i}.weight"] = (cout, cin, 4, 4)
             ln(f"encoder._cnn.layers.{3 * i + 1}.norm", cout)
             cin = cout
-    else:
-        E = s["enc_mlp_units"]
-        mlp("encoder._mlp.", "Encoder", s["enc_mlp_layers"], sum(w for _, w in PROPRIO_KEYS), E)
+    if s["encoder"] in ("mlp", "both"):
+        Em = s["enc_mlp_units"]
+        E += Em
+        mlp("encoder._mlp.", "Encoder", s["enc_mlp_layers"], sum(w for _, w in PROPRIO_KEYS), Em)
     sh["dynamics.W"] = (1, De)
     sh["dynamics._img_in_layers.0.weight"] = (Hd, SD + A)
     ln("dynamics._img_in_layers.1", Hd)
@@ -83,9 +85,10 @@ def param_shapes(name: str) -> Dict[str, Tuple[int, ...]]:
     sh["dynamics._imgs_stat_layer.bias"] = (SD,)
     sh["dynamics._obs_stat_layer.weight"] = (SD, Hd)
     sh["dynamics._obs_stat_layer.bias"] = (SD,)
-    if s["encoder"] == "cnn":
-        sh["heads.decoder._cnn._linear_layer.weight"] = (E, F)
-        sh["heads.decoder._cnn._linear_layer.bias"] = (E,)
+    if s["encoder"] in ("cnn", "both"):
+        Ec = d * 8 * 16
+        sh["heads.decoder._cnn._linear_layer.weight"] = (Ec, F)
+        sh["heads.decoder._cnn._linear_layer.bias"] = (Ec,)
         cin = d * 8
         for i in range(3):
             sh[f"heads.decoder._cnn.layers.{3 * i}.weight"] = (cin, cin // 2, 4, 4)
@@ -93,10 +96,11 @@ def param_shapes(name: str) -> Dict[str, Tuple[int, ...]]:
             cin //= 2
         sh["heads.decoder._cnn.layers.9.weight"] = (cin, 3, 4, 4)
         sh["heads.decoder._cnn.layers.9.bias"] = (3,)
-    else:
-        mlp("heads.decoder._mlp.", "Decoder", s["enc_mlp_layers"], F, E)
+    if s["encoder"] in ("mlp", "both"):
+        Em = s["enc_mlp_units"]
+        mlp("heads.decoder._mlp.", "Decoder", s["enc_mlp_layers"], F, Em)
         for k, w in PROPRIO_KEYS:
-            sh[f"heads.decoder._mlp.mean_layer.{k}.weight"] = (w, E)
+            sh[f"heads.decoder._mlp.mean_layer.{k}.weight"] = (w, Em)
             sh[f"heads.decoder._mlp.mean_layer.{k}.bias"] = (w,)
     for pre, nm, out in (("heads.reward.", "Reward", 255), ("heads.cont.", "Cont", 1)):
         mlp(pre, nm, s.get(nm.lower() + "_layers", 2), F, U)
@@ -209,7 +213,7 @@ def make_batch(name: str, seed: int = 0, extra_first: bool = True) -> Dict[str, 
     term = np.zeros((B, T), bool)
     term[B // 2, T - 1] = True  # one terminal so the cont head sees both classes
     data["is_terminal"] = term
-    if s["encoder"] == "mlp":
+    if s["encoder"] in ("mlp", "both"):
         for k, w in PROPRIO_KEYS:
             data[k] = rs.randn(B, T, w).astype(np.float32)
     return data

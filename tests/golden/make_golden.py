@@ -169,12 +169,16 @@ def build_reference(name, tools, networks, models):
         ov.update(expl_behavior="plan2explore", **s["p2e"])
     if s["actor_dist"] == "onehot":
         ov["actor"].update(dist="onehot", std="none")
-    if s["encoder"] == "mlp":
+    if s["encoder"] in ("mlp", "both"):
         ov["encoder"].update(mlp_units=s["enc_mlp_units"], mlp_layers=s["enc_mlp_layers"])
         ov["decoder"].update(mlp_units=s["enc_mlp_units"], mlp_layers=s["enc_mlp_layers"])
+    if s["encoder"] == "both":  # vision block + the vector keys routed to the MLPs too (as the `minecraft` block does)
+        keys = "|".join(k for k, _ in common.PROPRIO_KEYS)
+        ov["encoder"].update(mlp_keys=keys, cnn_keys="image")
+        ov["decoder"].update(mlp_keys=keys, cnn_keys="image")
     cfg = load_config(blocks, ov)
     spaces = {}
-    if s["encoder"] == "mlp":
+    if s["encoder"] in ("mlp", "both"):
         for k, w in common.PROPRIO_KEYS:
             spaces[k] = Space((w,))
     spaces["image"] = Space((64, 64, 3))
@@ -265,7 +269,7 @@ def run_config(name, tools, networks, models, full: bool):
     if "image" in preds:
         recon = to_np(preds["image"].mode())
         keep("recon", recon, (slice(0, 1), slice(0, 2)))
-    else:
+    if s["encoder"] in ("mlp", "both"):
         for k, _ in common.PROPRIO_KEYS:
             keep("recon/" + k, to_np(preds[k]._mode))
     keep("reward_logits", to_np(preds["reward"].logits), sel)
@@ -489,7 +493,8 @@ def main():
     torch.set_num_threads(8)
     tools, networks, models = import_reference()
     install_noise_hooks(tools)
-    plan = [("tiny", True), ("tiny_onehot", True), ("tiny_proprio", True), ("tiny_both", True), ("cfg2", False),
+    plan = [("tiny", True), ("tiny_onehot", True), ("tiny_proprio", True), ("tiny_both", True), ("tiny_mixed", True),
+            ("cfg2", False),
             ("cfg1", False), ("cfg3", False), ("cfg4_b4", False), ("cfg5_b4", False)]
     for name, full in plan:
         if args.only and name != args.only:

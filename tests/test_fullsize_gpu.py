@@ -434,6 +434,7 @@ def test_graph_replay_matches_eager_and_trains(name):
             r.step(data)
             losses.append(float(r.last_metrics["model_loss"]))
         torch.cuda.synchronize()
+        assert r.use_graph == use_graph, "hipGraph capture was refused: the runner fell back to eager launches"
         assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
         for k in ("actor_loss", "value_loss", "actor_grad_norm", "value_grad_norm", "model_grad_norm"):
             assert np.isfinite(float(r.last_metrics[k])), k
@@ -655,15 +656,38 @@ def test_large_configs_train_and_rows_are_independent(name):
     assert torch.equal(post["stoch"], ref["stoch"][perm]), "permuted rows sampled differently"
     close(post["deter"], ref["deter"][perm], 1e-5, "permuted deter")
     close(post["logit"], ref["logit"][perm], 1e-5, "permuted logit")
-    # (2) a few full updates on one minibatch: finite everywhere, model loss decreasing
-    r = UpdateRunner(wm, beh, use_graph=False)
-    losses = []
-    for _ in range(4):
-        r.step(data)
-        losses.append(float(r.last_metrics["model_loss"]))
-    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
-    for k in ("actor_loss", "value_loss", "actor_grad_norm", "value_grad_norm", "model_grad_norm", "kl", "actor_entropy"):
-        assert np.isfinite(float(r.last_metrics[k])), k
-    ws_bytes = wm.dynamics.engine.ws.nbytes()
-    print(f"\n[{name}] losses {['%.2f' % x for x in losses]}; RSSM workspace {ws_bytes / 2**30:.1f} GiB; "
-          f"peak allocated {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    # (2) a few full updates on one minibatch, launched eagerly AND replayed from hipGraphs (the path the 384 / 256 ms
+    # figures of DESIGN.md section 5 come from): finite everywhere, model loss decreasing, and the replayed sequence
+    # computes what the eager one does (same Philox stream; as test_graph_replay_matches_eager_and_trains for cfg 1-3)
+    del ref, post
+    outs = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        wm = models.WorldModel(shapes.obs_space(name), None, 0, cfg).to(dev)
+        beh = models.ImagBehavior(cfg, wm).to(dev)
+        wm.requires_grad_(False), beh.requires_grad_(False)
+        tools.default_rng(dev, seed=5)
+        r = UpdateRunner(wm, beh, use_graph=use_graph, warm=1)
+        losses = []
+        for _ in range(4):
+            r.step(data)
+            losses.append(float(r.last_metrics["model_loss"]))
+        assert r.use_graph == use_graph, "hipGraph capture was refused"
+        assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+        for k in ("actor_loss", "value_loss", "actor_grad_norm", "value_grad_norm", "model_grad_norm", "kl", "actor_entropy"):
+            assert np.isfinite(float(r.last_metrics[k])), k
+        outs.append((losses, float(r.last_metrics["actor_loss"]), float(r.last_metrics["value_loss"]),
+                     wm.dynamics.W.detach().clone()))
+        ws_bytes = wm.dynamics.engine.ws.nbytes()
+        print(f"\n[{name}] {'replayed' if use_graph else 'eager'}: losses {['%.2f' % x for x in losses]}; RSSM workspace "
+              f"{ws_bytes / 2**30:.1f} GiB; peak allocated {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+        del r, wm, beh
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+    (l0, al0, vl0, w0), (l1, al1, vl1, w1) = outs
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 2e-3 * abs(a), (l0, l1)
+    assert abs(vl0 - vl1) <= 2e-2 * max(1.0, abs(vl0)), (vl0, vl1)
+    close(w1, w0, 1e-4, "learned initial state after 4 updates, replayed vs eager")

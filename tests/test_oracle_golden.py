@@ -65,7 +65,7 @@ def wm_out(name, grad=False):
     return cfg, p, n, data, O.wm_forward(cfg, p, data, n["q_prior"], n["q_post"])
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both", "tiny_mixed"])
 def test_fixture_inputs_regenerate(name):
     """The generator's stored inputs are exactly what common.py regenerates from the seed."""
     g = load(name)
@@ -77,7 +77,7 @@ def test_fixture_inputs_regenerate(name):
         assert np.array_equal(g["noise/" + k], v), k
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both", "tiny_mixed"])
 def test_world_model_forward_full(name):
     g = load(name)
     cfg, p, n, data, out = wm_out(name)
@@ -87,8 +87,11 @@ def test_world_model_forward_full(name):
         close(out["prior"][k], g["prior/" + k], what="prior/" + k)
     # sampled one-hots must agree exactly (no flips at this size on the same host)
     assert np.array_equal(out["post"]["stoch"].detach().numpy(), g["post/stoch"])
-    if cfg.encoder == "cnn":
+    if cfg.encoder in ("cnn", "both"):
         close(out["recon"], g["recon"], what="recon")
+    if cfg.encoder in ("mlp", "both"):
+        for k, _ in cfg.mlp_keys:  # (the vector decoder's per-key modes, in symlog space)
+            close(out["recon_modes"][k], g["recon/" + k], what="recon/" + k)
     close(out["reward_logits"], g["reward_logits"], what="reward_logits")
     close(out["cont_logit"], g["cont_logit"], what="cont_logit")
     for k, v in out["losses"].items():
@@ -101,7 +104,7 @@ def test_world_model_forward_full(name):
     close(out["model_loss"], g["model_loss"], tol=1e-6, what="model_loss")
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both", "tiny_mixed"])
 def test_world_model_gradients(name):
     g = load(name)
     cfg, p, n, data, out = wm_out(name, grad=True)
@@ -125,7 +128,7 @@ def behaviour(name, grad=False):
     return g, cfg, p, out, ema
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both", "tiny_mixed"])
 def test_imagination_and_behaviour_forward(name):
     g, cfg, p, out, ema = behaviour(name)
     close(out["feats"], g["imag/feat"], what="feat")
@@ -142,7 +145,7 @@ def test_imagination_and_behaviour_forward(name):
     close(out["value_loss"], g["value_loss"], tol=1e-5, what="value_loss")
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both", "tiny_mixed"])
 def test_behaviour_gradients(name):
     g, cfg, p, out, ema = behaviour(name, grad=True)
     akeys = [k for k in p if k.startswith("actor.")]
@@ -155,7 +158,7 @@ def test_behaviour_gradients(name):
         close(gr, g["grad/" + k], tol=2e-4, what="grad/" + k)
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_onehot", "tiny_proprio", "tiny_both", "tiny_mixed"])
 def test_full_update_matches_reference_train(name):
     """One oracle update (WM step, then behaviour on the UPDATED world model, as dreamer.py:194-200)
     reproduces the reference's own `_train` metrics and post-update parameters."""

@@ -39,7 +39,7 @@ def gpu_noise(name, seed=0):
     return wm_noise, im_noise
 
 
-@pytest.fixture(scope="module", params=["tiny", "tiny_onehot", "tiny_proprio", "tiny_both", "cfg4_b4", "cfg5_b4"])
+@pytest.fixture(scope="module", params=["tiny", "tiny_onehot", "tiny_proprio", "tiny_both", "tiny_mixed", "cfg4_b4", "cfg5_b4"])
 def tiny_run(request):
     name = request.param
     exp = Hh.oracle_update(name, piecewise=True)
@@ -69,6 +69,33 @@ def test_world_model_forward(tiny_run):
     close(torch.tensor(float(m["cont_loss"])), exp["losses"]["cont"].mean(), what="cont_loss")
     for k in exp["losses"]:  # every decoder key logs its OWN -log_prob mean (models.py:150)
         close(torch.tensor(float(m[k + "_loss"])), exp["losses"][k].mean(), what=k + "_loss")
+
+
+def test_world_model_update_against_the_reference_fixture(tiny_run):
+    """The GPU update against the REFERENCE's own numbers (tests/golden/<name>.npz, written by make_golden.py from
+    /root/reference): posterior, every world-model gradient, the reference `_train`'s loss and post-Adam parameters --
+    in particular for `tiny_mixed`, image + vector observations together (networks.MultiEncoder / MultiDecoder,
+    networks.py:293-445; the `minecraft` block)."""
+    import os
+
+    name = tiny_run["name"]
+    path = os.path.join(os.path.dirname(__file__), "golden", name + ".npz")
+    g = np.load(path, allow_pickle=False)
+    if not bool(g["meta/full"]):
+        pytest.skip("slices + checksums only: compared in tests/test_fullsize_gpu.py")
+    post = tiny_run["post"]
+    assert np.array_equal(post["stoch"].cpu().numpy(), g["post/stoch"]), "sampled posterior differs from the reference"
+    close(post["logit"], torch.from_numpy(g["post/logit"]), what="post logit vs reference")
+    close(post["deter"], torch.from_numpy(g["post/deter"]), what="deter vs reference")
+    close(torch.tensor(float(tiny_run["mets"]["model_loss"])), torch.from_numpy(g["train/model_loss"]), tol=1e-5,
+          what="model_loss vs the reference's _train")
+    n = 0
+    for k, gr in tiny_run["wm_grads"].items():
+        close(gr, torch.from_numpy(g["grad/" + k]), tol=3e-4, what="grad vs reference " + k)
+        n += 1
+    assert n == sum(1 for k in g.files if k.startswith("grad/") and k.split("/")[1].split(".")[0] in Hh.WM_PREFIXES)
+    for k, v in tiny_run["wm_after"].items():
+        adam_close(v, torch.from_numpy(g["after/" + k]), 1e-4, "after vs reference " + k)
 
 
 def test_world_model_gradients_and_adam_step(tiny_run):

@@ -22,7 +22,7 @@ def _batches(name, n):
     return [{k: torch.from_numpy(v).cuda() for k, v in shapes.synthetic_batch(name, seed).items()} for seed in range(n)]
 
 
-def _run(name, n_calls, pipelined, lr_zero, pairs=False):
+def _run(name, n_calls, pipelined, lr_zero, pairs=False, plan=None):
     """n_calls updates on distinct batches -> per-update records.  warm=1: call 0 eager, from call 1 on hipGraph replay."""
     import tools
     from dv3hip.graph import UpdateRunner
@@ -33,6 +33,7 @@ def _run(name, n_calls, pipelined, lr_zero, pairs=False):
             opt._opt.param_groups[0]["lr"] = 0.0
     tools.default_rng("cuda:0", seed=7)
     r = UpdateRunner(wm, beh, warm=1)
+    r.pipe_plan.update(plan or {})
     data = _batches(name, n_calls)
     rec = dict(post=[], im_stoch=[], im_action=[], g_model=[], g_actor=[], g_value=[], model_loss=[], actor_loss=[],
                value_loss=[])
@@ -82,12 +83,20 @@ def _run(name, n_calls, pipelined, lr_zero, pairs=False):
     return rec
 
 
-@pytest.mark.parametrize("name,pairs", [("cfg2", False), ("cfg2", True), ("cfg3", False), ("cfg1", False), ("tiny", False)])
-def test_pipelined_updates_draw_and_compute_what_the_serial_updates_do(name, pairs):
-    """Learning rates 0: every update's sampled states and actions bit-equal, gradients equal up to atomic order."""
+PLANS = {"staged": dict(mode="staged", defer="post"), "staged_split": dict(mode="staged", defer="side", a_split=6, c_split=5),
+         "lanes": dict(mode="lanes")}
+
+
+@pytest.mark.parametrize("name,pairs,plan", [
+    ("cfg2", False, "staged"), ("cfg2", True, "staged"), ("cfg2", False, "staged_split"), ("cfg2", False, "lanes"),
+    ("cfg2", True, "lanes"), ("cfg3", False, "staged_split"), ("cfg3", False, "lanes"), ("cfg1", False, "lanes"),
+    ("tiny", False, "staged"), ("tiny", True, "lanes")])
+def test_pipelined_updates_draw_and_compute_what_the_serial_updates_do(name, pairs, plan):
+    """Learning rates 0: every update's sampled states and actions bit-equal, gradients equal up to atomic order --
+    for every schedule of the pipeline (graph._PIPE_PLAN)."""
     n = 6
     a = _run(name, n, pipelined=False, lr_zero=True)
-    b = _run(name, n, pipelined=True, lr_zero=True, pairs=pairs)
+    b = _run(name, n, pipelined=True, lr_zero=True, pairs=pairs, plan=PLANS[plan])
     assert torch.equal(a["rng"], b["rng"]), "the Philox stream ends elsewhere"
     for key in ("post", "im_stoch", "im_action"):
         assert len(a[key]) == len(b[key]) == n, (key, len(a[key]), len(b[key]))
@@ -114,7 +123,7 @@ def test_pipelined_updates_train_like_serial_updates(name):
     summation order moves Adam's early, sign-like steps), and the model loss falls."""
     n = 6
     a = _run(name, n, pipelined=False, lr_zero=False)
-    b = _run(name, n, pipelined=True, lr_zero=False)
+    b = _run(name, n, pipelined=True, lr_zero=False, plan=PLANS["lanes"])
     assert torch.equal(a["rng"], b["rng"])
     for key, tol in (("model_loss", 2e-3), ("value_loss", 2e-2), ("actor_loss", 5e-2)):
         for x, y in zip(a[key], b[key]):

@@ -67,7 +67,7 @@ def main():
         for nm, fn in (("serial", serial), ("pipelined", stream), ("pairs", pairs)):
             res.setdefault(nm, []).append(timed(fn, steps))
     print(f"{name}: ms per update  " + "  ".join(f"{k} {min(v):.3f} (median {np.median(v):.3f})" for k, v in res.items()),
-          f"| plan {r.pipe_plan} | model_loss {float(r._m1['model_loss']):.4f}")
+          f"| plan {r.pipe_plan} | model_loss {float(r.wm_metrics['model_loss']):.4f}")
     if r._pipe is None:
         print("pipeline not taken")
         return
@@ -88,6 +88,26 @@ def main():
         tls.append((e0.elapsed_time(e1), [(lb, e0.elapsed_time(a), e0.elapsed_time(b)) for lb, a, b in r._pipe_trace]))
         r._pipe_trace = None
     r.flush()
+    if "--segments" in sys.argv:
+        # every segment alone: on the whole chip and on the 128-CU side lane (values are garbage afterwards)
+        P = r._pipe
+        whole, side = r._home[1], P["lanes"].streams["side"]
+        print("segments alone, ms (whole chip / side lane):")
+        for lb, g in list(P["W"]) + list(P["B"]) + [("wm.opt", P["wopt"]), ("bh.opt", P["bopt"])]:
+            res = []
+            for st in (whole, side):
+                tt = []
+                for _ in range(5):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    with torch.cuda.stream(st):
+                        a.record()
+                        g.replay()
+                        b.record()
+                    torch.cuda.synchronize()
+                    tt.append(a.elapsed_time(b))
+                res.append(sorted(tt)[2])
+            print(f"  {lb:12s} {res[0]:7.3f} / {res[1]:7.3f}   x{res[1] / max(res[0], 1e-6):.2f}")
     tls.sort(key=lambda x: x[0])
     tot, tl = tls[len(tls) // 2]
     print(f"timeline of one pipelined iteration ({tot:.3f} ms, event-timed: each segment's events add a few us):")
