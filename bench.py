@@ -479,14 +479,17 @@ def main():
 
         host = {k: v.cpu().numpy() for k, v in data.items()}
         stager = BatchStager(device, overlap=os.environ.get("DV3_STAGE_OVERLAP", "1") != "0")  # ("0": upload in front)
+        step_fn = runner.step if mode == "serial" else runner.step_pipelined
         # (uploads on the stream the update is issued on: no second queue beside its dependent launches)
         with torch.cuda.stream(runner.launch_stream() or torch.cuda.current_stream()):
             for _ in range(3):
-                runner.step(stager.stage(host))
+                step_fn(stager.stage(host))
+            runner.flush()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                runner.step(stager.stage(host))
+                step_fn(stager.stage(host))
+            runner.flush()
             torch.cuda.synchronize()
         timers["T_upd_host_staged_ms"] = (time.perf_counter() - t0) / args.steps * 1e3
 

@@ -131,3 +131,63 @@ def test_pipelined_updates_train_like_serial_updates(name):
     w0, w1 = a["params"]["dynamics.W"], b["params"]["dynamics.W"]
     assert float((w0 - w1).abs().max()) <= 1e-4 + 1e-4 * float(w0.abs().max())
     assert np.isfinite(b["model_loss"]).all() and np.isfinite(b["actor_loss"]).all()
+
+
+class _Logger:
+    def __init__(self):
+        self.step, self.scalars = 0, {}
+
+    def scalar(self, k, v):
+        self.scalars[k] = v
+
+    def video(self, *a, **k):
+        pass
+
+    def write(self, fps=False):
+        pass
+
+
+def test_dreamer_update_loop_pipelines_and_logs_like_the_serial_loop():
+    """dreamer.Dreamer.__call__ (dreamer.py:87-106): the `pretrain` updates of one call go through step_pipelined, the
+    last behaviour phase is flushed before the policy acts and before the logger reads, every metric key is the mean
+    over exactly the updates of the interval, and the agent ends where the serial loop (`pipeline_updates: False`)
+    ends up to the atomic summation order of the reverse scan."""
+    import dreamer
+    import tools
+
+    name, n_upd = "tiny", 8
+    res = []
+    for pipelined in (False, True):
+        cfg = Hh.make_config(name)
+        cfg.pretrain, cfg.log_every, cfg.video_pred_log, cfg.train_ratio = n_upd, 1, False, 512
+        cfg.pipeline_updates = pipelined
+        logger = _Logger()
+
+        def dataset():
+            i = 0
+            while True:
+                yield common.make_batch(name, seed=i)
+                i += 1
+
+        torch.manual_seed(0)
+        agent = dreamer.Dreamer(Hh.obs_space(name), None, cfg, logger, dataset()).to(cfg.device)
+        agent.requires_grad_(False)
+        tools.default_rng(cfg.device, seed=11)
+        obs = {"image": np.zeros((2, 64, 64, 3), np.uint8), "is_first": np.ones(2, bool), "is_terminal": np.zeros(2, bool)}
+        out, state = agent(obs, np.ones(2, bool), None, training=True)
+        torch.cuda.synchronize()
+        r = agent._runner
+        assert agent._update_count == n_upd and not r._pipe_pending
+        assert (r._pipe is not None) == pipelined, "the update loop did not take the pipeline"
+        assert r.use_graph
+        assert torch.isfinite(out["action"]).all()
+        res.append((dict(logger.scalars), {k: v.detach().clone() for k, v in agent.state_dict().items()},
+                    tools.default_rng(cfg.device).state.clone()))
+    (m0, p0, g0), (m1, p1, g1) = res
+    assert set(m0) == set(m1), set(m0) ^ set(m1)
+    assert torch.equal(g0, g1), "the pipelined loop leaves the Philox stream elsewhere"
+    for k in m0:
+        assert abs(m0[k] - m1[k]) <= 2e-3 * max(1.0, abs(m0[k])), (k, m0[k], m1[k])
+    for k in p0:
+        d = (p0[k].double() - p1[k].double()).abs().max().item() if p0[k].numel() else 0.0
+        assert d <= 3e-4 + 1e-3 * p0[k].double().abs().max().item(), (k, d)
