@@ -285,6 +285,9 @@ class WorldModel(nn.Module):
             ops.mse_image(recon, st["image"], limg, drecon, upstream=up, perm=(B, T))
             ops.dot_accumulate(limg, acc[1:2], scale=up)
             dec_eng.backward(drecon, gs.view(TB, SD), gd.view(TB, De), acc_dx=False, defer=deferred)
+            # (pipelined update, lanes mode: the deferred launches behind this index -- the heads' weight gradients -- may
+            # run on the world model's own lane, graph.UpdateRunner._capture_pipe)
+            self._defer_heads_from = len(deferred)
             wrote = True
             if "decoder" not in grad_heads:
                 gs.zero_(), gd.zero_()

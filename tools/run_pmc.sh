@@ -1,10 +1,14 @@
 # rocprofv3 evidence for profiles/: kernel-trace stats, SQ (MFMA busy) counters, FETCH_SIZE and WRITE_SIZE passes
 # (separate passes; counters only with --kernel-trace, never with sys/runtime traces)
-TAG=${1:-r03}
-OUT=gpurun_out/$TAG
+# usage: tools/run_pmc.sh TAG [--serial]   default: the pipelined timed region of bench.py (every kernel on a 128-CU lane);
+# --serial: one update after the other (kernels on the whole chip, except the reverse scan and the deferred weight gradients)
+TAG=${1:-r04}
+MODE=${2:-}
+OUT=gpurun_out/$TAG${MODE:+_serial}
+SIMDS=$([ -n "$MODE" ] && echo 1024 || echo 512)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python3 bench.py --plain --steps 6 --warmup 2"  # update replays only: every traced launch belongs to an update
+CMD="python3 bench.py --plain --steps 6 --warmup 6 $MODE"  # update replays only: every traced launch belongs to an update
 # counter passes run for minutes without output: keep gpurun's silence watchdog fed
 ( while true; do date >> $OUT/heartbeat.log; sleep 45; done ) &
 HB=$!
@@ -21,7 +25,7 @@ SQ=$(find $OUT/pmc_sq -name "*counter_collection.csv" | head -1)
 FE=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1)
 WR=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
 ST=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
-python tools/pmc_mfma.py $SQ $OUT/pmc_mfma.json | head -16
+python tools/pmc_mfma.py $SQ $OUT/pmc_mfma.json --simds $SIMDS | head -16
 python tools/pmc_traffic.py $FE $WR $OUT/pmc_traffic.json | head -14
 cp $ST $OUT/kernel_stats.csv
 # the raw counter CSVs are large: keep only the summaries
