@@ -692,14 +692,16 @@ class UpdateRunner:
             Y.wait_event(ev["load"])  # (behind the serial world-model half the prologue has queued on this stream)
         else:
             Y.wait_event(ev["wopt"])
+        # (host order: both lanes get their first segment at once, then the behaviour lane its whole phase -- its rollout
+        # must not wait for the host to have queued the world model's eight graphs: 0.4 ms of idle lane otherwise)
         run(B, ["bh.start"], Y)
         ev["start"].record(Y)
         run(W, ["wm.pre"], X)
+        run(B, [lb for lb in B if lb != "bh.start"], Y)  # (capture order: rollout, heads, reverse rollout, actor)
         X.wait_event(ev["start"])
         run(W, ["wm.fscan", "wm.fscan2", "wm.mid"], X)
         ev["mid"].record(X)
         run(W, ["wm.rscan", "wm.rscan2", "wm.post"] + [lb for lb in W if lb.startswith("wm.defer@")], X)
-        run(B, [lb for lb in B if lb != "bh.start"], Y)  # (capture order: rollout, heads, reverse rollout, actor)
         with torch.cuda.stream(Y):
             self.beh._actor_opt.bucket.allreduce()
             self.beh._value_opt.bucket.allreduce()

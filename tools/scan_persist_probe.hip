@@ -20,6 +20,9 @@ struct ProbeParams {
   float* act[2];        // ping-pong activation vectors [16][KMAX]
   unsigned* counters;   // [0] flat barrier counter, [1] error flag, [2] stale-read count, [8..15] per-XCD, [16] top, [24] generation
   int steps, phases, G, K, cols, mode, verify;
+  int variant;          // hand-off form: 0 sc1 loads; 1 sc0 sc1 loads; 2 acquire fence + plain loads; 3 release + acquire fences, plain stores / loads
+  int nbuf;             // activation buffers in rotation (2: ping-pong; phases * steps + 1: every phase reads fresh addresses)
+  float* ring;          // [nbuf][16][K] when nbuf > 2
   const float* wsrc;    // [16][K] weights every workgroup copies into LDS (values irrelevant)
   long spin_limit;
 };
@@ -30,10 +33,14 @@ __device__ __forceinline__ unsigned ld_sc1(const unsigned* p) {
 
 // device-wide barrier on a monotonic counter: every workgroup adds 1 after its stores have drained; everybody polls.
 // Bounded: a poll loop that runs out sets the error flag, and every later barrier returns at once.
-__device__ __forceinline__ bool barrier_flat(unsigned* counters, unsigned target, long limit) {
+__device__ __forceinline__ bool barrier_flat(unsigned* counters, unsigned target, long limit, int variant) {
   __syncthreads();
   bool ok = true;
   if (threadIdx.x == 0) {
+    if (variant == 3) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // (every byte handed off was stored sc1 and has drained -- vmcnt(0) in front of the barrier -- so the arrival itself
     // needs no release fence: MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire)
     __hip_atomic_fetch_add(&counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -46,6 +53,10 @@ __device__ __forceinline__ bool barrier_flat(unsigned* counters, unsigned target
       }
       __builtin_amdgcn_s_sleep(1);
     }
+    if (variant >= 2) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __syncthreads();
   return ok;
@@ -53,10 +64,15 @@ __device__ __forceinline__ bool barrier_flat(unsigned* counters, unsigned target
 
 // XCD-hierarchical: arrivals go to the counter of the workgroup's XCD; the last arriver of an XCD adds to the top
 // counter; the last XCD publishes the generation; everybody polls the generation word.
-__device__ __forceinline__ bool barrier_xcd(unsigned* counters, unsigned gen, int G, int xcd, int per_xcd, long limit) {
+__device__ __forceinline__ bool barrier_xcd(unsigned* counters, unsigned gen, int G, int xcd, int per_xcd, long limit,
+                                            int variant) {
   __syncthreads();
   bool ok = true;
   if (threadIdx.x == 0) {
+    if (variant == 3) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const unsigned a = __hip_atomic_fetch_add(&counters[8 + xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a + 1 == (unsigned)per_xcd * gen) {
       const unsigned t = __hip_atomic_fetch_add(&counters[16], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -71,6 +87,10 @@ __device__ __forceinline__ bool barrier_xcd(unsigned* counters, unsigned gen, in
         break;
       }
       __builtin_amdgcn_s_sleep(1);
+    }
+    if (variant >= 2) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
   __syncthreads();
@@ -97,8 +117,9 @@ extern "C" __global__ __launch_bounds__(256) void persist_scan_probe(ProbeParams
   bool alive = true;
   for (int s = 0; s < p.steps && alive; ++s) {
     for (int ph = 0; ph < p.phases && alive; ++ph) {
-      const float* in = p.act[(s * p.phases + ph) & 1];
-      float* out = p.act[(s * p.phases + ph + 1) & 1];
+      const int n = s * p.phases + ph;
+      const float* in = p.nbuf > 2 ? p.ring + (long)(n % p.nbuf) * 16 * p.K : p.act[n & 1];
+      float* out = p.nbuf > 2 ? p.ring + (long)((n + 1) % p.nbuf) * 16 * p.K : p.act[(n + 1) & 1];
       // (1) the wave's K share of the 16 input rows: row i, k = wave*kq + 16c + 4q .. +3  (sc1: never from this CU's L1)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const float* arow = in + (long)i * p.K + wave * kq + 4 * q;
@@ -109,7 +130,9 @@ extern "C" __global__ __launch_bounds__(256) void persist_scan_probe(ProbeParams
         for (int c = 0; c < 8; ++c)
           if (c0 + c < chunks) {
             const float* src = arow + 16 * (c0 + c);
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(a[c]) : "v"(src) : "memory");
+            if (p.variant == 0) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(a[c]) : "v"(src) : "memory");
+            else if (p.variant == 1) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(a[c]) : "v"(src) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[c]) : "v"(src) : "memory");
           }
         // (the loads above are invisible to the compiler's wait-count pass: wait for all of them, and tie the wait to
         // the registers so that no use is scheduled in front of it)
@@ -142,13 +165,16 @@ extern "C" __global__ __launch_bounds__(256) void persist_scan_probe(ProbeParams
         float v = red[r * 16 + c] + red[256 + r * 16 + c] + red[512 + r * 16 + c] + red[768 + r * 16 + c];
         if (p.verify) v = (float)((s * p.phases + ph + 1) & 1023);
         const long col = (long)blockIdx.x * p.cols + c;
-        if (col < p.K) __hip_atomic_store(out + (long)r * p.K + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (col < p.K) {
+          if (p.variant == 3) out[(long)r * p.K + col] = v;
+          else __hip_atomic_store(out + (long)r * p.K + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // (4) the seam
       ++gen;
-      alive = p.mode == 1 ? barrier_xcd(p.counters, gen, p.G, xcd, per_xcd, p.spin_limit)
-                          : barrier_flat(p.counters, gen * (unsigned)p.G, p.spin_limit);
+      alive = p.mode == 1 ? barrier_xcd(p.counters, gen, p.G, xcd, per_xcd, p.spin_limit, p.variant)
+                          : barrier_flat(p.counters, gen * (unsigned)p.G, p.spin_limit, p.variant);
     }
   }
 }

@@ -23,8 +23,8 @@ LIB = os.path.join(REPO, "tools", "_probe", "libscanprobe.so")
 class Params(ctypes.Structure):
     _fields_ = [("act0", ctypes.c_void_p), ("act1", ctypes.c_void_p), ("counters", ctypes.c_void_p),
                 ("steps", ctypes.c_int), ("phases", ctypes.c_int), ("G", ctypes.c_int), ("K", ctypes.c_int),
-                ("cols", ctypes.c_int), ("mode", ctypes.c_int), ("verify", ctypes.c_int), ("wsrc", ctypes.c_void_p),
-                ("spin_limit", ctypes.c_long)]
+                ("cols", ctypes.c_int), ("mode", ctypes.c_int), ("verify", ctypes.c_int), ("variant", ctypes.c_int),
+                ("nbuf", ctypes.c_int), ("ring", ctypes.c_void_p), ("wsrc", ctypes.c_void_p), ("spin_limit", ctypes.c_long)]
 
 
 def build():
@@ -55,11 +55,13 @@ def main():
     except Exception as e:  # the probe is meaningful without the lanes
         print("no CU-masked lane:", e)
 
-    def run(G, mode, verify, stream):
+    ring = torch.zeros(steps * phases + 1, 16, K, device=dev)
+
+    def run(G, mode, verify, stream, variant=0, fresh=False):
         counters.zero_()
         act[0].zero_(), act[1].zero_()
         p = Params(act[0].data_ptr(), act[1].data_ptr(), counters.data_ptr(), steps, phases, G, K, K // G, mode, verify,
-                   w.data_ptr(), 400000)
+                   variant, steps * phases + 1 if fresh else 2, ring.data_ptr(), w.data_ptr(), 400000)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(stream):
@@ -72,14 +74,26 @@ def main():
         return a.elapsed_time(b) * 1e3 / steps, int(c[1]), int(c[2])
 
     print(f"persistent forward-scan skeleton: {steps} steps x {phases} dependent layers, 16 rows x K = {K}, weights in LDS")
+    names = {0: "sc1 stores + sc1 loads", 1: "sc1 stores + sc0 sc1 loads", 2: "sc1 stores, acquire fence + plain loads",
+             3: "plain stores + release fence, acquire fence + plain loads"}
+    print("hand-off forms (128 workgroups, one counter; stale = values a verify run read that the previous layer had not written):")
+    for variant in (0, 1, 2, 3):
+        for fresh in (False, True):
+            us, err, stale = run(128, 0, 1, streams["whole chip"], variant, fresh)
+            ts = sorted(run(128, 0, 0, streams["whole chip"], variant, fresh)[0] for _ in range(5))
+            print(f"  {names[variant]:58s} {'fresh addresses every layer' if fresh else 'two buffers in rotation  '} "
+                  f"{ts[2]:6.2f} us per step   stale {stale}  error flag {err}")
+    if "--forms" in sys.argv:
+        return
+    VAR = int(sys.argv[sys.argv.index("--variant") + 1]) if "--variant" in sys.argv else 3
     for sname, st in streams.items():
         for G in (64, 128, 256):
             if sname != "whole chip" and G > 128:
                 continue  # (a lane holds 128 workgroups at one per CU: more would wait for a CU and the barrier never completes)
             for mode, mname in ((0, "one counter"), (1, "per-XCD counters")):
-                us, err, stale = run(G, mode, 1, st)
+                us, err, stale = run(G, mode, 1, st, VAR)
                 ok = "protocol ok" if (err == 0 and stale == 0) else f"ERROR flag {err}, {stale} stale reads"
-                ts = sorted(run(G, mode, 0, st)[0] for _ in range(7))
+                ts = sorted(run(G, mode, 0, st, VAR)[0] for _ in range(7))
                 print(f"  {sname:12s} G = {G:3d} workgroups, barrier: {mname:17s} {ts[3]:6.2f} us per step "
                       f"({ts[3] / phases:5.2f} us per layer; min {ts[0]:.2f})   [{ok}; verify run {us:.2f}]")
                 if err:
