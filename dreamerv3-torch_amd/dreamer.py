@@ -42,7 +42,7 @@ class Dreamer(nn.Module):
             plan2explore=lambda: expl.Plan2Explore(config, self._wm, reward),
         )[config.expl_behavior]().to(self._config.device)
         self._runner, self._stager, self._policy_runner = None, None, None
-        self._metric_keys, self._metric_sum, self._metric_cnt, self._metric_idx = [], None, None, {}
+        self._macc = {}  # metric group ("wm" / "beh" / "expl") -> device-resident running sums (see _accumulate)
 
     def __call__(self, obs, reset, state=None, training=True):
         step = self._step
@@ -137,6 +137,8 @@ class Dreamer(nn.Module):
                                         use_graph=bool(getattr(self._config, "hip_graph", True)))
             self._stager = BatchStager(self._config.device)
             models.share_runner(self._wm, self._runner)  # (WorldModel._train / ImagBehavior._train share it)
+            # the metrics of a phase are added up right behind its optimizer graph, on the stream that graph ran on
+            self._runner.metric_sinks = (lambda m: self._accumulate(m, "wm"), lambda m: self._accumulate(m, "beh"))
         host = all(not isinstance(v, torch.Tensor) for v in data.values())
         explorer = self._expl_behavior is not self._task_behavior
         pipelined = pipelined and not explorer and bool(getattr(self._config, "pipeline_updates", True))
@@ -145,14 +147,12 @@ class Dreamer(nn.Module):
             staged = (self._stager.stage(data) if host else
                       {k: (v if k == "image" else v.to(torch.float32)) for k, v in data.items()})
             (self._runner.step_pipelined if pipelined else self._runner.step)(staged)
-        mets = dict(self._runner.last_metrics)
-        if explorer:
-            # dreamer.py:201-203: the explorer trains on the same posterior states (eagerly: its objective runs torch
-            # autograd, which a hipGraph segment cannot hold)
-            staged = self._runner.last_data
-            xm = self._expl_behavior.train(self._runner.last_post, self._runner.last_context, staged)[-1]
-            mets.update({"expl_" + k: v for k, v in xm.items()})
-        self._accumulate(mets)
+            if explorer:
+                # dreamer.py:201-203: the explorer trains on the same posterior states (eagerly: its objective runs torch
+                # autograd, which a hipGraph segment cannot hold)
+                xm = self._expl_behavior.train(self._runner.last_post, self._runner.last_context,
+                                               self._runner.last_data)[-1]
+                self._accumulate({"expl_" + k: v for k, v in xm.items()}, "expl")
 
     def _finish_updates(self):
         """End of a run of pipelined updates: issue the behaviour phase that is still pending."""
@@ -160,12 +160,12 @@ class Dreamer(nn.Module):
         if r is not None and r._pipe_pending:
             with torch.cuda.stream(r.launch_stream() or torch.cuda.current_stream()):
                 r.flush()
-            self._accumulate(dict(r.last_metrics))
 
-    def _accumulate(self, mets):
+    def _accumulate(self, mets, group):
         """Device-resident metrics -- the snapshots of the fused path (DeviceScalar) and the 0-d tensors an autograd-style
-        caller's Optimizer.__call__ returns (the explorer) -- go into one running sum and one count per key (a pipelined
-        call reports the world-model keys of one update and the behaviour keys of the previous one)."""
+        caller's Optimizer.__call__ returns (the explorer) -- go into one running sum and one count per key, on the
+        CURRENT stream: UpdateRunner calls this right behind the optimizer graph that wrote them (metric_sinks), so the
+        two phases of the pipelined update add up their own keys on their own lanes and no queue waits for another."""
         dev = [(k, v._t if isinstance(v, models.DeviceScalar) else v.detach()) for k, v in mets.items()
                if isinstance(v, (models.DeviceScalar, torch.Tensor))]
         for k, v in mets.items():
@@ -174,28 +174,26 @@ class Dreamer(nn.Module):
         if not dev:
             return
         keys = tuple(k for k, _ in dev)
-        idx = self._metric_idx.get(keys)
-        if idx is None:
-            new = [k for k in keys if k not in self._metric_keys]
-            if new:
-                self._metric_keys += new
-                d = dev[0][1].device
-                grow = torch.zeros(len(new), device=d, dtype=torch.float32)
-                self._metric_sum = grow if self._metric_sum is None else torch.cat([self._metric_sum, grow])
-                self._metric_cnt = grow.clone() if self._metric_cnt is None else torch.cat([self._metric_cnt, grow])
-            idx = torch.tensor([self._metric_keys.index(k) for k in keys], device=dev[0][1].device)
-            self._metric_idx[keys] = idx
-        vals = torch.stack([t.reshape(()).to(torch.float32) for _, t in dev])
-        self._metric_sum.index_add_(0, idx, vals)
-        self._metric_cnt.index_add_(0, idx, torch.ones_like(vals))
+        acc = self._macc.get(group)
+        if acc is None or acc["keys"] != keys:
+            if acc is not None:
+                self._flush_group(acc)  # (the key set of a group changed: rare -- settle what has been added up)
+            d = dev[0][1].device
+            acc = dict(keys=keys, sum=torch.zeros(len(keys), device=d, dtype=torch.float32), n=0)
+            self._macc[group] = acc
+        acc["sum"].add_(torch.stack([t.reshape(()).to(torch.float32) for _, t in dev]))
+        acc["n"] += 1
+
+    def _flush_group(self, acc):
+        if acc["n"]:
+            mean = (acc["sum"] / acc["n"]).cpu().numpy()
+            for k, v in zip(acc["keys"], mean):
+                self._metrics.setdefault(k, []).append(float(v))
+            acc["sum"].zero_()
+            acc["n"] = 0
 
     def _flush_metrics(self):
         """Device-side running sums -> self._metrics[name] = [mean] (what the reference's logging loop, which takes
-        np.mean of each list, then reports): a single device-to-host copy per log interval."""
-        if self._metric_sum is not None:
-            both = torch.stack([self._metric_sum, self._metric_cnt]).cpu().numpy()
-            for k, sm, n in zip(self._metric_keys, both[0], both[1]):
-                if n > 0:
-                    self._metrics.setdefault(k, []).append(float(sm / n))
-            self._metric_sum.zero_()
-            self._metric_cnt.zero_()
+        np.mean of each list, then reports): one device-to-host copy per metric group and log interval."""
+        for acc in self._macc.values():
+            self._flush_group(acc)

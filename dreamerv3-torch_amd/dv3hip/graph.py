@@ -314,6 +314,10 @@ class UpdateRunner:
         self.last_metrics = {}
         self.last_post = self.last_context = self.last_data = None  # what a further behaviour (Plan2Explore) trains on
         # two-update software pipeline (step_pipelined / flush): labelled segments of both phases + their schedule
+        # (on_wm(metrics), on_beh(metrics)): called right behind the optimizer graph of a phase, on the stream that graph
+        # was launched on -- the caller's accumulation of the device-resident metrics is then stream-ordered with their
+        # producer and needs no other queue to wait (a blocked queue costs every launch of the others ~1.3 us)
+        self.metric_sinks = None
         self._pipe = None
         self._pipe_trace = None
         self._pipe_pending = False  # a world-model phase has been issued whose behaviour phase has not
@@ -347,6 +351,7 @@ class UpdateRunner:
         if not self._replaying(eager):
             post, ctx, m1 = self.wm._train_eager(data)
             self._m1, self.last_post, self.last_context, self.last_data = m1, post, ctx, data
+            self._sink(0, m1)
             return
         g1, ga = self._g_wm
         # (queueing the collectives only once the segment in front is over -- so that RCCL's stream does not sit blocked
@@ -367,6 +372,7 @@ class UpdateRunner:
                     w.wait()
         ga.replay()
         self._m1, self.last_post, self.last_context, self.last_data = self._cap["m1"], self._cap["post"], self._cap["ctx"], self._static
+        self._sink(0, self._m1)
 
     def _beh_half(self, eager=False):
         if self._replaying(eager) and self._g_beh is None:
@@ -378,6 +384,7 @@ class UpdateRunner:
         if not self._replaying(eager):
             self._beh_out = self.beh._train_eager(self.last_post, None)
             self._m2 = self._beh_out[-1]
+            self._sink(1, self._m2)
             return
         gb, g3 = self._g_beh
         gb.replay()
@@ -385,6 +392,11 @@ class UpdateRunner:
         self.beh._value_opt.bucket.allreduce()  # (the return-normalisation EMA values ride in its tail)
         g3.replay()
         self._beh_out, self._m2 = self._cap["beh_out"], self._cap["beh_out"][-1]
+        self._sink(1, self._m2)
+
+    def _sink(self, which, metrics):
+        if self.metric_sinks is not None and self.metric_sinks[which] is not None:
+            self.metric_sinks[which](metrics)
 
     def _model_cut(self):
         """Where the world-model gradient bucket is cut into two all-reduces (floats): the first decoder / head
@@ -628,7 +640,7 @@ class UpdateRunner:
         self._pipe = dict(W=W.segments, B=B.segments, wopt=gw, bopt=gb, cap=cap, rng_wm=rng_wm, rng_beh=rng_beh,
                           lanes=lanes, entered=False, shared=tools.default_rng(key_dev), mode=mode,
                           ev={k: mk() for k in ("tail", "fork1", "q1", "mid", "fork2", "q2")},
-                          ev2={k: torch.cuda.Event() for k in ("load", "start", "mid", "defer", "wopt")},
+                          ev2={k: (mk() if k == "mid" else torch.cuda.Event()) for k in ("load", "start", "mid", "defer", "wopt")},
                           ring=[mk(), mk()])
 
     def _pipe_enter(self):
@@ -682,9 +694,11 @@ class UpdateRunner:
                     if g is not None:
                         self._traced(lb, g)
 
-        # the batch: its last reader in update k was the decoder loss (wm.mid)
+        # the batch: its last reader in update k was the decoder loss (wm.mid).  The HOST waits for that point, not the
+        # stream: a queue whose head is a blocked barrier packet costs every launch of the two lanes ~1.3 us, and the host
+        # is up to two updates ahead here
         if not first:
-            cur.wait_event(ev["mid"])
+            ev["mid"].synchronize()
         self._load(data)
         ev["load"].record(cur)
         X.wait_event(ev["load"])
@@ -706,6 +720,7 @@ class UpdateRunner:
             self.beh._actor_opt.bucket.allreduce()
             self.beh._value_opt.bucket.allreduce()
             self._traced("bh.opt", P["bopt"])
+            self._sink(1, P["cap"]["beh_out"][-1])
         Y.wait_event(ev["mid"])
         run(W, ["wm.defer"], Y)
         ev["defer"].record(Y)
@@ -713,6 +728,7 @@ class UpdateRunner:
         with torch.cuda.stream(X):
             self.wm._model_opt.bucket.allreduce()
             self._traced("wm.opt", P["wopt"])
+            self._sink(0, P["cap"]["m1"])
         ev["wopt"].record(X)
         ring[it % 2].record(X)
         P["lanes_running"] = True
@@ -815,9 +831,11 @@ class UpdateRunner:
             if w is not None:
                 w.wait()
         P["wopt"].replay()
+        self._sink(0, P["cap"]["m1"])
         self.beh._actor_opt.bucket.allreduce()
         self.beh._value_opt.bucket.allreduce()
         P["bopt"].replay()
+        self._sink(1, P["cap"]["beh_out"][-1])
 
     # -- the reference's two calls ------------------------------------------------------------------------
     def train_wm(self, data):
