@@ -168,7 +168,10 @@ class WorldModel(nn.Module):
         q_post) of [T,B,S,D] Exp(1) draws.  A driver written against the reference's classes (its dreamer.py:192-199)
         calls this and then ImagBehavior._train(post, reward): once a behaviour exists both go through one
         dv3hip.graph.UpdateRunner, which replays the update from hipGraphs after two eager warm-up calls (config key
-        `hip_graph`, default on) -- the eager launch sequence is host-bound (19.5 ms per cfg-2 update against 16.2)."""
+        `hip_graph`, default on) -- the eager launch sequence is host-bound (19.5 ms per cfg-2 update against 16.2).
+        Aliasing: `post` / `context` are views of the scan's buffers, which the NEXT world-model update rewrites in place
+        (the behaviour of the same update reads them there); a caller that keeps them across a later update clones
+        them.  The metrics are per-call snapshots."""
         r = self._auto_runner() if noise is None else None
         if r is None:
             return self._train_eager(data, noise)
