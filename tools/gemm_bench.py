@@ -52,6 +52,7 @@ SHAPES = [
 
 
 ZEROS = False
+LANE = None  # --lane: replay on the 128-CU side lane (engine.Lanes) -- what a kernel sees in the pipelined update
 
 
 def bench(M, N, K, tA, tB, tile, reps):
@@ -78,9 +79,10 @@ def bench(M, N, K, tA, tB, tile, reps):
     g.replay()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    g.replay()
-    b.record()
+    with torch.cuda.stream(LANE if LANE is not None else torch.cuda.current_stream()):
+        a.record()
+        g.replay()
+        b.record()
     torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3 / reps
     return us, 2.0 * M * N * K / us / 1e6
@@ -92,9 +94,14 @@ def main():
     ap.add_argument("--tiles", default="0,1")
     ap.add_argument("--only", default="", help="substring of the note column")
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands (clock / power check)")
+    ap.add_argument("--lane", action="store_true", help="replay on the 128-CU side lane instead of the whole chip")
     args = ap.parse_args()
-    global ZEROS
+    global ZEROS, LANE
     ZEROS = args.zeros
+    if args.lane:
+        from dv3hip import engine
+
+        LANE = engine.Lanes.get(torch.device("cuda", 0)).streams["side"]
     tiles = [int(t) for t in args.tiles.split(",")]
     print(f"{'shape':>22s} {'tA tB':>6s} {'tile':>5s} {'us':>9s} {'TFLOP/s':>8s} {'frac':>6s}  note")
     for M, N, K, tA, tB, note in SHAPES:

@@ -2,7 +2,10 @@
 """Soak run (MI355X only): N hipGraph-replayed updates of a BASELINE config on fresh synthetic batches staged from the
 host each step; checks that every logged metric stays finite and prints the loss trajectory.
 
-    python tools/soak.py [cfg2] [--steps 200]
+    python tools/soak.py [cfg2] [--steps 200] [--pipelined | --pairs]
+
+--pipelined: the run of updates through UpdateRunner.step_pipelined (the two-update pipeline), flushed every 10 updates
+where the metrics are read; --pairs: two updates per call + flush, as Dreamer.__call__ issues them at the dmc configs.
 """
 import os
 import sys
@@ -36,11 +39,17 @@ def main():
     import time
 
     t0 = time.perf_counter()
+    mode = "pipelined" if "--pipelined" in sys.argv else ("pairs" if "--pairs" in sys.argv else "serial")
     for i in range(steps):
         # (uploads and update on the stream the runner launches on: dv3hip.graph.UpdateRunner.launch_stream)
         with torch.cuda.stream(runner.launch_stream() or torch.cuda.current_stream()):
-            runner.step(stager.stage(batches[i % len(batches)]))
+            (runner.step if mode == "serial" else runner.step_pipelined)(stager.stage(batches[i % len(batches)]))
+            if mode == "pairs" and i % 2 == 1:
+                runner.flush()
         if i % 10 == 9 or i == steps - 1:
+            with torch.cuda.stream(runner.launch_stream() or torch.cuda.current_stream()):
+                runner.flush()
+            runner.last_metrics = {**runner.wm_metrics, **runner.beh_metrics}
             m = {k: float(v) for k, v in runner.last_metrics.items() if np.ndim(float(v)) == 0}
             bad = [k for k, v in m.items() if not np.isfinite(v)]
             assert not bad, (i, bad)
@@ -49,7 +58,7 @@ def main():
                   f"value_loss {m['value_loss']:9.4f}  model_grad_norm {m['model_grad_norm']:9.2f}", flush=True)
     assert hist[-1][1] < hist[0][1], "model loss did not decrease"
     torch.cuda.synchronize()
-    print(f"soak ok: {steps} updates, {(time.perf_counter() - t0) / steps * 1e3:.2f} ms per update including the metric read-backs")
+    print(f"soak ok ({mode}): {steps} updates, {(time.perf_counter() - t0) / steps * 1e3:.2f} ms per update including the metric read-backs")
 
 
 if __name__ == "__main__":
