@@ -318,6 +318,11 @@ class UpdateRunner:
         # was launched on -- the caller's accumulation of the device-resident metrics is then stream-ordered with their
         # producer and needs no other queue to wait (a blocked queue costs every launch of the others ~1.3 us)
         self.metric_sinks = None
+        # data parallel: all-reduce the decoder / head half of the world-model gradient as soon as the lanes have joined,
+        # beside the encoder's backward (_model_cut).  OFF until it has been measured on more than one GPU: in the
+        # one-rank RCCL rehearsal (DV3_BENCH_PG1=1 DV3_FORCE_ALLREDUCE=1 bench.py --plain --serial) the two asynchronous
+        # collectives cost 17.58 ms per update against 16.51 with the single all-reduce (16.43 without a process group)
+        self.dp_split = _dev.flag("DV3_DP_SPLIT", False)
         self._pipe = None
         self._pipe_trace = None
         self._pipe_pending = False  # a world-model phase has been issued whose behaviour phase has not
@@ -402,7 +407,7 @@ class UpdateRunner:
         """Where the world-model gradient bucket is cut into two all-reduces (floats): the first decoder / head
         parameter -- `heads.*` follows encoder and dynamics in WorldModel.parameters().  None on a single rank."""
         mb = self.wm._model_opt.bucket
-        if not mb.distributed():
+        if not mb.distributed() or not self.dp_split:
             return None
         if "cut" not in self.__dict__:
             first = next((p for n, p in self.wm.named_parameters() if n.startswith("heads.")), None)
