@@ -499,10 +499,13 @@ class UpdateRunner:
     # self._train(next(self._dataset))` (dreamer.py:95-97; 2 per call at the dmc configs, 100 at pretrain).  Within such a
     # run the behaviour phase of update k only READS the world model that update k's Adam step left behind, and the
     # world-model phase of update k+1 reads the same weights and a fresh batch: the two are independent until update
-    # k+1's own Adam step.  step_pipelined() therefore issues world model k+1 BESIDE behaviour k: the two observe scans
-    # of the world-model phase are chains of dependent 16-row launches that cannot use more than half of the chip
-    # (DESIGN.md section 4), and the behaviour phase's rollout and reverse rollout -- themselves chains of 1024-row
-    # launches -- run on the other half meanwhile (engine.Lanes: complementary CU masks).  Every number is the serial
+    # k+1's own Adam step.  step_pipelined() therefore issues world model k+1 BESIDE behaviour k, on the two CU-masked
+    # lanes of engine.Lanes (complementary halves of the chip).  Schedule "lanes" (_pipe_iteration_lanes; taken where the
+    # world model has the conv stacks): each phase on its own half from end to end -- a segment of this update's
+    # launches takes only 1.5-1.8x as long on 128 compute units as on 256, so two half-chip streams of independent work
+    # beat one whole-chip stream (cfg 2: 16.3 -> 13.6 ms per update).  Schedule "staged" (_pipe_iteration): only the two
+    # observe scans -- chains of dependent 16-row launches that cannot use more than half of the chip -- beside the
+    # behaviour's rollout / reverse rollout, everything else on the whole chip (cfg 2: 15.3; cfg 1: 11.5).  Every number is the serial
     # sequence's: the same weights are read (world-model Adam k+1 is ordered behind behaviour k's last read of them),
     # the posterior of update k is copied out before scan k+1 overwrites it ("bh.start"), and each phase draws from
     # the Philox counters the serial order would have given it (ops.PhasedRng).  flush() issues the last behaviour
