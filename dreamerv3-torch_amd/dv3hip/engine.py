@@ -119,6 +119,7 @@ class Lanes:
                 _lib.check(lib.dv3_stream_create_cu_masked(words, mask, ctypes.byref(out)), "dv3_stream_create_cu_masked")
                 self._handles[lane] = out.value
                 self.streams[lane] = torch.cuda.ExternalStream(out.value, device=device)
+                ops.LANE_STREAMS[out.value] = self.cus[lane]  # (ops.gemm picks its tile for the CUs the launch can use)
         # the runtime's own teardown of these queues at process exit (static destructors) crashes under rocprofv3: hand them
         # back while the interpreter is still alive
         import atexit

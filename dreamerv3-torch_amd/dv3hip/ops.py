@@ -218,6 +218,19 @@ def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
     return _legacy_tile(M, N)
 
 
+# The pipelined update (graph.UpdateRunner.step_pipelined, schedule "lanes") launches every kernel on a queue that owns
+# 128 of the 256 compute units (engine.Lanes registers its streams here).  On half of the chip the k-contiguous LDS tiles
+# trade places for a few shapes (tools/gemm_bench.py --lane, us per launch on a lane, picked / whole-chip choice):
+#   1024 x 1536 x 1024 (GRU of the rollout)  64x96 62.9 / 32x64 74.2      2048 x 3072 x 1536 (cfg 3 GRU)  128x64 325 / 32x64 362
+#   2048 x 1024 x 1024 (cfg 3 stacked)        128x64 76.8 / 64x64 84.2    15360 x 255 x 512 (head out)     128x128 76.8 / 64x64 86.9
+#   14336 x 1024 x 512 (head dgrad to stoch)  64x64 281.6 / 128x128 297.6
+# All of these tiles run the same K loop (32-wide K tiles, v_mfma_f32_16x16x4_f32 in ascending k): switching among them
+# changes no bit of the result (tests/test_kernels_gpu.py::test_l16_tiles_agree_bit_for_bit), so the lanes schedule still
+# computes exactly what the serial update computes.
+LANE_STREAMS = {}  # stream handle -> compute units of its queue
+_LANE_TILES = {(1024, 1536): 12, (2048, 3072): 16, (2048, 1024): 16, (15360, 255): 15, (14336, 1024): 13}
+
+
 # ---------------------------------------------------------------------------------------------
 def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=False, tile=-1):
     """C (+)= [A|A2] @ op(B) + bias.   op(B)[K,N]: transB -> B is [N,K]; else B is [K,N].
@@ -266,6 +279,8 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         return gemm(A, Bt, C, transA=False, transB=True, bias=bias, accumulate=accumulate)
     if tile < 0:
         tile = pick_gemm_tile(M, N, bool(transA), K)
+        if tile in (13, 14, 15) and LANE_STREAMS.get(s, 256) <= 128:
+            tile = _LANE_TILES.get((M, N), tile)
         if M <= 32 and not transA:
             tile = 3
         if 32 < M <= 128 and tile == 9 and not transA and (A2 is None or K1 % 16 == 0):

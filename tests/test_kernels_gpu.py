@@ -140,6 +140,49 @@ def test_gemm_kcontiguous_lds_tile(ops, M, N, K1, K2, acc, tile):
     assert_close(C, want, what=f"gemm tile {tile}")
 
 
+@pytest.mark.parametrize("M,N,K1,K2", [(1024, 1536, 512, 512), (2048, 3072, 1536, 0), (2048, 1024, 1024, 0),
+                                       (15360, 255, 512, 0), (14336, 1024, 512, 0), (130, 200, 96, 32)])
+def test_l16_tiles_agree_bit_for_bit(ops, M, N, K1, K2):
+    """The k-contiguous LDS tiles (12-17: 64x96, 64x64, 32x64, 128x128, 128x64, 64x128) run ONE K loop -- 32-wide K
+    tiles, v_mfma_f32_16x16x4_f32 in ascending k, the [A | A2] seam on a K-tile boundary -- so which of them a launch
+    takes changes no bit of the result.  ops.gemm relies on that: on a 128-CU lane of the pipelined update it picks
+    another tile than on the whole chip (ops._LANE_TILES) and the lanes schedule still computes exactly the serial update."""
+    g = torch.Generator().manual_seed(M + N)
+    K = K1 + K2
+    A, A2 = dev(torch.randn(M, K1, generator=g)), dev(torch.randn(M, K2, generator=g)) if K2 else None
+    W, b = dev(torch.randn(N, K, generator=g) / math.sqrt(K)), dev(torch.randn(N, generator=g))
+    outs = {}
+    for tile in (12, 13, 14, 15, 16, 17):
+        C = torch.empty(M, N, device="cuda")
+        ops.gemm(A, W, C, A2=A2, bias=b, tile=tile)
+        outs[tile] = C
+    for tile, C in outs.items():
+        assert torch.equal(C, outs[14]), f"tile {tile} differs from the 32x64 tile by {float((C - outs[14]).abs().max()):.3e}"
+
+
+def test_gemm_picks_lane_tiles_on_a_cu_masked_stream(ops):
+    """On a 128-CU lane ops.gemm takes the tile measured best there, on the whole chip the whole-chip choice; same bits."""
+    from dv3hip import engine
+
+    ln = engine.Lanes.get(torch.device("cuda", 0))
+    if ln is None:
+        pytest.skip("no CU-masked streams on this device")
+    M, N, K = 1024, 1536, 1024
+    g = torch.Generator().manual_seed(5)
+    A, W = dev(torch.randn(M, K, generator=g)), dev(torch.randn(N, K, generator=g) / 32.0)
+    outs, keys = [], []
+    for st in (ln.streams["whole"], ln.streams["side"]):
+        C = torch.empty(M, N, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            ops.PROFILE.start()
+            ops.gemm(A, W, C)
+            keys.append(list(ops.PROFILE.stop()))
+        outs.append(C)
+    assert keys[0] == ["gemm_kernel<l16_32x64,tA=0,tB=1>"] and keys[1] == ["gemm_kernel<l16_64x96,tA=0,tB=1>"], keys
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("M", [33, 50, 64, 100, 128])
 @pytest.mark.parametrize("transB", [True, False])
 @pytest.mark.parametrize("acc", [False, True, "atomic"])

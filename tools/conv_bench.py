@@ -18,6 +18,9 @@ import torch  # noqa: E402
 from dv3hip import ops  # noqa: E402
 
 
+LANE = None  # --lane: replay on the 128-CU side lane (engine.Lanes)
+
+
 def graph_us(fn, reps):
     for _ in range(2):
         fn()
@@ -31,9 +34,10 @@ def graph_us(fn, reps):
     g.replay()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    g.replay()
-    b.record()
+    with torch.cuda.stream(LANE if LANE is not None else torch.cuda.current_stream()):
+        a.record()
+        g.replay()
+        b.record()
     torch.cuda.synchronize()
     return a.elapsed_time(b) * 1e3 / reps
 
@@ -45,7 +49,13 @@ def main():
     ap.add_argument("--depth", type=int, default=32, help="cnn_depth: 32 (cfg 2) or 96 (cfg 4 / 5)")
     ap.add_argument("--only", default="", help="substring of the op name (conv_s2, convT_s2, conv_wgrad)")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-GEMM comparison column")
+    ap.add_argument("--lane", action="store_true", help="replay on the 128-CU side lane instead of the whole chip")
     args = ap.parse_args()
+    if args.lane:
+        global LANE
+        from dv3hip import engine
+
+        LANE = engine.Lanes.get(torch.device("cuda", 0)).streams["side"]
     N = args.frames
     r = lambda *s: torch.randn(*s, device="cuda")
     # (H = fine grid side, C fine, C coarse): encoder conv fine->coarse; decoder convT coarse->fine
