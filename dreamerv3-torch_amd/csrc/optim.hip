@@ -25,6 +25,34 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) atomicAdd(out, a);
 }
 
+// The same sum in a FIXED order: block b leaves its partial sum in partial[b] (no atomics), one workgroup adds the
+// partials up by index.  The gradient norm -- and with it the clipping coefficient -- is then a pure function of the
+// gradient: data-parallel replicas that hold the same all-reduced gradient take bit-identical Adam steps (with the
+// atomic form their norms differed in the last bit and the replicas drifted apart by 1e-9 per clipped update).
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float a = 0.f;
+  const long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    a += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0) {
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) a += x[i] * x[i];
+  }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < blocks; i += 256) a += partial[i];
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) out[0] += a;
+}
+
 // state[0] = step count (float, exact up to 2^24), state[1] = sum of squared grads (input),
 // state[2] = grad norm (output, for the `*_grad_norm` metric)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -266,6 +294,16 @@ extern "C" int dv3_sumsq_accumulate(const float* x, long n, float* out, void* st
   if (n <= 0) return 0;
   if (!x || !out || ((uintptr_t)x & 15)) return DV3_ERR_ARG;
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks_for(n, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_sumsq_ordered(const float* x, long n, float* out, float* partial, int partial_len, void* stream) {
+  if (n <= 0) return 0;
+  if (!x || !out || !partial || partial_len < 1 || ((uintptr_t)x & 15)) return DV3_ERR_ARG;
+  const unsigned blocks = blocks_for(n, partial_len < 1024 ? partial_len : 1024);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, s, x, n, partial);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, partial, (int)blocks, out);
   return (int)hipGetLastError();
 }
 

@@ -1051,6 +1051,12 @@ def sumsq_accumulate(x, out):
     _call("dv3_sumsq_accumulate", _ptr(x), x.numel(), _ptr(out), _stream())
 
 
+def sumsq_ordered(x, out, partial):
+    """out[0] += sum(x^2), summed in a fixed order (partial: float32 scratch of >= 1 element, up to 1024 are used)."""
+    _contig(x, "x"), _contig(out, "out"), _contig(partial, "partial")
+    _call("dv3_sumsq_ordered", _ptr(x), x.numel(), _ptr(out), _ptr(partial), int(partial.numel()), _stream())
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, state, *, lr, beta1=0.9, beta2=0.999, eps, clip, weight_decay=0.0,
               grad_scale=1.0):
     for t, nm in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"),

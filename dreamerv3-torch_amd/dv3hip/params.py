@@ -73,6 +73,7 @@ class ParamBucket:
             self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
             self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
             self.state = torch.zeros(4, dtype=torch.float32, device=dev)  # step, sumsq, last norm, spare
+            self._norm_partial = torch.zeros(1024, dtype=torch.float32, device=dev)  # ops.sumsq_ordered's scratch
         return self
 
     def numel(self) -> int:
@@ -115,7 +116,8 @@ class ParamBucket:
 
     def step(self, *, lr, eps, clip, weight_decay=0.0, grad_scale=1.0):
         """clip_grad_norm_ + Adam on the whole bucket; the pre-clip norm lands in state[2]."""
-        ops.sumsq_accumulate(self.grad, self.state[1:2])
+        # (fixed summation order: replicas with the same all-reduced gradient clip and step bit-identically)
+        ops.sumsq_ordered(self.grad, self.state[1:2], self._norm_partial)
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.state, lr=lr, eps=eps, clip=clip,
                       weight_decay=weight_decay, grad_scale=grad_scale)
 

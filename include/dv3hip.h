@@ -307,6 +307,10 @@ int dv3_obs_carry_st_bwd(const float* dsin, long ld_dsin, const float* ddin, lon
  * clip/(norm+1e-6) (clip <= 0: no clipping), applies torch.optim.Adam's update, bumps the step and
  * clears the accumulator -- all on device.  dv3_axpby: y = a*x + b*y (slow critic, models.py:683-689). */
 int dv3_sumsq_accumulate(const float* x, long n, float* out, void* stream);
+/* The same sum in a fixed order (per-workgroup partial sums in partial[0 .. min(partial_len, 1024)), added up by index by
+ * one workgroup; two launches, no atomics): the clipping norm of tools.py:768 as a pure function of the gradient, so that
+ * data-parallel replicas holding the same all-reduced gradient take bit-identical steps. */
+int dv3_sumsq_ordered(const float* x, long n, float* out, float* partial, int partial_len, void* stream);
 int dv3_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float* state,
                   double lr, double beta1, double beta2, double eps, float clip, float weight_decay,
                   float grad_scale, void* stream);

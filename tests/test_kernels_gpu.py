@@ -709,6 +709,29 @@ def test_adam_clip_matches_oracle(ops):
     assert state[0].item() == 3.0 and state[1].item() == 0.0
 
 
+@pytest.mark.parametrize("n", [1, 5, 4099, 1 << 20, 15687811])
+def test_gradient_norm_is_summed_in_a_fixed_order(ops, n):
+    """dv3_sumsq_ordered (the clipping norm of tools.py:768 on the flat bucket): equal to the sum of squares, accumulates
+    into `out`, and bit-identical from launch to launch -- per-workgroup partial sums added up by index, no atomics --
+    so that data-parallel replicas with the same all-reduced gradient take the same step (tests/test_dp_gpu.py)."""
+    g = torch.Generator().manual_seed(n % 1000)
+    x = dev(torch.randn(n + 4, generator=g))[:n] if n % 4 else dev(torch.randn(n, generator=g))
+    x = x.contiguous()
+    partial = torch.zeros(1024, device="cuda")
+    outs = []
+    for _ in range(4):
+        out = torch.full((1,), 2.5, device="cuda")
+        ops.sumsq_ordered(x, out, partial)
+        outs.append(out.clone())
+    want = float((x.double() ** 2).sum()) + 2.5
+    assert abs(float(outs[0]) - want) <= 2e-6 * want
+    assert all(torch.equal(o, outs[0]) for o in outs), [float(o) for o in outs]
+    small = torch.zeros(3, device="cuda")  # a short scratch buffer limits the number of workgroups, not the result's value
+    out = torch.zeros(1, device="cuda")
+    ops.sumsq_ordered(x, out, small)
+    assert abs(float(out) - (want - 2.5)) <= 2e-6 * want
+
+
 # ------------------------------------------------------------------------------------------ conv stacks
 CONV_CASES = [(4, 64, 64, 3, 32), (3, 32, 32, 32, 64), (2, 16, 16, 64, 128), (5, 8, 8, 128, 256),
               (3, 64, 64, 3, 2), (3, 32, 32, 2, 4), (2, 8, 8, 8, 16), (1, 4, 4, 6, 5),
