@@ -74,6 +74,7 @@ class Dreamer(nn.Module):
     def _policy(self, obs, state, training, noise=None):
         """Acting step.  With config.hip_graph (default) the launch sequence is replayed from a hipGraph per
         (number of envs, training) signature (dv3hip.graph.PolicyRunner); injected noise (tests) takes the eager path."""
+        self._finish_updates()  # (a behaviour phase the update loop left pending trains the actor this step acts with)
         # the Random explorer samples from torch's generator: not a static launch sequence
         random_now = training and self._config.expl_behavior == "random" and self._exploring()
         if (noise is None and bool(getattr(self._config, "hip_graph", True)) and self._policy_runner is not False
@@ -153,6 +154,11 @@ class Dreamer(nn.Module):
                 xm = self._expl_behavior.train(self._runner.last_post, self._runner.last_context,
                                                self._runner.last_data)[-1]
                 self._accumulate({"expl_" + k: v for k, v in xm.items()}, "expl")
+
+    def state_dict(self, *args, **kwargs):
+        """The checkpoint of dreamer.py:563-567 holds the actor / critic of the LAST update: flush a pending phase first."""
+        self._finish_updates()
+        return super().state_dict(*args, **kwargs)
 
     def _finish_updates(self):
         """End of a run of pipelined updates: issue the behaviour phase that is still pending."""
