@@ -47,5 +47,44 @@ def main():
         print(f"kernels of the main queue inside the lanes' window: {len(inside)}", file=out)
 
 
+def pipelined():
+    """--pipelined: the two-update pipeline in the lanes schedule (bench.py --plain): the two lane queues carry the
+    whole update.  Over the last four updates: each queue's busy time, and for how much of the window both / exactly
+    one / none of them had a kernel running."""
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    out = open(sys.argv[2], "w") if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else sys.stdout
+    for r in rows:
+        r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    rows.sort(key=lambda r: r["s"])
+    adam = [r for r in rows if "adam_kernel" in r["Kernel_Name"]]
+    n_upd = 4
+    end, begin = adam[-1]["e"], adam[-1 - 3 * n_upd]["e"]
+    win = [r for r in rows if begin < r["s"] and r["e"] <= end]
+    byq = collections.defaultdict(list)
+    for r in win:
+        byq[r["Queue_Id"]].append(r)
+    qs = sorted(byq, key=lambda q: -len(byq[q]))[:2]
+    print(f"last {n_upd} updates: {len(win)} kernels in {(end - begin) / 1e6:.3f} ms = {(end - begin) / 1e6 / n_upd:.3f} ms per update "
+          f"(under the tracer); kernels per queue: " + ", ".join(f"queue {q}: {len(byq[q])}" for q in sorted(byq)), file=out)
+    ev = []
+    for i, q in enumerate(qs):
+        busy = sum(k["e"] - k["s"] for k in byq[q])
+        top = collections.Counter(k["Kernel_Name"].split("(")[0][:50] for k in byq[q]).most_common(3)
+        print(f"queue {q}: busy {busy / 1e6:7.3f} ms ({100.0 * busy / (end - begin):4.1f} % of the window); "
+              + "; ".join(f"{n} x{c}" for n, c in top), file=out)
+        for k in byq[q]:
+            ev.append((k["s"], 1 << i)), ev.append((k["e"], -(1 << i)))
+    ev.sort()
+    t, state, acc = begin, [0, 0], collections.Counter()
+    for ts, d in ev:
+        acc[(state[0] > 0) + (state[1] > 0)] += ts - t
+        t = ts
+        state[0 if abs(d) == 1 else 1] += 1 if d > 0 else -1
+    acc[(state[0] > 0) + (state[1] > 0)] += end - t
+    tot = float(end - begin)
+    print(f"both lane queues busy {100 * acc[2] / tot:4.1f} % of the window, exactly one {100 * acc[1] / tot:4.1f} %, "
+          f"none {100 * acc[0] / tot:4.1f} %", file=out)
+
+
 if __name__ == "__main__":
-    main()
+    pipelined() if "--pipelined" in sys.argv else main()
