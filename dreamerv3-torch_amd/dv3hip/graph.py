@@ -617,11 +617,10 @@ class UpdateRunner:
         cap = {}
         # separate graph pools: the two phases replay in an order other than the capture order
         pool_w, pool_b = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
-        if mode == "lanes" and plan.get("defer_split") is None and self.wm._config.imag_gradient != "reinforce":
-            # balance: with a reverse rollout on the behaviour's lane (imag_gradient dynamics / both) the heads' deferred
-            # weight gradients run on the world model's own lane (cfg 2: 13.75 against 13.9 ms; cfg 3, reinforce: 24.2
-            # with all of them on the behaviour's lane against 24.4-24.7)
-            plan["defer_split"] = getattr(self.wm, "_defer_heads_from", None)
+        # (defer_split, development switch: move the deferred launches behind that index -- WorldModel._defer_heads_from names
+        # where the heads' begin -- onto the world model's own lane.  With the lane-aware weight-gradient tiles both lanes of
+        # cfg 2 end within 0.03 ms of each other with ALL of them on the behaviour's lane: 13.21 ms against 13.35 / 13.43 with
+        # the last three / six on the other lane)
         w_cuts = [f"wm.defer@{plan['defer_split']}"] if (plan.get("defer_split") and mode == "lanes") else []
         with tools.rng_override(key_dev, rng_wm):
             W = PhaseRecorder(pool_w, dev, lanes, lane_wm, "wm.pre", optional=w_cuts).record(

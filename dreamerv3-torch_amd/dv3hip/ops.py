@@ -281,6 +281,15 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         tile = pick_gemm_tile(M, N, bool(transA), K)
         if tile in (13, 14, 15) and LANE_STREAMS.get(s, 256) <= 128:
             tile = _LANE_TILES.get((M, N), tile)
+        if tile in (4, 10) and transA and not transB and A2 is None and bias is None and LANE_STREAMS.get(s, 256) <= 128:
+            # weight gradients on a 128-CU lane (tools/gemm_bench.py --lane --only wgrad, us): long reductions on the k-major
+            # 128x128x16 tile -- 512 x 512 x 14336: 151 against 180 (register-direct) / 193 (128x128x32); 512 x 1536 x 15360:
+            # 423 against 554 -- and the K = 1024 products of the world model up to 2 M outputs on the 64x64x32 tile
+            # (1536 x 1024: 74.8 against 85.5; 1024 x 512: 30.9 against 35.3; 512 x 4608 stays register-direct: 118.9)
+            if K >= 4096:
+                tile = 0
+            elif M * N <= 2 * 1024 * 1024:
+                tile = 1
         if M <= 32 and not transA:
             tile = 3
         if 32 < M <= 128 and tile == 9 and not transA and (A2 is None or K1 % 16 == 0):
