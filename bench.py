@@ -413,11 +413,32 @@ def main():
                 mfma_pmc = {"mfma_util": pm[sym]["mfma_util"], "source": f"profiles/{os.path.basename(path)} "
                             "(SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))"}
                 break
+        # the timed region runs the two-update pipeline: every kernel on a 128-CU lane, some on another tile than on the
+        # whole chip (ops._LANE_TILES).  Per-kernel durations there cannot be taken with event pairs (two queues run side
+        # by side): the dominant kernel of the committed rocprofv3 trace of `bench.py --plain` is quoted beside this leg's
+        lanes_row = None
+        for path in sorted((q for q in glob.glob(os.path.join(REPO, "profiles", "r*_kernel_stats.csv")) if "serial" not in q),
+                           reverse=True):
+            try:
+                import csv
+
+                top = next(csv.DictReader(open(path)))
+                lanes_row = {"kernel_symbol": top["Name"], "avg_launch_us": float(top["AverageNs"]) / 1e3,
+                             "share_of_kernel_time_pct": float(top["Percentage"]),
+                             "source": f"profiles/{os.path.basename(path)} (rocprofv3 --kernel-trace --stats of bench.py --plain: "
+                                       "the pipelined timed region, every kernel on a 128-CU lane)", "measured_in_run": False}
+                break
+            except Exception:
+                continue
         scan = {k: v for k, v in mf.items() if "skinny16" in k}
         scan_ms = sum(v["ms"] for v in scan.values())
         scan_n = sum(v["launches"] for v in scan.values())
         scan_bytes = sum(v["bytes"] for v in scan.values())
         roofline = {"bound": "mfma", "kernel": dom, "kernel_symbol": sym, "achieved": ach,
+                    "measured_on": "one eager update on the whole chip after the timed region, HIP event pair per launch; its "
+                                   "kernel trace is profiles/rNN_serial_kernel_stats.csv (bench.py --plain --serial), whose top "
+                                   "row is this kernel",
+                    "pipelined_trace_top_kernel": lanes_row,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                     "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": False,
                     "mfma_busy_counter": mfma_pmc,
