@@ -608,6 +608,14 @@ class UpdateRunner:
                               "wm.defer": "side"}.get(lb, "main")
         lane_beh = lambda lb: "side" if lb.startswith(("bh.A", "bh.C")) else "main"
         mode = self._pipe_mode()
+        if plan.get("defer", "auto") == "auto":
+            # staged: the side lane beside the reverse scan takes the reverse rollout where there is one (imag_gradient
+            # dynamics / both) and the deferred weight gradients run in line on the whole chip (cfg 2: 15.3 against
+            # 16.1 ms with them behind the reverse rollout on the lane); else the lane is theirs (reinforce)
+            plan["defer"] = "post" if wm._config.imag_gradient in ("dynamics", "both") else "side"
+        if mode == "staged" and plan["defer"] != "side":
+            # (captured where it runs: ops.gemm picks its tile for the compute units of the capture stream's queue)
+            lane_wm = lambda lb: {"wm.fscan": "scan", "wm.fscan2": "scan", "wm.rscan": "scan", "wm.rscan2": "scan"}.get(lb, "main")
         if mode == "lanes":
             # each phase on a lane of its own from end to end: its segments are captured on that lane's stream
             lane_wm = lambda lb: "side" if lb == "wm.defer" else "scan"  # ("wm.defer@i", the rest of them: on the scan lane)
@@ -636,11 +644,6 @@ class UpdateRunner:
                 lambda: beh.train_fwd_bwd(cap["post"]), at_end=rng_beh.finish_phase)
             gb = torch.cuda.CUDAGraph()
             _capture(gb, lambda: cap.update(beh_out=beh.train_opt(allreduce=False)), pool=pool_b)
-        if plan.get("defer", "auto") == "auto":
-            # staged: the side lane beside the reverse scan takes the reverse rollout where there is one (imag_gradient
-            # dynamics / both) and the deferred weight gradients run in line on the whole chip (cfg 2: 15.3 against
-            # 16.1 ms with them behind the reverse rollout on the lane); else the lane is theirs (reinforce)
-            plan["defer"] = "post" if any(lb == "bh.C" for lb, _ in B.segments) else "side"
         stride = rng_wm.taken + rng_beh.taken
         rng_wm.stride.fill_(stride), rng_beh.stride.fill_(stride)
         mk = lambda: torch.cuda.Event(blocking=True)
