@@ -106,22 +106,24 @@ def phase_timers(wm, beh, data, H, t_upd_ms, reps=10):
     """T_img / T_beh of SURVEY 8(d): device time of one hipGraph replay each (median of `reps`)."""
     from dv3hip import ops
 
-    def replay_ms(fn):
+    def replay_ms(fn, on=None):
+        """on: capture and replay on that stream (a 128-CU lane of engine.Lanes) instead of a whole-chip torch stream."""
         fn()  # warm (workspace allocation happens outside capture)
         torch.cuda.synchronize()
-        st = torch.cuda.Stream()
+        st = on if on is not None else torch.cuda.Stream()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(st):
             with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
                 fn()
-        g.replay()
+            g.replay()
         torch.cuda.synchronize()
         ts = []
         for _ in range(reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            g.replay()
-            b.record()
+            with torch.cuda.stream(st):
+                a.record()
+                g.replay()
+                b.record()
             torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
         return float(np.median(ts))
@@ -140,7 +142,17 @@ def phase_timers(wm, beh, data, H, t_upd_ms, reps=10):
         beh.train_opt(allreduce=False)
 
     t_beh = replay_ms(behaviour)
-    return {"T_upd_ms": t_upd_ms, "T_beh_ms": t_beh, "T_img_ms": t_img,
+    # the rollout where the pipelined update runs it: alone on one 128-CU lane (half of the chip's matrix pipes)
+    t_img_lane = None
+    try:
+        from dv3hip import engine
+
+        ln = engine.Lanes.get(data["action"].device)
+        if ln is not None:
+            t_img_lane = replay_ms(lambda: beh._imagine_fwd(post, H), on=ln.streams["side"])
+    except Exception as e:  # (a device without CU-masked streams: the figure is simply absent)
+        print(f"[bench] no lane timing of the rollout: {e}", file=sys.stderr)
+    return {"T_upd_ms": t_upd_ms, "T_beh_ms": t_beh, "T_img_ms": t_img, "T_img_lane_ms": t_img_lane,
             "method": "hipGraph replay of the phase, HIP events, median of 10",
             "imagine_fwd_gflop": gflop, "imagine_fwd_gflop_mfma": gflop_mfma, "imagine_fwd_tflops": gflop / t_img}
 
@@ -482,12 +494,20 @@ def main():
         timers["value_uses"] = "T_upd_pipelined_ms" if (mode == "pipelined" and runner._pipe is not None) else "T_upd_ms"
         if roofline is not None:
             g_mfma = timers.pop("imagine_fwd_gflop_mfma")
+            roofline_gflop = timers.pop("imagine_fwd_gflop")
             roofline["imagine_fwd"] = {
-                "gflop_dense_equivalent": timers.pop("imagine_fwd_gflop"), "ms": timers["T_img_ms"],
+                "gflop_dense_equivalent": roofline_gflop, "ms": timers["T_img_ms"],
                 "achieved": timers["imagine_fwd_tflops"], "unit": "TFLOP/s", "peak": PEAK_F32_MFMA_TFLOPS,
                 "frac": timers.pop("imagine_fwd_tflops") / PEAK_F32_MFMA_TFLOPS,
                 "gflop_mfma_executed": g_mfma,
                 "frac_mfma_executed": g_mfma / timers["T_img_ms"] / PEAK_F32_MFMA_TFLOPS,
+                "on_lane": (None if not timers.get("T_img_lane_ms") else {
+                    "ms": timers["T_img_lane_ms"], "cus": 128, "peak": PEAK_F32_MFMA_TFLOPS / 2,
+                    "achieved": roofline_gflop / timers["T_img_lane_ms"], "unit": "TFLOP/s",
+                    "frac_of_lane_peak": roofline_gflop / timers["T_img_lane_ms"] / (PEAK_F32_MFMA_TFLOPS / 2),
+                    "frac_mfma_executed_of_lane_peak": g_mfma / timers["T_img_lane_ms"] / (PEAK_F32_MFMA_TFLOPS / 2),
+                    "note": "the same rollout alone on one 128-CU lane, where the pipelined update runs it (beside the "
+                            "world-model phase of the next update on the other lane)"}),
                 "note": "imagination rollout (H actor evaluations + H-1 img_steps on B*T rows; the discarded H-th "
                         "successor of models.py:546 is not computed).  frac = SURVEY 8(d) algorithmic FLOPs (the "
                         "one-hot gather layers priced as the Linear they replace) / T_img / peak; frac_mfma_executed "
