@@ -126,6 +126,17 @@ class Lanes:
 
         atexit.register(self._destroy)
 
+    _closers: list = []  # weak references to the close() of whatever holds hipGraphs captured on the lanes' streams
+
+    @classmethod
+    def on_teardown(cls, bound_method):
+        """bound_method() is called before the lanes' streams are destroyed at interpreter exit: graphs captured on them
+        (and the allocator blocks of their pools, which are tagged with the capturing stream) must go first -- an agent
+        that is still alive as a module global would otherwise be torn down AFTER its streams (segfault at exit)."""
+        import weakref
+
+        cls._closers.append(weakref.WeakMethod(bound_method))
+
     def _destroy(self):
         from . import _lib
 
@@ -133,6 +144,15 @@ class Lanes:
         if not handles:
             return
         try:
+            torch.cuda.synchronize()
+            closers, Lanes._closers = Lanes._closers, []
+            for ref in closers:
+                fn = ref()
+                if fn is not None:
+                    fn()
+            import gc
+
+            gc.collect()
             torch.cuda.synchronize()
             lib = _lib.load()
             for h in handles.values():

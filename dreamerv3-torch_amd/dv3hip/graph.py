@@ -13,6 +13,7 @@ from __future__ import annotations
 
 from typing import Dict
 
+import numpy as np
 import torch
 
 from . import _dev, _lib, ops
@@ -327,6 +328,9 @@ class UpdateRunner:
         self._pipe_trace = None
         self._pipe_pending = False  # a world-model phase has been issued whose behaviour phase has not
         self.pipe_plan = dict(_PIPE_PLAN)
+        from . import engine
+
+        engine.Lanes.on_teardown(self.close)
 
     # -- the two halves of one update -----------------------------------------------------------------
     # World-model half: [fwd+bwd as per-lane graphs] -> all-reduce -> [clip+Adam].  Behaviour half: [imagine, returns,
@@ -346,6 +350,7 @@ class UpdateRunner:
     def _wm_half(self, data, eager=False):
         self._calls += 1
         if self._replaying(eager):
+            self._check_weights()
             self._load(data)
             if self._g_wm is None:
                 torch.cuda.synchronize()
@@ -424,6 +429,24 @@ class UpdateRunner:
         print(f"[dv3hip] hipGraph capture refused ({e}); falling back to eager launches", file=sys.stderr)
         self.use_graph, self._g_wm, self._g_beh = False, None, None
         torch.cuda.synchronize()  # an asynchronous HIP error surfaces here instead of being trained over
+
+    def close(self):
+        """Drop every captured graph (engine.Lanes calls this before it destroys the streams they were captured on)."""
+        self._g_wm = self._g_beh = self._pipe = None
+        self._cap, self._beh_out = {}, None
+        self._pipe_pending = False
+        self.use_graph = False
+
+    def _check_weights(self):
+        """The captured launches hold raw pointers into the three flat parameter buckets: replaying them over weights
+        that have been moved since (Module.to, a rebuilt bucket) would train memory nobody reads."""
+        where = tuple(b.flat.data_ptr() if b.settled() else 0 for b in
+                      (self.wm._model_opt.bucket, self.beh._actor_opt.bucket, self.beh._value_opt.bucket))
+        if self._g_wm is None:
+            self._weights = where
+        elif where != self._weights:
+            raise RuntimeError("the parameters were moved after the update's launch sequence was captured (Module.to / "
+                               "a rebuilt ParamBucket): build a new UpdateRunner")
 
     def _capture_wm(self):
         wm = self.wm
@@ -565,6 +588,7 @@ class UpdateRunner:
             if not self._pipe["entered"]:
                 self._pipe_enter()
             self._calls += 1
+            self._check_weights()
             if self._pipe["mode"] == "lanes":
                 self._pipe_iteration_lanes(data)
             else:
@@ -909,6 +933,18 @@ class UpdateRunner:
         return lanes.whole_chip_stream() if lanes is not None else None
 
 
+def weight_buckets(root):
+    """Every flat parameter bucket (params.ParamBucket) of the tools.Optimizer instances hanging off root's modules."""
+    import tools
+
+    out = []
+    for m in root.modules():
+        for v in vars(m).values():
+            if isinstance(v, tools.Optimizer) and all(v.bucket is not b for b in out):
+                out.append(v.bucket)
+    return out
+
+
 class PolicyRunner:
     """hipGraph replay of the acting step (Dreamer._policy: preprocess -> encoder -> obs_step -> actor; SURVEY 8(f)
     N1).  Eager, the step is ~45 launches and host-bound (0.8 ms at 1-16 envs); its launch sequence is static for a
@@ -921,6 +957,11 @@ class PolicyRunner:
     def __init__(self, agent):
         self.agent = agent
         self._sig = {}
+        self._buckets = weight_buckets(agent)
+        self._weights = None
+
+    def _weights_where(self):
+        return tuple((b.flat.data_ptr(), b.settled()) if b.flat is not None else (0, False) for b in self._buckets)
 
     def _build(self, obs, state, training):
         ag = self.agent
@@ -934,6 +975,10 @@ class PolicyRunner:
             dt = torch.uint8 if (k == "image" and t.dtype == torch.uint8) else torch.float32
             st["obs"][k] = torch.zeros(tuple(t.shape), dtype=dt, device=dev)
             st["pin"][k] = torch.zeros(tuple(t.shape), dtype=dt).pin_memory()
+        # the host fills the pinned buffers through numpy views: torch's CPU copy_ goes parallel above 32 K elements,
+        # and a pool of spinning OpenMP workers is what an env loop under a CPU quota cannot afford (r04: one acting
+        # step in twelve took ~100 ms, the cgroup's throttling period; 0.29 ms median either way)
+        st["pin_np"] = {k: v.numpy() for k, v in st["pin"].items()}
         # one flat buffer holds the step's outputs [action | logprob | stoch | deter | logit]; the carried state the
         # graph READS is the same memory (views of the previous step's outputs): when the caller hands back exactly
         # what the last step returned, nothing has to be copied in (see _load)
@@ -977,9 +1022,8 @@ class PolicyRunner:
             if isinstance(v, torch.Tensor):
                 st["obs"][k].copy_(v, non_blocking=True)
             else:
-                pin = st["pin"][k]
-                pin.copy_(torch.as_tensor(v))
-                st["obs"][k].copy_(pin, non_blocking=True)
+                np.copyto(st["pin_np"][k], np.asarray(v), casting="unsafe")
+                st["obs"][k].copy_(st["pin"][k], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         st["h2d_done"] = ev
@@ -1019,6 +1063,17 @@ class PolicyRunner:
         # (float vs uint8) or shape is another signature, never a silent conversion into the old buffers
         sig = tuple((k, tuple(torch.as_tensor(obs[k]).shape), str(torch.as_tensor(obs[k]).dtype)) for k in sorted(obs))
         key = (n, bool(training), bool(training and self.agent._exploring()), sig)
+        # the graphs hold raw pointers to the weights: those must sit in their optimizer's flat bucket BEFORE a capture
+        # (the buckets are built lazily, by the first update -- and the reference's loop evaluates before it trains,
+        # dreamer.py:534-549), and a graph captured over weights that have moved since (Module.to) is dropped
+        where = self._weights_where()
+        if where != self._weights or not all(ok for _, ok in where):
+            if self._sig:
+                torch.cuda.synchronize()
+                self._sig.clear()
+            for b in self._buckets:
+                b.ensure()
+            self._weights = self._weights_where()
         st = self._sig.get(key)
         if st is None:
             st = self._build(obs, state, training)

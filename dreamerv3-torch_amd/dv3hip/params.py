@@ -45,6 +45,16 @@ class ParamBucket:
                 return True
         return False
 
+    def settled(self) -> bool:
+        """O(1) form of `not _needs_build()` for callers that REPLAY captured launches (hipGraphs hold raw pointers into
+        `flat`): the bucket exists and its first and last parameter still live in it.  Whatever moves parameters moves
+        all of them (Module.to, a rebuilt bucket)."""
+        if self.flat is None:
+            return False
+        base = self.flat.data_ptr()
+        (o0, _), (o1, _) = self._layout[0], self._layout[-1]
+        return self.params[0].data_ptr() == base + 4 * o0 and self.params[-1].data_ptr() == base + 4 * o1
+
     def ensure(self):
         """(Re)flatten if any parameter no longer lives in the bucket (e.g. after Module.to())."""
         if not self._needs_build():

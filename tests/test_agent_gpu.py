@@ -183,6 +183,49 @@ def test_policy_graph_replay_equals_eager(name, n_envs):
         assert torch.allclose(a0, a1, atol=1e-6) and torch.allclose(l0, l1, atol=1e-5)
 
 
+def test_policy_graph_captured_before_the_first_update_follows_the_training():
+    """The reference's loop EVALUATES before it trains (dreamer.py:534-549), so the acting step is captured while the
+    optimizers' flat parameter buckets -- built lazily by the first update -- do not exist yet.  The graph holds raw
+    pointers to the weights: PolicyRunner has to settle the weights into their buckets before it captures, or its
+    replays would act with (and, after the next capture's empty_cache, fault on) the storage the weights have left.
+    A later move of the weights (Module.to) drops the acting graphs; the update's graphs refuse to replay."""
+    import tools
+
+    agent, _ = _load_agent("tiny")
+    obs = _obs(2, True)
+    reseed = lambda: tools.default_rng(agent._config.device, seed=5)  # (the posterior state is a sample)
+    reseed()
+    out0, _ = agent._policy(obs, None, training=False)  # (the very first thing the agent is asked to do)
+    runner = agent._policy_runner
+    assert runner not in (None, False) and runner._buckets and all(b.settled() for b in runner._buckets)
+    where = {k: v.data_ptr() for k, v in agent.named_parameters()}
+    ds = _dataset("tiny")
+    for _ in range(6):  # eager warm-up, serial graphs, pipelined segments: each capture empties the allocator's cache
+        agent._train(next(ds), pipelined=True)
+    agent._finish_updates()
+    torch.cuda.synchronize()
+    assert agent._runner.use_graph and agent._runner._g_wm is not None
+    # (the slow critic is flattened by the first update as well: training reads it, the acting step does not)
+    moved = [k for k, v in agent.named_parameters() if v.data_ptr() != where[k] and "_slow_value." not in k]
+    assert not moved, f"the first update moved weights the acting graph reads: {moved}"
+    reseed()
+    out_g, _ = agent._policy(obs, None, training=False)
+    reseed()
+    out_e, _ = agent._policy_eager(obs, None, training=False)
+    assert len(runner._sig) == 1, "the acting graph was rebuilt"
+    assert torch.allclose(out_g["action"], out_e["action"], atol=1e-6), "the replay acts with stale weights"
+    assert not torch.allclose(out_g["action"], out0["action"], atol=1e-6), "six updates left the actor's mode where it was"
+    # the weights move: the acting graphs are rebuilt over the new storage, the update refuses to replay
+    for prm in agent._task_behavior.actor.parameters():
+        prm.data = prm.data.clone()
+    reseed()
+    out_m, _ = agent._policy(obs, None, training=False)
+    assert all(b.settled() for b in runner._buckets)
+    assert torch.allclose(out_m["action"], out_e["action"], atol=1e-6)
+    with pytest.raises(RuntimeError, match="moved after"):
+        agent._train(next(ds))
+
+
 def test_policy_graph_sees_a_state_the_caller_rewrote():
     """PolicyRunner keeps the carried state where the previous replay left it and skips the copy-in when the caller
     hands back exactly what it was given; a state edited in place (or any other tensors) must be copied in."""

@@ -4,7 +4,9 @@
     python tools/policy_bench.py [--envs 1 4 16]
 
 Prints the host-visible time per call (launch + device + the final D2H of the action): hipGraph replay
-(dv3hip.graph.PolicyRunner, the default of Dreamer._policy) and eager.
+(dv3hip.graph.PolicyRunner, the default of Dreamer._policy) and eager.  Mean and p99 beside the median: under a CPU quota
+(cgroup cpu.max) a host-side torch op that goes OpenMP-parallel makes one step in twelve take the throttling period
+(~100 ms) -- r04 found the acting step's pinned-buffer fill doing that (mean 5 ms at a median of 0.29).
 """
 import argparse
 import os
@@ -37,7 +39,7 @@ class _Logger:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, nargs="+", default=[1, 4, 16])
-    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--reps", type=int, default=1000)
     args = ap.parse_args()
     import dreamer
 
@@ -67,7 +69,8 @@ def main():
                 t0 = time.perf_counter()
                 fn()
                 ts.append(time.perf_counter() - t0)
-            return float(np.median(ts)) * 1e3, float(np.max(ts)) * 1e3
+            ts = np.asarray(ts) * 1e3
+            return float(np.median(ts)), float(ts.mean()), float(np.percentile(ts, 99)), float(ts.max())
 
         def graph_step():
             nonlocal state
@@ -79,10 +82,10 @@ def main():
             out, state = agent._policy_eager(obs, state, training=True)
             return out["action"].cpu()
 
-        g, gmax = med(graph_step)
-        e, emax = med(eager_step)
-        print(f"envs={E:3d}: median {g:6.3f} ms per acting step with hipGraph replay (max {gmax:.2f}), {e:6.3f} ms eager "
-              f"(max {emax:.2f}); incl. H2D of the image and D2H of the action")
+        g, e = med(graph_step), med(eager_step)
+        fmt = lambda r: f"median {r[0]:6.3f} mean {r[1]:6.3f} p99 {r[2]:6.3f} max {r[3]:7.2f} ms"
+        print(f"envs={E:3d}: hipGraph replay {fmt(g)} | eager {fmt(e)}   (per acting step, incl. H2D of the image and D2H "
+              f"of the action; {args.reps} steps)")
 
 
 if __name__ == "__main__":
