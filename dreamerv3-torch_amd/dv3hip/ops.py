@@ -52,6 +52,7 @@ class _Profile:
     def __init__(self):
         self.enabled = False
         self.by_shape = False
+        self.prefix = ""  # put in front of every key (tools/segment_profile.py: the segment of the update being launched)
         self.records = {}  # key -> [launches, flops, bytes, [event pairs]]
 
     def start(self):
@@ -77,7 +78,7 @@ def _call(fn_name: str, *args, key=None, flops=0.0, nbytes=0.0) -> None:
         a.record()
         _lib.check(getattr(lib, fn_name)(*args), fn_name)
         b.record()
-        rec = PROFILE.records.setdefault(key or fn_name, [0, 0.0, 0.0, []])
+        rec = PROFILE.records.setdefault(PROFILE.prefix + (key or fn_name), [0, 0.0, 0.0, []])
         rec[0] += 1
         rec[1] += flops
         rec[2] += nbytes
@@ -224,11 +225,15 @@ def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
 #   1024 x 1536 x 1024 (GRU of the rollout)  64x96 62.9 / 32x64 74.2      2048 x 3072 x 1536 (cfg 3 GRU)  128x64 325 / 32x64 362
 #   2048 x 1024 x 1024 (cfg 3 stacked)        128x64 76.8 / 64x64 84.2    15360 x 255 x 512 (head out)     128x128 76.8 / 64x64 86.9
 #   14336 x 1024 x 512 (head dgrad to stoch)  64x64 281.6 / 128x128 297.6
+#   1024 x 4096 x 1536 (decoder Linear)       128x128 202 / 64x64 236     14336 x 255 x 512 (head out)     128x128 76.7 / 64x64 82.7
+#   1024 x 1024 x 1536 | 4096 (rollout dgrad, encoder Linear dgrad)  64x64 62.3 | 157 / 32x64 65.2 | 164
+#   14336 x 512 x 512 (head layers)           64x64 146.7 / 128x128 150.6     (r04 sweep: profiles/r04_gemm_lane_sweep.txt)
 # All of these tiles run the same K loop (32-wide K tiles, v_mfma_f32_16x16x4_f32 in ascending k): switching among them
 # changes no bit of the result (tests/test_kernels_gpu.py::test_l16_tiles_agree_bit_for_bit), so the lanes schedule still
 # computes exactly what the serial update computes.
 LANE_STREAMS = {}  # stream handle -> compute units of its queue
-_LANE_TILES = {(1024, 1536): 12, (2048, 3072): 16, (2048, 1024): 16, (15360, 255): 15, (14336, 1024): 13}
+_LANE_TILES = {(1024, 1536): 12, (2048, 3072): 16, (2048, 1024): 16, (15360, 255): 15, (14336, 1024): 13,
+               (1024, 4096): 15, (14336, 255): 15, (1024, 1024): 13, (14336, 512): 13}
 
 
 # ---------------------------------------------------------------------------------------------

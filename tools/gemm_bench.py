@@ -95,7 +95,11 @@ def main():
     ap.add_argument("--only", default="", help="substring of the note column")
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands (clock / power check)")
     ap.add_argument("--lane", action="store_true", help="replay on the 128-CU side lane instead of the whole chip")
+    ap.add_argument("--shapes", default="", help='"M,N,K,tA,tB;..." instead of the built-in list')
     args = ap.parse_args()
+    shapes = SHAPES
+    if args.shapes:
+        shapes = [tuple(int(x) for x in sh.split(",")) + ("",) for sh in args.shapes.split(";") if sh]
     global ZEROS, LANE
     ZEROS = args.zeros
     if args.lane:
@@ -104,7 +108,7 @@ def main():
         LANE = engine.Lanes.get(torch.device("cuda", 0)).streams["side"]
     tiles = [int(t) for t in args.tiles.split(",")]
     print(f"{'shape':>22s} {'tA tB':>6s} {'tile':>5s} {'us':>9s} {'TFLOP/s':>8s} {'frac':>6s}  note")
-    for M, N, K, tA, tB, note in SHAPES:
+    for M, N, K, tA, tB, note in shapes:
         if args.only and args.only not in note:
             continue
         for t in tiles:
@@ -114,7 +118,7 @@ def main():
                 us, tf = bench(M, N, K, tA, tB, t, args.reps)
             except Exception:  # the tile does not take this shape / layout
                 continue
-            print(f"{M:6d}x{N:5d}x{K:6d} {tA:3d}{tB:3d} {t:5d} {us:9.1f} {tf:8.1f} {tf / 157.3:6.2f}  {note}")
+            print(f"{M:6d}x{N:5d}x{K:6d} {tA:3d}{tB:3d} {t:5d} {us:9.1f} {tf:8.1f} {tf / 157.3:6.2f}  {note}", flush=True)
 
 
 if __name__ == "__main__":
