@@ -16,7 +16,25 @@ import tools
 to_np = lambda x: x.detach().cpu().numpy()
 
 
+class _Accel:
+    """The graph runners and the batch stager of one Dreamer.  No __dict__ (slots): the checkpoint's optimizer collector
+    (tools.recursively_collect_optim_state_dict, dreamer.py:563-567) walks every attribute that has one, plain attributes
+    first -- through `_runner.wm` it would reach the optimizers under paths the reference does not know
+    ("_runner.wm._model_opt._opt") and a fresh agent cannot resolve (its runner does not exist yet)."""
+
+    __slots__ = ("runner", "stager", "policy_runner")
+
+    def __init__(self):
+        self.runner = self.stager = self.policy_runner = None
+
+
+def _accel_attr(name):
+    return property(lambda self: getattr(self._accel, name), lambda self, v: setattr(self._accel, name, v))
+
+
 class Dreamer(nn.Module):
+    _runner, _stager, _policy_runner = _accel_attr("runner"), _accel_attr("stager"), _accel_attr("policy_runner")
+
     def __init__(self, obs_space, act_space, config, logger, dataset):
         super().__init__()
         self._config = config
@@ -41,7 +59,7 @@ class Dreamer(nn.Module):
             random=lambda: expl.Random(config, act_space),
             plan2explore=lambda: expl.Plan2Explore(config, self._wm, reward),
         )[config.expl_behavior]().to(self._config.device)
-        self._runner, self._stager, self._policy_runner = None, None, None
+        self._accel = _Accel()  # (._runner: graph.UpdateRunner, ._stager: staging.BatchStager, ._policy_runner: graph.PolicyRunner)
         self._macc = {}  # metric group ("wm" / "beh" / "expl") -> device-resident running sums (see _accumulate)
 
     def __call__(self, obs, reset, state=None, training=True):

@@ -226,6 +226,65 @@ def test_policy_graph_captured_before_the_first_update_follows_the_training():
         agent._train(next(ds))
 
 
+def test_resumed_agent_continues_where_the_checkpointed_one_does():
+    """The reference's resume order (dreamer.py:502-506, 534-560): fresh agent -> load_state_dict ->
+    recursively_load_optim_state_dict -> _should_pretrain._once = False -> EVALUATE -> train.  The resumed agent's next
+    updates (pipelined, hipGraph replay) end where the original agent's same updates end, up to the reverse scan's
+    atomic summation order."""
+    import dreamer
+    import tools
+
+    name, n_envs = "tiny", 2
+    cfg = Hh.make_config(name)
+    cfg.pretrain, cfg.log_every, cfg.video_pred_log = 0, 1e9, False
+    batches = [common.make_batch(name, seed=i) for i in range(10)]
+
+    def make():
+        torch.manual_seed(3)
+        ag = dreamer.Dreamer(Hh.obs_space(name), None, cfg, _Logger(), iter(())).to(cfg.device)
+        ag.requires_grad_(False)
+        return ag
+
+    def train(ag, lo, hi):
+        for i in range(lo, hi):
+            ag._train(batches[i], pipelined=True)
+        ag._finish_updates()
+        torch.cuda.synchronize()
+
+    rng = tools.default_rng(cfg.device, seed=17)
+    a = make()
+    train(a, 0, 5)
+    ckpt = {"agent_state_dict": {k: v.detach().clone() for k, v in a.state_dict().items()},
+            "optims_state_dict": tools.recursively_collect_optim_state_dict(a)}
+    # the reference's attribute paths (what its own checkpoints hold), although the runners hold the same optimizers
+    assert set(ckpt["optims_state_dict"]) == {"_wm._model_opt._opt", "_task_behavior._actor_opt._opt",
+                                              "_task_behavior._value_opt._opt"}
+    rng_at = rng.state.clone()
+    train(a, 5, 10)
+    want = {k: v.detach().clone() for k, v in a.state_dict().items()}
+    b = make()
+    b.load_state_dict(ckpt["agent_state_dict"])
+    tools.recursively_load_optim_state_dict(b, ckpt["optims_state_dict"])
+    b._should_pretrain._once = False
+    out, state = b(_obs(n_envs, True), np.ones(n_envs, bool), None, training=False)  # (evaluation comes first)
+    out, state = b(_obs(n_envs, False), np.zeros(n_envs, bool), state, training=False)
+    assert torch.isfinite(out["action"]).all() and b._update_count == 0
+    rng.state.copy_(rng_at)  # (the evaluation drew its posterior samples from the shared Philox stream)
+    train(b, 5, 10)
+    assert b._runner.use_graph and b._runner._g_wm is not None
+    got = b.state_dict()
+    assert set(got) == set(want)
+    for k in want:
+        d = (want[k].double() - got[k].double()).abs().max().item() if want[k].numel() else 0.0
+        assert d <= 3e-4 + 1e-3 * want[k].double().abs().max().item(), (k, d)
+    # and it acts like the original agent after the same updates
+    rng.state.copy_(rng_at)
+    oa, _ = a._policy(_obs(n_envs, True), None, training=False)
+    rng.state.copy_(rng_at)
+    ob, _ = b._policy(_obs(n_envs, True), None, training=False)
+    assert torch.allclose(oa["action"], ob["action"], atol=5e-3)
+
+
 def test_policy_graph_sees_a_state_the_caller_rewrote():
     """PolicyRunner keeps the carried state where the previous replay left it and skips the copy-in when the caller
     hands back exactly what it was given; a state edited in place (or any other tensors) must be copied in."""
