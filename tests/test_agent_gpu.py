@@ -226,7 +226,7 @@ def test_policy_graph_captured_before_the_first_update_follows_the_training():
         agent._train(next(ds))
 
 
-def test_resumed_agent_continues_where_the_checkpointed_one_does():
+def test_resumed_agent_continues_where_the_checkpointed_one_does(tmp_path):
     """The reference's resume order (dreamer.py:502-506, 534-560): fresh agent -> load_state_dict ->
     recursively_load_optim_state_dict -> _should_pretrain._once = False -> EVALUATE -> train.  The resumed agent's next
     updates (pipelined, hipGraph replay) end where the original agent's same updates end, up to the reverse scan's
@@ -259,6 +259,8 @@ def test_resumed_agent_continues_where_the_checkpointed_one_does():
     # the reference's attribute paths (what its own checkpoints hold), although the runners hold the same optimizers
     assert set(ckpt["optims_state_dict"]) == {"_wm._model_opt._opt", "_task_behavior._actor_opt._opt",
                                               "_task_behavior._value_opt._opt"}
+    torch.save(ckpt, tmp_path / "latest.pt")  # (dreamer.py:563-567 writes it, :503 reads it back)
+    ckpt = torch.load(tmp_path / "latest.pt")
     rng_at = rng.state.clone()
     train(a, 5, 10)
     want = {k: v.detach().clone() for k, v in a.state_dict().items()}
