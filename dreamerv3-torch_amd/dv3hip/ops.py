@@ -233,7 +233,8 @@ def pick_gemm_tile(M: int, N: int, wgrad: bool = False, K: int = 0) -> int:
 # computes exactly what the serial update computes.
 LANE_STREAMS = {}  # stream handle -> compute units of its queue
 _LANE_TILES = {(1024, 1536): 12, (2048, 3072): 16, (2048, 1024): 16, (15360, 255): 15, (14336, 1024): 13,
-               (1024, 4096): 15, (14336, 255): 15, (1024, 1024): 13, (14336, 512): 13}
+               (1024, 4096): 15, (14336, 255): 15, (1024, 1024): 13, (14336, 512): 13,
+               (2048, 512): 13, (28672, 512): 13, (28672, 255): 13}  # (cfg 3: profiles/r04_gemm_lane_sweep_cfg3.txt)
 
 
 # ---------------------------------------------------------------------------------------------
