@@ -62,6 +62,7 @@ class Dreamer(nn.Module):
         self._accel = _Accel()  # (._runner: graph.UpdateRunner, ._stager: staging.BatchStager, ._policy_runner: graph.PolicyRunner)
         self._macc = {}  # metric group ("wm" / "beh" / "expl") -> device-resident running sums (see _accumulate)
 
+    @tools.on_config_device
     def __call__(self, obs, reset, state=None, training=True):
         step = self._step
         if training:
@@ -89,6 +90,7 @@ class Dreamer(nn.Module):
                 self._logger.step = self._config.action_repeat * self._step
         return policy_output, state
 
+    @tools.on_config_device
     def _policy(self, obs, state, training, noise=None):
         """Acting step.  With config.hip_graph (default) the launch sequence is replayed from a hipGraph per
         (number of envs, training) signature (dv3hip.graph.PolicyRunner); injected noise (tests) takes the eager path."""
@@ -141,6 +143,7 @@ class Dreamer(nn.Module):
             raise NotImplementedError("actor dist onehot_gumble")
         return {"action": action, "logprob": logprob}, (latent, action)
 
+    @tools.on_config_device
     def _train(self, data, pipelined=False):
         """dreamer.py:192-208.  One update = WorldModel._train + ImagBehavior._train on the updated world model; the
         launch sequence is replayed from hipGraphs (dv3hip.graph.UpdateRunner, ~1130 launches per update) once it has
@@ -178,6 +181,7 @@ class Dreamer(nn.Module):
         self._finish_updates()
         return super().state_dict(*args, **kwargs)
 
+    @tools.on_config_device
     def _finish_updates(self):
         """End of a run of pipelined updates: issue the behaviour phase that is still pending."""
         r = self._runner

@@ -163,6 +163,7 @@ class WorldModel(nn.Module):
         return out
 
     # ------------------------------------------------------------------------------------------
+    @tools.on_config_device
     def _train(self, data, noise=None):
         """One world-model update (models.py:108-171) -> (post, context, metrics).  `noise` (tests): dict(q_prior,
         q_post) of [T,B,S,D] Exp(1) draws.  A driver written against the reference's classes (its dreamer.py:192-199)
@@ -392,6 +393,7 @@ class WorldModel(nn.Module):
         rng.commit()
         self._pending = (post, context, metrics, loss[0])
 
+    @tools.on_config_device
     def video_pred(self, data, noise=None):
         """models.py:192-213 (forward-only open-loop prediction for logging).  noise (tests): dict of Exp(1)
         draws q_prior, q_post [5,Bv,S,D] and q_open [T-5,Bv,S,D]; default = the Philox stream."""
@@ -624,6 +626,7 @@ class ImagBehavior(nn.Module):
                         actor=actor_eng, idx=idx)
 
     # ------------------------------------------------------------------------------------------
+    @tools.on_config_device
     def _train(self, start, objective=None, noise=None):
         """One actor + critic update (models.py:327-446).  `objective(feat, state, action) -> reward [H,N,1]`:
         * None, or the world model's reward head on the imagined states (what dreamer.py:196-199 passes; recognised on

@@ -291,12 +291,21 @@ _DEFAULT_RNG = {}
 _RNG_OVERRIDE = {}
 
 
+def _rng_key(device) -> str:
+    """One key per physical device: "cuda" (config.device without an index) and the "cuda:0" a tensor reports are the
+    same Philox stream."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return str(d)
+
+
 class rng_override:
     """`with tools.rng_override(device, stream):` -- samplers that ask for the default stream of `device` get `stream`
     (dv3hip.graph.UpdateRunner captures each phase of the pipelined update against a Philox state of its own)."""
 
     def __init__(self, device, stream):
-        self._key, self._stream = str(torch.device(device)), stream
+        self._key, self._stream = _rng_key(device), stream
 
     def __enter__(self):
         self._prev = _RNG_OVERRIDE.get(self._key)
@@ -311,9 +320,26 @@ class rng_override:
         return False
 
 
+def on_config_device(fn):
+    """Method decorator: run with `self._config.device` as the CURRENT device.  The kernels are launched on
+    torch.cuda.current_stream() -- the current device's -- so an agent built on "cuda:1" in a process whose current device
+    is 0 (the reference's `--device cuda:1`; torch's own ops switch per call) needs the switch at its entry points."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        dev = torch.device(self._config.device)
+        if dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+
+    return wrapper
+
+
 def default_rng(device, seed=None):
     """Device-resident Philox stream shared by every sampler that gets no injected noise."""
-    key = str(torch.device(device))
+    key = _rng_key(device)
     if seed is None and key in _RNG_OVERRIDE:
         return _RNG_OVERRIDE[key]
     if key not in _DEFAULT_RNG:
