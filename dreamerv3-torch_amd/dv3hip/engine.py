@@ -135,6 +135,7 @@ class Lanes:
         that is still alive as a module global would otherwise be torn down AFTER its streams (segfault at exit)."""
         import weakref
 
+        cls._closers = [r for r in cls._closers if r() is not None]  # (runners come and go: keep only the living)
         cls._closers.append(weakref.WeakMethod(bound_method))
 
     def _destroy(self):
