@@ -287,6 +287,35 @@ def test_resumed_agent_continues_where_the_checkpointed_one_does(tmp_path):
     assert torch.allclose(oa["action"], ob["action"], atol=5e-3)
 
 
+def test_policy_takes_the_observation_dict_tools_simulate_builds():
+    """tools.simulate (tools.py:163-166) stacks EVERY key of the env's observation that does not start with "log_": beside
+    image / is_first / is_terminal that is `reward`, `is_last`, `discount` and the proprioceptive vectors the vision
+    config's encoder ignores -- float64 from dm_control.  The replayed acting step takes them like the eager one."""
+    import tools
+
+    agent, _ = _load_agent("tiny")
+    rs = np.random.RandomState(5)
+    n = 3
+
+    def obs(first):
+        o = _obs(n, first)
+        o.update(reward=rs.randn(n), is_last=np.zeros(n, bool), discount=np.ones(n), orientations=rs.randn(n, 14),
+                 velocity=rs.randn(n, 9).astype(np.float64), height=rs.randn(n))
+        return o
+
+    o0, o1 = obs(True), obs(False)
+    res = {}
+    for mode in ("eager", "graph"):
+        tools.default_rng(agent._config.device, seed=8)
+        fn = agent._policy_eager if mode == "eager" else agent._policy
+        out, state = fn(o0, None, True)
+        out, state = fn(o1, state, True)
+        res[mode] = (out["action"].clone(), state[0]["stoch"].clone())
+    assert agent._policy_runner not in (None, False), "the acting step fell back to eager launches"
+    assert torch.equal(res["eager"][1], res["graph"][1])
+    assert torch.allclose(res["eager"][0], res["graph"][0], atol=1e-6)
+
+
 def test_policy_graph_sees_a_state_the_caller_rewrote():
     """PolicyRunner keeps the carried state where the previous replay left it and skips the copy-in when the caller
     hands back exactly what it was given; a state edited in place (or any other tensors) must be copied in."""
