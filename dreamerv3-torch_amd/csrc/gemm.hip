@@ -108,6 +108,70 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmParams p) {
 
 
 // ------------------------------------------------------------------------------------------------
+// Grouped weight gradients: up to kMaxGroup independent products C_g (+)= A_g^T B_g (A_g [K_g][M_g], B_g [K_g][N_g], both
+// pixel / row major as the backward pass holds them) in ONE grid.  The world model's seventeen K = B*T = 1024 weight
+// gradients have 64 ... 1024 output tiles of 64 x 64 each: launched one by one they need split-K with atomics to cover
+// the chip and still pay a launch boundary per 20-60 us of work (0.56 ms per update on a 128-CU lane at 32 % MFMA-busy);
+// as one grid every tile walks its full K range (no atomics: the sums are reproducible) and the lane stays full.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxGroup = 48;
+
+struct GroupItem {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int tiles_n, tile0, accumulate;
+};
+
+struct GroupParams {
+  int n, total;
+  GroupItem it[kMaxGroup];
+};
+
+template <class TS>
+__global__ __launch_bounds__(kThreads) void gemm_tn_grouped_kernel(GroupParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[TS::lds_floats];
+  using ATile = DenseTile<TS::BM, TS::BK, false>;
+  using BTile = DenseTile<TS::BN, TS::BK, false>;
+  const int id = xcd_remap(blockIdx.x, p.total);
+  int g = 0;
+  while (g + 1 < p.n && id >= p.it[g + 1].tile0) ++g;  // (uniform over the workgroup: scalar loads of the kernel arguments)
+  const GroupItem it = p.it[g];
+  const int wg = id - it.tile0;
+  const int m0 = (wg / it.tiles_n) * TS::BM;
+  const int n0 = (wg % it.tiles_n) * TS::BN;
+  DenseOperand<false> aop{it.A, nullptr, it.lda, 0, it.M, it.K, it.K, true};
+  DenseOperand<false> bop{it.B, nullptr, it.ldb, 0, it.N, it.K, it.K, true};
+  f32x16 acc[TS::TM][TS::TN];
+  bool owner;
+  mfma_mainloop<TS, ATile, BTile>(aop, bop, m0, n0, 0, it.K, lds, acc, owner);
+  if (!owner) return;
+  const int tid = threadIdx.x;
+  const int wave = (tid >> 6) % (TS::WM * TS::WN), lane = tid & 63;
+  const int wm = wave / TS::WN, wn = wave % TS::WN;
+  const int col_l = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < TS::TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TS::TN; ++b) {
+      const int n = n0 + (wn * TS::TN + b) * 32 + col_l;
+      if (n >= it.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TS::TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < it.M) {
+          float* c = it.C + (long)m * it.ldc + n;
+          *c = it.accumulate ? (*c + acc[a][b][r]) : acc[a][b][r];
+        }
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // Skinny GEMM for the observe scan: M <= 32 rows (the replay batch) against a full weight matrix.
 // Weight-streaming bound (every step re-reads ~11 MB of weights from L2 / Infinity Cache), so the
 // shape is one 16-column output tile per workgroup with K split over its 4 waves (LDS reduce):
@@ -1355,5 +1419,32 @@ extern "C" int dv3_gemm_split_f32(int M, int N, int K, const float* A, long lda,
   p.C2 = C2; p.ldc2 = ldc2; p.nsplit = nsplit; p.accumulate2 = accumulate2 ? 1 : 0;
   if (!l16_ok(p, 0, 1)) return DV3_ERR_ARG;
   launch_l16(p, 0, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dv3_gemm_tn_grouped_f32(int n, const float* const* A, const long* lda, const float* const* B,
+                                       const long* ldb, float* const* C, const long* ldc, const int* M, const int* N,
+                                       const int* K, const int* accumulate, void* stream) {
+  if (n <= 0) return 0;
+  if (n > kMaxGroup || !A || !lda || !B || !ldb || !C || !ldc || !M || !N || !K || !accumulate) return DV3_ERR_ARG;
+  using TS = TileShape<2, 2, 1, 1, 32>;  // 64 x 64 output tiles, BK 32
+  GroupParams p{};
+  int total = 0;
+  for (int g = 0; g < n; ++g) {
+    if (M[g] <= 0 || N[g] <= 0 || K[g] <= 0 || !A[g] || !B[g] || !C[g]) return DV3_ERR_ARG;
+    if (lda[g] < M[g] || ldb[g] < N[g] || ldc[g] < N[g] || lda[g] > 0x7fffffffL || ldb[g] > 0x7fffffffL ||
+        ldc[g] > 0x7fffffffL)
+      return DV3_ERR_ARG;
+    GroupItem& it = p.it[p.n++];
+    it.A = A[g]; it.B = B[g]; it.C = C[g];
+    it.M = M[g]; it.N = N[g]; it.K = K[g];
+    it.lda = (int)lda[g]; it.ldb = (int)ldb[g]; it.ldc = (int)ldc[g];
+    it.tiles_n = (N[g] + TS::BN - 1) / TS::BN;
+    it.tile0 = total;
+    it.accumulate = accumulate[g] ? 1 : 0;
+    total += ((M[g] + TS::BM - 1) / TS::BM) * it.tiles_n;
+  }
+  p.total = total;
+  hipLaunchKernelGGL((gemm_tn_grouped_kernel<TS>), dim3(total), dim3(kThreads), 0, (hipStream_t)stream, p);
   return (int)hipGetLastError();
 }

@@ -29,6 +29,9 @@ _CTYPES = {
     "unsigned int*": ctypes.c_void_p,
     "const unsigned int*": ctypes.c_void_p,
     "void*": ctypes.c_void_p,
+    "const float* const*": ctypes.c_void_p,  # (host arrays of the grouped entry points)
+    "float* const*": ctypes.c_void_p,
+    "const long*": ctypes.c_void_p,
     "unsigned long long": ctypes.c_ulonglong,
     "long": ctypes.c_long,
     "int": ctypes.c_int,

@@ -185,6 +185,14 @@ class Cuts:
     def active() -> bool:
         return Cuts.recorder is not None
 
+    @staticmethod
+    def wants(label: str) -> bool:
+        """Whether mark(label) would cut (optional "@" labels cut only when the recorder lists them)."""
+        rec = Cuts.recorder
+        if rec is None:
+            return False
+        return "@" not in label or label in getattr(rec, "optional", ())
+
 
 class SideStream:
     """Work that is off the critical path (weight gradients) beside a latency-bound chain of few-row launches.
@@ -263,35 +271,42 @@ class SideStream:
         backward), so in lanes mode the callables simply run in line."""
         if not fns:
             return
+        # (the deferred callables are weight gradients: nothing reads their outputs before the optimizer and their inputs
+        # stay put until they have run, so the small dense ones among them go out as ONE grid: ops.gemm_group)
         if self._mode == "cuts":
             if chain:
                 Cuts.mark("wm.defer")
                 self._cut = True
-            for i, f in enumerate(fns):
-                if chain and i:
-                    Cuts.mark(f"wm.defer@{i}")  # (optional cut: the schedule may share the deferred launches between lanes)
-                f()
+            with ops.gemm_group() as grp:
+                for i, f in enumerate(fns):
+                    if chain and i and Cuts.wants(f"wm.defer@{i}"):
+                        grp.flush()
+                        Cuts.mark(f"wm.defer@{i}")  # (optional cut: the schedule may share the deferred launches between lanes)
+                    f()
             return
         if self._mode == "off" or (self._mode == "lanes" and not chain):
-            for f in fns:
-                f()
+            self._run_all(fns)
             return
         if self._mode == "plain":
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                for f in fns:
-                    f()
+                self._run_all(fns)
             self._forked.append(self.stream)
             return
         self._on_lane("side", fns)
+
+    @staticmethod
+    def _run_all(fns):
+        with ops.gemm_group():
+            for f in fns:
+                f()
 
     def _on_lane(self, lane, fns):
         rec = SideStream.recorder
         if rec is not None:
             rec.cut(lane)
             self._cut = True
-            for f in fns:
-                f()
+            self._run_all(fns)
             return
         ln = Lanes.get(self.device)
         if self._main is None:
@@ -299,8 +314,7 @@ class SideStream:
         s = ln.streams[lane]
         s.wait_stream(self._main)
         with torch.cuda.stream(s):
-            for f in fns:
-                f()
+            self._run_all(fns)
         self._forked.append(s)
 
     class _Chain:
@@ -913,12 +927,14 @@ class RSSMEngine:
                                       gd[t - 1] if t > 0 else None, dstoch0, ddeter0)
             # ---- the encoder-output gradient (critical path) and, beside it, the batched weight gradients
         side.join()  # the init-state backward below adds into the same prior-head gradients
-        if prior_inline:
-            _prior_wgrads()
         ops.gemm(v2(dx3pre, Hd), P.obs_out.W[:, De:], v2(dembed, E), transB=False)
         dpl = v2(dpl_out, SD)
 
         def _scan_wgrads():
+            # (one grid for these products, ops.gemm_group in SideStream.run; the init-state backward's additions into the
+            # prior head's gradients overlap the prior's own and go out as a second one behind it)
+            if prior_inline:
+                _prior_wgrads()
             lin_wgrad(P.obs.W, dpl, v2(x3, Hd))
             ops.colsum(dpl, _g(P.obs.b), accumulate=True)
             lin_wgrad(P.obs_out.W, v2(dx3pre, Hd), v2(deter, De), v2(self._embed, E))

@@ -112,6 +112,8 @@ def kernel_symbol(key: str) -> str:
         return "void dv3::gemm_l16_kernel<32, 64, 1, 1>(dv3::GemmParams)"
     if key.startswith("gemm_kernel<direct32x64+sample"):
         return "void dv3::gemm_direct_kernel<true, 4, 2, 1, 0>(dv3::GemmParams)"
+    if key.startswith("gemm_tn_grouped_kernel"):
+        return "void dv3::gemm_tn_grouped_kernel<dv3::TileShape<2, 2, 1, 1, 32, 1> >(dv3::GroupParams)"
     m = re.match(r"gemm_kernel<([^,]+),tA=(\d),tB=(\d)>", key)
     if m:
         tile = {v: k for k, v in _TILE_NAMES.items()}[m.group(1)]
@@ -237,6 +239,76 @@ _LANE_TILES = {(1024, 1536): 12, (2048, 3072): 16, (2048, 1024): 16, (15360, 255
                (2048, 512): 13, (28672, 512): 13, (28672, 255): 13}  # (cfg 3: profiles/r04_gemm_lane_sweep_cfg3.txt)
 
 
+class gemm_group:
+    """`with ops.gemm_group():` -- the weight gradients C += A^T B issued inside (ops.gemm(transA=True, transB=False,
+    accumulate=True) with a reduction of at most `max_k` rows) are collected and launched as ONE grid at exit
+    (dv3_gemm_tn_grouped_f32): the world model's K = B*T = 1024 weight gradients are 64 ... 1024 output tiles each, one
+    by one they need split-K with atomics to cover the chip and pay a launch boundary per 20-60 us.  The caller
+    guarantees what deferring a launch to the end of the block needs: nothing inside the block reads these C or
+    overwrites these A / B.  Two products into overlapping C (never issued by the engines; checked) end the current
+    grid first.  Longer reductions (the behaviour's 14 k-row products) are launched as before: they need split-K."""
+
+    current = None
+    MAX = 48
+
+    def __init__(self, max_k: int = 2048, enabled: bool = True):
+        self.max_k, self.enabled = max_k, enabled
+        self.items, self.stream = [], None
+
+    def __enter__(self):
+        self._prev = gemm_group.current
+        gemm_group.current = self if self.enabled else None
+        return self
+
+    def __exit__(self, et, ev, tb):
+        gemm_group.current = self._prev
+        if et is None:
+            self.flush()
+        return False
+
+    def takes(self, M, N, K) -> bool:
+        return K <= self.max_k and M > 32 and N > 32
+
+    def add(self, A, lda, B, ldb, C, ldc, M, N, K, s):
+        if self.stream is not None and s != self.stream:
+            self.flush()
+        lo = C.data_ptr()
+        if len(self.items) >= self.MAX or any(self._overlap(lo, ldc, M, N, it[4], it[5], it[6], it[7]) for it in self.items):
+            self.flush()
+        self.stream = s
+        self.items.append((A.data_ptr(), lda, B.data_ptr(), ldb, lo, ldc, M, N, K))
+
+    @staticmethod
+    def _overlap(p1, ld1, M1, N1, p2, ld2, M2, N2) -> bool:
+        """Do two row-strided float matrices share an element?  Column slices of one weight gradient ([:, :k1] and
+        [:, k1:] of the same rows: the two K-segments of a Linear over a concatenation) interleave in memory without
+        overlapping: with equal row pitch they are rectangles on one grid."""
+        if p1 > p2:
+            p1, ld1, M1, N1, p2, ld2, M2, N2 = p2, ld2, M2, N2, p1, ld1, M1, N1
+        if p2 >= p1 + 4 * ((M1 - 1) * ld1 + N1):
+            return False
+        d = (p2 - p1) // 4
+        r, c = d // ld1, d % ld1
+        if ld1 == ld2 and (p2 - p1) % 4 == 0 and N1 <= ld1 and c + N2 <= ld1:
+            return r < M1 and c < N1  # (rectangle 2 starts at (r, c) >= (0, 0) of rectangle 1's grid)
+        return True
+
+    def flush(self):
+        items, self.items = self.items, []
+        if not items:
+            return
+        import ctypes
+
+        n = len(items)
+        col = lambda j, ty: (ty * n)(*[it[j] for it in items])
+        flops = sum(2.0 * it[6] * it[7] * it[8] for it in items)
+        _call("dv3_gemm_tn_grouped_f32", n, col(0, ctypes.c_void_p), col(1, ctypes.c_long), col(2, ctypes.c_void_p),
+              col(3, ctypes.c_long), col(4, ctypes.c_void_p), col(5, ctypes.c_long), col(6, ctypes.c_int),
+              col(7, ctypes.c_int), col(8, ctypes.c_int), (ctypes.c_int * n)(*([1] * n)), self.stream,
+              key="gemm_tn_grouped_kernel<64x64x32>" + (f"[{n} products]" if PROFILE.by_shape else ""), flops=flops,
+              nbytes=sum(4.0 * (it[8] * (it[6] + it[7]) + it[6] * it[7]) for it in items))
+
+
 # ---------------------------------------------------------------------------------------------
 def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=False, tile=-1):
     """C (+)= [A|A2] @ op(B) + bias.   op(B)[K,N]: transB -> B is [N,K]; else B is [K,N].
@@ -268,6 +340,11 @@ def gemm(A, B, C, *, transA=False, transB=True, A2=None, bias=None, accumulate=F
         if bias.numel() != N:
             raise ValueError("bias size mismatch")
     s = _stream()
+    grp = gemm_group.current
+    if (grp is not None and tile < 0 and transA and not transB and A2 is None and bias is None and accumulate is True
+            and grp.takes(M, N, K)):
+        grp.add(A, lda, B, ldb, C, ldc, M, N, K, s)
+        return C
     if A2 is not None and (K1 % (64 if tile in (5, 6, 8) else 32)) != 0:
         # segment edge not on a K-tile boundary: two passes, the second accumulating
         Bv1 = B[:, :K1] if transB else B[:K1]

@@ -364,10 +364,11 @@ class WorldModel(nn.Module):
             d_mlp.copy_(de[:, Ec:])
         else:
             d_cnn = d_mlp = de
-        if cnn_eng is not None:
-            cnn_eng.backward(d_cnn)
-        if mlp_eng is not None:
-            mlp_eng.backward(self._enc_in, None, slice(0, TB), wgrad=True, dh=d_mlp)
+        with ops.gemm_group():  # (the encoder's dense weight gradients as one grid: their operands stay put until the join)
+            if cnn_eng is not None:
+                cnn_eng.backward(d_cnn)
+            if mlp_eng is not None:
+                mlp_eng.backward(self._enc_in, None, slice(0, TB), wgrad=True, dh=d_mlp)
         side.join()
 
         # ---- scalar loss + optimizer

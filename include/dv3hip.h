@@ -63,6 +63,16 @@ int dv3_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, lo
 int dv3_gemm_split_f32(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                        int accumulate, float* C2, long ldc2, int nsplit, int accumulate2, void* stream);
 
+/* n <= 48 independent weight gradients C_g (+)= A_g^T B_g in ONE grid: A_g [K_g, M_g] (row stride lda[g]), B_g
+ * [K_g, N_g] (ldb[g]), C_g [M_g, N_g] (ldc[g]); 64 x 64 output tiles, every tile walks its whole K range (no split-K, no
+ * atomics: reproducible sums).  The ARRAYS are host memory (n entries each), the pointers inside A / B / C device
+ * memory.  The C_g must not overlap.  Replaces the per-parameter `.grad` accumulation of loss.backward() for the
+ * nn.Linear weights of one backward pass (tools.py:765; networks.py:657-681 MLP layers, :195-233 RSSM layers) where the
+ * reduction is the replay batch (K = B*T rows): seventeen launches of 20-60 us become one. */
+int dv3_gemm_tn_grouped_f32(int n, const float* const* A, const long* lda, const float* const* B, const long* ldb,
+                            float* const* C, const long* ldc, const int* M, const int* N, const int* K,
+                            const int* accumulate, void* stream);
+
 /* dv3_gemm_f32 (transA=0, transB=1, register-direct kernel) with the one-hot categorical sampling of its output fused
  * into the epilogue: C [M,N] = the logits of N/32 groups of 32 classes per row (N % 64 == 0), sampled exactly as
  * dv3_onehot_sample_fwd_ex would (same noise layout [M*N/32, 32], same Philox counters).  Replaces

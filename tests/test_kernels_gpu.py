@@ -183,6 +183,78 @@ def test_gemm_picks_lane_tiles_on_a_cu_masked_stream(ops):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_grouped_weight_gradients_equal_the_single_launches(ops):
+    """ops.gemm_group (dv3_gemm_tn_grouped_f32): C_g += A_g^T B_g for a mixed bag of shapes in one grid -- ragged edges,
+    row strides wider than the matrix, non-zero C to accumulate into -- against an fp64 product; reproducible (no
+    atomics: two runs agree bit for bit); products the group does not take (long reductions, few rows) are launched as
+    before; overlapping outputs and more than 48 products end the current grid instead of racing."""
+    g = torch.Generator().manual_seed(11)
+    shapes = [(512, 512, 1024), (512, 1024, 1024), (1536, 512, 1024), (255, 512, 1024), (100, 70, 96), (64, 64, 37),
+              (4096, 512, 1024), (33, 1030, 1000)]
+
+    def operands():
+        ops_ = []
+        for M, N, K in shapes:
+            a = dev(torch.randn(K, M + 8, generator=g))[:, :M]   # (row stride wider than the matrix)
+            b = dev(torch.randn(K, N + 4, generator=g))[:, :N]
+            c = dev(torch.randn(M, N + 12, generator=g))[:, :N]
+            ops_.append((a, b, c))
+        return ops_
+
+    trip = operands()
+    want = [(c.double() + a.double().t() @ b.double()) for a, b, c in trip]
+    outs = []
+    for rep in range(2):
+        cs = [c.clone() for _, _, c in trip]
+        cs = [dev(torch.zeros(c.shape[0], c.shape[1] + 12))[:, :c.shape[1]].copy_(c) for c in cs]
+        ops.PROFILE.start()
+        ops.PROFILE.by_shape = False
+        with ops.gemm_group():
+            for (a, b, _), c in zip(trip, cs):
+                ops.gemm(a, b, c, transA=True, transB=False, accumulate=True)
+        keys = ops.PROFILE.stop()
+        assert list(keys) == ["gemm_tn_grouped_kernel<64x64x32>"] and keys["gemm_tn_grouped_kernel<64x64x32>"]["launches"] == 1
+        outs.append(cs)
+    for (M, N, K), w, c0, c1 in zip(shapes, want, outs[0], outs[1]):
+        err = float((c0.double() - w).abs().max())
+        assert err <= 2e-5 * (1.0 + float(w.abs().max())), ((M, N, K), err)
+        assert torch.equal(c0, c1), ("not reproducible", (M, N, K))
+    # not taken: a 14 k-row reduction, a few-row output; both still computed
+    a, b = dev(torch.randn(14336, 512, generator=g)), dev(torch.randn(14336, 256, generator=g))
+    c = torch.zeros(512, 256, device="cuda")
+    a2, b2 = dev(torch.randn(64, 16, generator=g)), dev(torch.randn(64, 48, generator=g))
+    c2 = torch.zeros(16, 48, device="cuda")
+    ops.PROFILE.start()
+    with ops.gemm_group():
+        ops.gemm(a, b, c, transA=True, transB=False, accumulate=True)
+        ops.gemm(a2, b2, c2, transA=True, transB=False, accumulate=True)
+    assert not any(k.startswith("gemm_tn_grouped") for k in ops.PROFILE.stop())
+    assert float((c.double() - a.double().t() @ b.double()).abs().max()) <= 2e-2
+    assert float((c2.double() - a2.double().t() @ b2.double()).abs().max()) <= 1e-4
+    # overlapping outputs: the second product accumulates on top of the first one's result (two grids, in order)
+    a, b = dev(torch.randn(256, 128, generator=g)), dev(torch.randn(256, 192, generator=g))
+    c = torch.zeros(128, 192, device="cuda")
+    ops.PROFILE.start()
+    with ops.gemm_group():
+        ops.gemm(a, b, c, transA=True, transB=False, accumulate=True)
+        ops.gemm(a[:, :64], b, c[:64], transA=True, transB=False, accumulate=True)
+    k = ops.PROFILE.stop()
+    assert k["gemm_tn_grouped_kernel<64x64x32>"]["launches"] == 2
+    w = a.double().t() @ b.double()
+    w[:64] += a[:, :64].double().t() @ b.double()
+    assert float((c.double() - w).abs().max()) <= 1e-3
+    # more than 48 products
+    cs = [torch.zeros(64, 64, device="cuda") for _ in range(50)]
+    a, b = dev(torch.randn(128, 64, generator=g)), dev(torch.randn(128, 64, generator=g))
+    ops.PROFILE.start()
+    with ops.gemm_group():
+        for c in cs:
+            ops.gemm(a, b, c, transA=True, transB=False, accumulate=True)
+    assert ops.PROFILE.stop()["gemm_tn_grouped_kernel<64x64x32>"]["launches"] == 2
+    w = (a.double().t() @ b.double())
+    assert all(float((c.double() - w).abs().max()) <= 1e-4 for c in cs)
+
+
 @pytest.mark.parametrize("M", [33, 50, 64, 100, 128])
 @pytest.mark.parametrize("transB", [True, False])
 @pytest.mark.parametrize("acc", [False, True, "atomic"])
