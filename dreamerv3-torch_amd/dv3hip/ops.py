@@ -267,7 +267,7 @@ class gemm_group:
         return False
 
     def takes(self, M, N, K) -> bool:
-        return K <= self.max_k and M > 32 and N > 32
+        return 32 <= K <= self.max_k and M > 32 and N > 32  # (a K = 1 outer product -- the init state's -- is a launch of its own)
 
     def add(self, A, lda, B, ldb, C, ldc, M, N, K, s):
         if self.stream is not None and s != self.stream:
