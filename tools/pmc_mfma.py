@@ -10,7 +10,8 @@ two-update pipeline in "lanes" mode: EVERY kernel is dispatched by a queue that 
 (512 SIMDs), so its busy share is taken over 512.  `bench.py --plain --serial` runs one update after the other on the
 whole chip, except the reverse observe scan (scan_* kernels) and the weight gradients deferred beside it (conv_wgrad*,
 the decoder's / heads' gemm_direct_tn launches), which run on 128-CU lanes: for those the JSON carries both figures
-(`mfma_util` over the --simds count, `mfma_util_128cu` over 512) and `lane_kernel: true`.
+(`mfma_util` over the --simds count, `mfma_util_128cu` over 512) and `lane_kernel: true`.  gemm_tn_grouped_kernel is a mix there:
+of its two grids per update the deferred cluster runs on a lane, the scan's on the whole chip (not flagged).
 
 Per kernel (averages per launch):
   mfma_util   = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024)   -- matrix-pipe busy cycles summed over the
