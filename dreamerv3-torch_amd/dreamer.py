@@ -146,7 +146,7 @@ class Dreamer(nn.Module):
     @tools.on_config_device
     def _train(self, data, pipelined=False):
         """dreamer.py:192-208.  One update = WorldModel._train + ImagBehavior._train on the updated world model; the
-        launch sequence is replayed from hipGraphs (dv3hip.graph.UpdateRunner, ~1130 launches per update) once it has
+        launch sequence is replayed from hipGraphs (dv3hip.graph.UpdateRunner, ~1110 launches per update) once it has
         been captured, with the host batch staged through pinned buffers (dv3hip.staging.BatchStager).  Metrics stay
         on the device: one running sum per key, read back once per log interval (see _flush_metrics).
         pipelined (the update loop of __call__): the behaviour phase of this update may still be pending when the call

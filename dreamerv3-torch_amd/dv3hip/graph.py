@@ -1,6 +1,6 @@
 """hipGraph replay of the training update and of the acting step.
 
-One update is ~1130 short kernel launches (two sequential scans of small GEMMs); launched eagerly
+One update is ~1110 short kernel launches (two sequential scans of small GEMMs); launched eagerly
 from Python it is host-bound.  The launch sequence is static (fixed shapes, no host reads, RNG and
 Adam step counters live in device memory), so it is captured once into HIP graphs and replayed:
 MI355X-native replacement for the reference's (inert) torch.compile switch (dreamer.py:75-79).
