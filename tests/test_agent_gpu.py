@@ -316,6 +316,65 @@ def test_policy_takes_the_observation_dict_tools_simulate_builds():
     assert torch.allclose(res["eager"][0], res["graph"][0], atol=1e-6)
 
 
+def test_agent_lifecycle_replayed_equals_eager():
+    """One agent driven through the interleavings a training run produces -- evaluate, train (three, two, one update per
+    call), act with another number of envs, video_pred, checkpoint into the live agent, evaluate again -- once with hipGraph
+    replay + the two-update pipeline (the defaults) and once with every launch eager and serial (`hip_graph: False`): the
+    two runs end in the same Philox position and, up to the reverse scan's atomic summation order, the same weights."""
+    import dreamer
+    import tools
+
+    name = "tiny"
+    res = []
+    for replay in (True, False):
+        cfg = Hh.make_config(name)
+        cfg.pretrain, cfg.log_every, cfg.video_pred_log = 0, 1e9, False
+        cfg.hip_graph, cfg.pipeline_updates = replay, replay
+        torch.manual_seed(1)
+        agent = dreamer.Dreamer(Hh.obs_space(name), None, cfg, _Logger(), _dataset(name)).to(cfg.device)
+        agent.requires_grad_(False)
+        rng = tools.default_rng(cfg.device, seed=23)
+        per_call = [3, 2, 1, 2]
+        agent._should_train = lambda step: per_call.pop(0) if per_call else 0
+        agent._should_pretrain._once = False
+        acts = []
+
+        def evaluate(n):
+            out, st = agent(_obs(n, True), np.ones(n, bool), None, training=False)
+            out, st = agent(_obs(n, False), np.zeros(n, bool), st, training=False)
+            acts.append(out["action"].clone())
+
+        evaluate(2)
+        out, st = agent(_obs(3, True), np.ones(3, bool), None, training=True)       # 3 updates, then acts
+        out, st = agent(_obs(3, False), np.zeros(3, bool), st, training=True)        # 2 updates
+        acts.append(out["action"].clone())
+        video = agent._wm.video_pred(common.make_batch(name, seed=99))
+        assert torch.isfinite(video).all()
+        sd = {k: v.detach().clone() for k, v in agent.state_dict().items()}
+        osd = tools.recursively_collect_optim_state_dict(agent)
+        agent.load_state_dict(sd)                                                  # (into the live agent: in place)
+        tools.recursively_load_optim_state_dict(agent, osd)
+        evaluate(2)
+        out, st = agent(_obs(3, False), np.zeros(3, bool), st, training=True)        # 1 update (not pipelined)
+        out, st = agent(_obs(4, True), np.ones(4, bool), None, training=True)        # 2 updates, another number of envs
+        acts.append(out["action"].clone())
+        evaluate(2)
+        torch.cuda.synchronize()
+        assert agent._update_count == 8
+        if replay:
+            assert agent._runner.use_graph and agent._runner._pipe is not None and agent._policy_runner not in (None, False)
+        else:
+            assert agent._runner._g_wm is None and agent._policy_runner in (None, False)
+        res.append((rng.state.clone(), {k: v.detach().clone() for k, v in agent.state_dict().items()}, acts))
+    (r0, p0, a0), (r1, p1, a1) = res
+    assert torch.equal(r0, r1), "the replayed run leaves the Philox stream elsewhere"
+    for k in p0:
+        d = (p0[k].double() - p1[k].double()).abs().max().item() if p0[k].numel() else 0.0
+        assert d <= 3e-4 + 1e-3 * p0[k].double().abs().max().item(), (k, d)
+    for x, y in zip(a0, a1):
+        assert x.shape == y.shape and torch.allclose(x, y, atol=2e-2), float((x - y).abs().max())
+
+
 def test_policy_graph_sees_a_state_the_caller_rewrote():
     """PolicyRunner keeps the carried state where the previous replay left it and skips the copy-in when the caller
     hands back exactly what it was given; a state edited in place (or any other tensors) must be copied in."""
