@@ -470,10 +470,11 @@ __global__ __launch_bounds__(256) void ln_act_bwd_vec_kernel(const float* __rest
                                                              const float* __restrict__ rstd_in,
                                                              float* __restrict__ dx, long lddx,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             long R, int N, int act, int accumulate_dx, int row_blocks) {
+                                                             long R, int N, int act, int accumulate_dx, int row_blocks,
+                                                             float* __restrict__ part) {
   constexpr int RPB = 256 / LPR;
   const int sub = threadIdx.x / LPR, l = threadIdx.x % LPR;
-  __shared__ float red[2][64 * kMaxV];
+  __shared__ __attribute__((aligned(16))) float red[2][64 * kMaxV];
   if ((int)blockIdx.x >= row_blocks) {  // column role: owns 64 columns of d-gamma / d-beta
     ln_bwd_cols(dy, lddy, x, ldx, gamma, beta, mean_in, rstd_in, dgamma, dbeta, R, N, act, (int)blockIdx.x - row_blocks,
                 &red[0][0]);
@@ -533,6 +534,42 @@ __global__ __launch_bounds__(256) void ln_act_bwd_vec_kernel(const float* __rest
       }
     }
   }
+  if (flush && part != nullptr) {
+    // two-stage form (dv3_ln_act_bwd_ws, N <= 512): this workgroup's column sums go to ITS row of the partial buffer
+    // with plain stores; ln_fold_partials_kernel adds the rows up.  (All row blocks adding onto the same N addresses
+    // instead serialise in the memory-side atomic unit -- 2048 x 2 N atomics on four cache lines at N = 64 -- and the
+    // LDS atomics in front of them are compare-and-swap loops: together +40 us on a 37 us kernel.)  The block's own
+    // reduction without atomics: the lane groups of a wave hold the same columns for different rows (xor shuffles over
+    // the group stride), then the four waves meet in LDS ([wave][2][N] floats = the 16 KB of `red`).
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) {
+        pg[v].x += __shfl_xor(pg[v].x, off); pg[v].y += __shfl_xor(pg[v].y, off);
+        pg[v].z += __shfl_xor(pg[v].z, off); pg[v].w += __shfl_xor(pg[v].w, off);
+        pb[v].x += __shfl_xor(pb[v].x, off); pb[v].y += __shfl_xor(pb[v].y, off);
+        pb[v].z += __shfl_xor(pb[v].z, off); pb[v].w += __shfl_xor(pb[v].w, off);
+      }
+    }
+    float* w4 = &red[0][0];
+    const int wave = threadIdx.x >> 6, wl = threadIdx.x & 63;
+    __syncthreads();  // (the zeroing pass above used red)
+    if (wl < LPR) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = 4 * (wl + LPR * v);
+        if (c < N) {
+          *reinterpret_cast<f4*>(w4 + (long)(wave * 2 + 0) * N + c) = pg[v];
+          *reinterpret_cast<f4*>(w4 + (long)(wave * 2 + 1) * N + c) = pb[v];
+        }
+      }
+    }
+    __syncthreads();
+    float* row = part + (long)blockIdx.x * 2 * N;
+    for (int c = threadIdx.x; c < 2 * N; c += 256)
+      row[c] = (w4[c] + w4[2 * N + c]) + (w4[4 * N + c] + w4[6 * N + c]);
+    return;
+  }
   if (flush) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -549,6 +586,37 @@ __global__ __launch_bounds__(256) void ln_act_bwd_vec_kernel(const float* __rest
       atomicAdd(dgamma + c, red[0][c]);
       atomicAdd(dbeta + c, red[1][c]);
     }
+  }
+}
+
+// Second stage of dv3_ln_act_bwd_ws: part [nb][2 N] -> dgamma / dbeta (+=).  grid (column blocks of 64, row slices);
+// lane = column, the 4 waves split the slice's rows, 8 rows in flight per lane; one atomic per column and slice.
+constexpr int kFoldSlices = 16;
+__global__ __launch_bounds__(256) void ln_fold_partials_kernel(const float* __restrict__ part, int nb, int N,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + lane, W = 2 * N;
+  const bool ok = c < W;
+  const int cc = ok ? c : 0;
+  const int per = (nb + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int r_beg = blockIdx.y * per, r_end = min(nb, r_beg + per);
+  float sum = 0.f;
+  for (int r0 = r_beg + wave; r0 < r_end; r0 += 32) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = r0 + 4 * k;
+      v[k] = (r < r_end) ? part[(long)r * W + cc] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += v[k];
+  }
+  red[wave][lane] = sum;
+  __syncthreads();
+  if (wave == 0 && ok) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    atomicAdd((c < N) ? dgamma + c : dbeta + (c - N), t);
   }
 }
 
@@ -985,35 +1053,60 @@ extern "C" int dv3_ln_act_fwd(const float* x, long ldx, const float* gamma, cons
   return (int)hipGetLastError();
 }
 
-extern "C" int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
-                              const float* beta, const float* mean, const float* rstd, float* dx, long lddx,
-                              float* dgamma, float* dbeta, long R, int N, int act, int chw_group, int accumulate_dx,
-                              void* stream) {
+constexpr long kLnPartRows = 2048;  // row blocks of the vectorised backward (its grid cap) = rows of the partial buffer
+
+static int ln_act_bwd_impl(const float* dy, long lddy, const float* x, long ldx, const float* gamma, const float* beta,
+                           const float* mean, const float* rstd, float* dx, long lddx, float* dgamma, float* dbeta,
+                           long R, int N, int act, int chw_group, int accumulate_dx, float* ws, long ws_floats,
+                           void* stream) {
   if (R <= 0) return 0;
   if (N <= 0 || N > 64 * kMaxV || !x || !dy || !dx || !gamma || !beta || !mean || !rstd) return DV3_ERR_ARG;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return DV3_ERR_ARG;
+  if (ws && ws_floats < kLnPartRows * 2 * N) return DV3_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   {
     int lpr0, nv0;
     if (chw_group <= 0 && vec_shape(N, lpr0, nv0)) {
-      // with parameter gradients every block ends with N atomics per array onto the same N addresses: few,
-      // fat blocks (256) keep that contention off the critical path; without them use the whole chip
-      // d-gamma / d-beta: wide rows (N >= 256) get column-role workgroups -- flushing N atomics per row-role
-      // workgroup is what dominates there; narrow rows (conv channels, R up to 1M) keep the atomic flush from
-      // few fat workgroups, which is cheap for small N and does not re-read the (HBM-bound) inputs.
-      // (Never when dx overwrites dy in place: the column role re-reads dy while the row role writes dx.)
-      const bool col_role = dgamma && dx != dy && N >= 256;
-      // narrow rows flush only N (< 256) atomics per workgroup: the grid can stay wide (HBM-bound at R ~ 1M)
-      const long cap = (dgamma && !col_role && N >= 128) ? 256 : 2048;
+      // d-gamma / d-beta WITHOUT a workspace: every block ends with N atomics per array onto the same N addresses:
+      // few, fat blocks (256) keep that contention off the critical path for N >= 128; wide rows (N >= 256) get
+      // column-role workgroups instead (they re-read the inputs); narrow rows keep the wide grid and pay the
+      // serialised atomics.  (Never the column role when dx overwrites dy in place: it re-reads dy while the row
+      // role writes dx.)  WITH a workspace (dv3_ln_act_bwd_ws): partial rows + a second, column-parallel launch.
+      const bool two_stage = ws != nullptr && dgamma != nullptr;
+      const bool col_role = !two_stage && dgamma && dx != dy && N >= 256;
+      const long cap = (!two_stage && dgamma && !col_role && N >= 128) ? 256 : kLnPartRows;
       const int col_blocks = col_role ? ((N + 63) / 64) * (int)((R + kColRoleRows - 1) / kColRoleRows) : 0;
+      float* part = two_stage ? ws : nullptr;
+      int nb = 0;
       DV3_LNV_DISPATCH(ln_act_bwd_vec_kernel, cap, col_blocks, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma,
-                       dbeta, R, N, act, accumulate_dx, (int)blocks_);
+                       dbeta, R, N, act, accumulate_dx, (nb = (int)blocks_), part);
+      if (two_stage) {
+        const int slices = nb >= 256 ? kFoldSlices : 1;
+        hipLaunchKernelGGL(ln_fold_partials_kernel, dim3((2 * N + 63) / 64, slices), dim3(256), 0, s, part, nb, N, dgamma,
+                           dbeta);
+      }
       return (int)hipGetLastError();
     }
   }
   DV3_LN_DISPATCH(launch_ln_bwd, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, R, N, act, chw_group,
                   accumulate_dx, s);
   return (int)hipGetLastError();
+}
+
+extern "C" int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
+                              const float* beta, const float* mean, const float* rstd, float* dx, long lddx,
+                              float* dgamma, float* dbeta, long R, int N, int act, int chw_group, int accumulate_dx,
+                              void* stream) {
+  return ln_act_bwd_impl(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, R, N, act, chw_group,
+                         accumulate_dx, nullptr, 0, stream);
+}
+
+extern "C" int dv3_ln_act_bwd_ws(const float* dy, long lddy, const float* x, long ldx, const float* gamma,
+                                 const float* beta, const float* mean, const float* rstd, float* dx, long lddx,
+                                 float* dgamma, float* dbeta, long R, int N, int act, int chw_group, int accumulate_dx,
+                                 float* ws, long ws_floats, void* stream) {
+  return ln_act_bwd_impl(dy, lddy, x, ldx, gamma, beta, mean, rstd, dx, lddx, dgamma, dbeta, R, N, act, chw_group,
+                         accumulate_dx, ws, ws_floats, stream);
 }
 
 static int gru_fwd_impl(const float* p, long ldp, const float* gamma, const float* beta, const float* h, long ldh,

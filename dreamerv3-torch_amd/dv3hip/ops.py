@@ -518,11 +518,37 @@ def ln_act_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma=None, dbeta=None, *, a
         _contig(dgamma, "dgamma"), _contig(dbeta, "dbeta")
         if dgamma.numel() != N or dbeta.numel() != N:
             raise ValueError("dgamma size mismatch")
+    key = "dv3_ln_act_bwd" + (f"[{R}x{N}{' +dgamma' if dgamma is not None else ''}]" if PROFILE.by_shape else "")
+    if (dgamma is not None and not chw_group and N % 4 == 0 and 16 <= N <= _LN_PART_MAXN and R * N >= _LN_PART_MIN
+            and _LN_TWO_STAGE):
+        # big activations (the conv stacks' channel LayerNorms, the 14 k-row head layers): parameter gradients through
+        # per-block partial rows and a second launch instead of contended atomics (tools/ln_bench.py: 262 k x 64
+        # 78 -> 45 us, 1 M x 32 107 -> 93, 65 k x 128 46 -> 27)
+        ws = _ln_partials(x.device)
+        _call("dv3_ln_act_bwd_ws", _ptr(dy), lddy, _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx),
+              lddx, _ptr(dgamma), _ptr(dbeta), R, N, int(act), 0, int(accumulate_dx), _ptr(ws), ws.numel(), _stream(),
+              key=key, nbytes=12.0 * R * N)
+        return dx
     _call("dv3_ln_act_bwd", _ptr(dy), lddy, _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx),
-          lddx, _ptr(dgamma), _ptr(dbeta), R, N, int(act), int(chw_group), int(accumulate_dx), _stream(),
-          key="dv3_ln_act_bwd" + (f"[{R}x{N}{' +dgamma' if dgamma is not None else ''}]" if PROFILE.by_shape else ""),
+          lddx, _ptr(dgamma), _ptr(dbeta), R, N, int(act), int(chw_group), int(accumulate_dx), _stream(), key=key,
           nbytes=12.0 * R * N)
     return dx
+
+
+# Partial-sum buffers of dv3_ln_act_bwd_ws ([2048 row blocks][2 N] floats, contents irrelevant between launches): one
+# per launch stream -- two lanes may run a LayerNorm backward at the same time.
+_LN_TWO_STAGE = _dev.flag("DV3_LN_TWO_STAGE", True)
+_LN_PART_MAXN, _LN_PART_MIN = 512, 2 * 1024 * 1024
+_LN_PART = {}
+
+
+def _ln_partials(device):
+    key = (str(device), _stream())
+    t = _LN_PART.get(key)
+    if t is None:
+        t = torch.empty(2048 * 2 * _LN_PART_MAXN, dtype=F32, device=device)
+        _LN_PART[key] = t
+    return t
 
 
 def gru_fwd(p, gamma, beta, h, h_new, mean, rstd, *, next_blend=None):

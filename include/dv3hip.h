@@ -97,6 +97,17 @@ int dv3_ln_act_fwd(const float* x, long ldx, const float* gamma, const float* be
 int dv3_ln_act_bwd(const float* dy, long lddy, const float* x, long ldx, const float* gamma, const float* beta,
                    const float* mean, const float* rstd, float* dx, long lddx, float* dgamma, float* dbeta,
                    long R, int N, int act, int chw_group, int accumulate_dx, void* stream);
+/* dv3_ln_act_bwd with a workspace for the parameter gradients (two launches): ws (device, >= 4096 N floats, contents
+ * irrelevant) receives one row of 2 N column sums per row block, written with plain stores; a second, column-parallel
+ * launch adds the rows up into dgamma / dbeta (+=).  Without it every row block adds its sums onto the same N addresses:
+ * up to 2048 blocks x 2 N device-scope atomics on a few cache lines, +18-40 us per launch on the conv stacks' channel
+ * LayerNorms (37 us without the parameter gradients at 262 k x 64).  One workspace per stream (launches that may overlap
+ * must not share it).  Same reference seams as dv3_ln_act_bwd: the .grad accumulation of nn.LayerNorm / ImgChLayerNorm
+ * weights under loss.backward() (tools.py:765; networks.py:631-633, 801-810). */
+int dv3_ln_act_bwd_ws(const float* dy, long lddy, const float* x, long ldx, const float* gamma, const float* beta,
+                      const float* mean, const float* rstd, float* dx, long lddx, float* dgamma, float* dbeta,
+                      long R, int N, int act, int chw_group, int accumulate_dx, float* ws, long ws_floats,
+                      void* stream);
 
 /* ---- LayerNorm-GRU gates -- GRUCell.forward (networks.py:760-768) ---------------------------------
  * p [M,3*De] is the output of the fused Linear on cat[x,h]; LN over all 3*De, then

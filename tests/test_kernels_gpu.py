@@ -448,6 +448,50 @@ def test_ln_act_fwd_bwd(ops, R, N, act):
     assert_close(db, bet.grad, tol=2e-4, what="ln dbeta")
 
 
+@pytest.mark.parametrize("R,N", [(70000, 32), (40000, 64), (20000, 128), (9000, 256), (5000, 512), (14336, 512)])
+def test_ln_bwd_parameter_gradients_in_two_stages(ops, R, N):
+    """dv3_ln_act_bwd_ws (big activations): every row block writes its column sums to its own row of a partial buffer, a
+    second launch adds the rows up.  Against torch autograd; three launches in a row accumulate; the same from a hipGraph
+    captured on a CU-masked lane (a stream that gets a partial buffer of its own)."""
+    from dv3hip import engine
+
+    assert R * N >= ops._LN_PART_MIN and ops._LN_TWO_STAGE
+    g = torch.Generator().manual_seed(R + N)
+    x = (torch.randn(R, N, generator=g) * 2 + 0.3).requires_grad_(True)
+    gam = (1 + 0.1 * torch.randn(N, generator=g)).requires_grad_(True)
+    bet = (0.1 * torch.randn(N, generator=g)).requires_grad_(True)
+    dy = torch.randn(R, N, generator=g)
+    F.silu(O.layer_norm(x, gam, bet)).backward(dy)
+    xd, gd, bd, dyd = dev(x.detach()), dev(gam.detach()), dev(bet.detach()), dev(dy)
+    y, mean, rstd = torch.empty(R, N).cuda(), torch.empty(R).cuda(), torch.empty(R).cuda()
+    ops.ln_act_fwd(xd, gd, bd, y, mean, rstd, act=True)
+    dx, dg, db = torch.empty(R, N).cuda(), torch.zeros(N).cuda(), torch.zeros(N).cuda()
+    ops.PROFILE.start()
+    for _ in range(3):
+        ops.ln_act_bwd(dyd, xd, gd, bd, mean, rstd, dx, dg, db, act=True)
+    assert list(ops.PROFILE.stop()) == ["dv3_ln_act_bwd"]
+    scale = float(gam.grad.abs().max()) + float(bet.grad.abs().max())
+    assert_close(dx, x.grad, what="ln dx")
+    assert float((dg / 3 - dev(gam.grad)).abs().max()) <= 3e-5 * scale + 1e-4, "d-gamma"
+    assert float((db / 3 - dev(bet.grad)).abs().max()) <= 3e-5 * scale + 1e-4, "d-beta"
+    ln = engine.Lanes.get(torch.device("cuda", 0))
+    if ln is None:
+        return
+    dg2, db2 = torch.zeros(N).cuda(), torch.zeros(N).cuda()
+    gr = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    n_bufs = len(ops._LN_PART)
+    with torch.cuda.graph(gr, stream=ln.streams["side"]):
+        ops.ln_act_bwd(dyd, xd, gd, bd, mean, rstd, dx, dg2, db2, act=True)
+    assert len(ops._LN_PART) >= n_bufs
+    with torch.cuda.stream(ln.streams["side"]):
+        gr.replay()
+        gr.replay()
+    torch.cuda.synchronize()
+    assert float((dg2 / 2 - dev(gam.grad)).abs().max()) <= 3e-5 * scale + 1e-4
+    assert float((db2 / 2 - dev(bet.grad)).abs().max()) <= 3e-5 * scale + 1e-4
+
+
 def test_ln_chw_flatten_matches_reference_order(ops):
     """Encoder output is flattened (C,H,W) (networks.py:494); our activations are NHWC."""
     n_img, G, C = 5, 16, 24
