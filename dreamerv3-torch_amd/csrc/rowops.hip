@@ -538,7 +538,8 @@ __global__ __launch_bounds__(256) void ln_act_bwd_vec_kernel(const float* __rest
     // two-stage form (dv3_ln_act_bwd_ws, N <= 512): this workgroup's column sums go to ITS row of the partial buffer
     // with plain stores; ln_fold_partials_kernel adds the rows up.  (All row blocks adding onto the same N addresses
     // instead serialise in the memory-side atomic unit -- 2048 x 2 N atomics on four cache lines at N = 64 -- and the
-    // LDS atomics in front of them are compare-and-swap loops: together +40 us on a 37 us kernel.)  The block's own
+    // ds_add_f32 reduction in front of them costs ~4 us per workgroup at N = 512 (4096 lane-atomics): together +40 us on
+    // a 37 us kernel.)  The block's own
     // reduction without atomics: the lane groups of a wave hold the same columns for different rows (xor shuffles over
     // the group stride), then the four waves meet in LDS ([wave][2][N] floats = the 16 KB of `red`).
 #pragma unroll
