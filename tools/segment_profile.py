@@ -7,7 +7,7 @@ segment on 128 compute units.  This tool launches the update's phases eagerly on
 around every launch (ops.PROFILE, keys by shape), tagged with the segment labels of engine.Cuts, and prints per segment
 the launches that make up its time with their rate against the lane's fp32 MFMA peak (78.6 TFLOP/s) or HBM share.
 
-    python tools/segment_profile.py [cfg2] [--whole]        # --whole: on the whole-chip stream instead
+    python tools/segment_profile.py [cfg2] [--whole] [--all]   # --whole: on the whole-chip stream; --all: every kernel
 """
 import os
 import sys
@@ -93,7 +93,7 @@ def main():
         tot_all += tot
         print(f"\n{seg}: {tot:.3f} ms in {sum(r_[1] for r_ in rows)} launches, {fl / 1e9:.1f} GFLOP "
               f"({fl / 1e9 / max(tot, 1e-9):.1f} TFLOP/s = {100 * fl / 1e9 / max(tot, 1e-9) / peak:.0f} % of the lane's peak)")
-        for key, n, f, b, ms in sorted(rows, key=lambda r_: -r_[4])[:14]:
+        for key, n, f, b, ms in sorted(rows, key=lambda r_: -r_[4])[:(10 ** 6 if "--all" in sys.argv else 14)]:
             us = ms * 1e3 / n
             rate = f"{f / 1e9 / ms:6.1f} TF/s ({100 * f / 1e9 / ms / peak:3.0f} %)" if f else (f"{b / 1e6 / ms:6.0f} GB/s" if b else "")
             print(f"   {ms:7.3f} ms  {n:4d} x {us:7.1f} us  {rate:22s} {key[:110]}")
