@@ -254,6 +254,7 @@ class gemm_group:
     def __init__(self, max_k: int = 2048, enabled: bool = True):
         self.max_k, self.enabled = max_k, enabled
         self.items, self.stream = [], None
+        self.sums = []  # the cluster's bias gradients (ops.colsum(..., accumulate=True)): one more grid at exit
 
     def __enter__(self):
         self._prev = gemm_group.current
@@ -293,12 +294,29 @@ class gemm_group:
             return r < M1 and c < N1  # (rectangle 2 starts at (r, c) >= (0, 0) of rectangle 1's grid)
         return True
 
+    def add_colsum(self, x, ldx, out, R, N, s):
+        if self.stream is not None and s != self.stream:
+            self.flush()
+        lo = out.data_ptr()
+        if len(self.sums) >= self.MAX or any(lo < q + 4 * m and q < lo + 4 * N for _, _, q, _, m in self.sums):
+            self.flush()
+        self.stream = s
+        self.sums.append((x.data_ptr(), ldx, lo, R, N))
+
     def flush(self):
+        import ctypes
+
+        sums, self.sums = self.sums, []
+        if sums:
+            n = len(sums)
+            col = lambda j, ty: (ty * n)(*[it[j] for it in sums])
+            _call("dv3_colsum_grouped", n, col(0, ctypes.c_void_p), col(1, ctypes.c_long), col(2, ctypes.c_void_p),
+                  col(3, ctypes.c_long), col(4, ctypes.c_int), self.stream,
+                  key="dv3_colsum_grouped" + (f"[{n} sums]" if PROFILE.by_shape else ""),
+                  nbytes=sum(4.0 * it[3] * it[4] for it in sums))
         items, self.items = self.items, []
         if not items:
             return
-        import ctypes
-
         n = len(items)
         col = lambda j, ty: (ty * n)(*[it[j] for it in items])
         flops = sum(2.0 * it[6] * it[7] * it[8] for it in items)
@@ -1046,6 +1064,10 @@ def colsum(x, out, *, accumulate=False):
     _contig(out, "out")
     if out.numel() != N:
         raise ValueError("out size mismatch")
+    grp = gemm_group.current
+    if grp is not None and accumulate and N > 32 and R >= 64:
+        grp.add_colsum(x, ldx, out, R, N, _stream())
+        return out
     _call("dv3_colsum", _ptr(x), ldx, _ptr(out), R, N, int(accumulate), _stream())
     return out
 

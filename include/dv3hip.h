@@ -206,6 +206,11 @@ int dv3_transpose01(const float* x, float* y, int B, int T, int k, void* stream)
 int dv3_concat6(const float* s0, long n0, const float* s1, long n1, const float* s2, long n2, const float* s3, long n3,
                 const float* s4, long n4, const float* s5, long n5, float* dst, void* stream);
 int dv3_colsum(const float* x, long ldx, float* out, long R, int N, int accumulate, void* stream);
+/* n <= 48 column sums out_g[N_g] += sum_r x_g[r][:] in ONE grid (the bias gradients of a cluster of weight gradients,
+ * see dv3_gemm_tn_grouped_f32).  The ARRAYS are host memory, the pointers inside x / out device memory; the out_g must
+ * not overlap.  Same seam as dv3_colsum: nn.Linear bias .grad under loss.backward() (tools.py:765). */
+int dv3_colsum_grouped(int n, const float* const* x, const long* ldx, float* const* out, const long* R, const int* N,
+                       void* stream);
 int dv3_tanh_fwd(const float* x, float* y, long n, void* stream);
 int dv3_tanh_bwd(const float* y, const float* dy, float* dx, long n, int accumulate, void* stream);
 

@@ -243,6 +243,19 @@ def test_grouped_weight_gradients_equal_the_single_launches(ops):
     w = a.double().t() @ b.double()
     w[:64] += a[:, :64].double().t() @ b.double()
     assert float((c.double() - w).abs().max()) <= 1e-3
+    # the cluster's bias gradients ride along: one more grid
+    g2 = torch.Generator().manual_seed(12)
+    xs = [dev(torch.randn(R_, N_ + 4, generator=g2))[:, :N_] for R_, N_ in ((1024, 512), (1000, 255), (14336, 512), (64, 33))]
+    outs2 = [dev(torch.randn(x.shape[1], generator=g2)) for x in xs]
+    want2 = [o.double() + x.double().sum(0) for o, x in zip(outs2, xs)]
+    ops.PROFILE.start()
+    with ops.gemm_group():
+        for x, o in zip(xs, outs2):
+            ops.colsum(x, o, accumulate=True)
+    k = ops.PROFILE.stop()
+    assert list(k) == ["dv3_colsum_grouped"] and k["dv3_colsum_grouped"]["launches"] == 1
+    for o, w in zip(outs2, want2):
+        assert float((o.double() - w).abs().max()) <= 1e-4 * (1.0 + float(w.abs().max()))
     # more than 48 products
     cs = [torch.zeros(64, 64, device="cuda") for _ in range(50)]
     a, b = dev(torch.randn(128, 64, generator=g)), dev(torch.randn(128, 64, generator=g))
